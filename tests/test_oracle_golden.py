@@ -1,0 +1,180 @@
+"""Pins the CPU oracle (oracle/ks_oracle.py) against fixtures produced by running
+the reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from conftest import csr_from, load_golden
+
+C128 = np.complex128
+TIGHT = dict(rtol=1e-12, atol=1e-13)
+
+
+def test_literal_matrices():
+    g = load_golden("g1_matrices")
+    for m in (2, 3, 10, 50):
+        ref = csr_from(g, f"mark{m}")
+        mine = oracle.mark_matrix(m)
+        mine.sort_indices()
+        assert mine.shape == ref.shape
+        assert mine.nnz == ref.nnz == (2 * m * (m - 1) if m > 2 else ref.nnz)
+        np.testing.assert_array_equal(mine.indptr, ref.indptr)
+        np.testing.assert_array_equal(mine.indices, ref.indices)
+        np.testing.assert_array_equal(mine.data, ref.data)  # bit-exact
+    # tests/test_matrices.py:10-28 literals
+    np.testing.assert_array_almost_equal(
+        oracle.mark_matrix(2).toarray(), [[0, 1, 1], [0.5, 0, 0], [0.5, 0, 0]]
+    )
+    lap = sp.csr_matrix(oracle.laplace_1d(5))
+    np.testing.assert_array_equal(lap.toarray(), csr_from(g, "laplace5").toarray())
+    np.testing.assert_array_equal(oracle.laplace_1d_eigen(5), g["laplace_eigen5"])
+    np.testing.assert_array_equal(oracle.laplace_1d_eigen(100), g["laplace_eigen100"])
+
+
+@pytest.mark.parametrize("tag,second", [("generic", False), ("near", True), ("inside", True)])
+def test_dgks_gs(tag, second):
+    g = load_golden("g5_dgks_gs")
+    V = np.asfortranarray(g["V"])
+    w = g[f"{tag}_w_in"].copy()
+    h = np.zeros(V.shape[1], C128)
+    beta, broke, again = oracle.dgks_gs(w, V, h, 1e-8)
+    assert again == second
+    assert broke == bool(g[f"{tag}_breakdown"])
+    np.testing.assert_allclose(h, g[f"{tag}_h"], **TIGHT)
+    if not broke:
+        np.testing.assert_allclose(beta, g[f"{tag}_beta"], rtol=1e-12)
+        np.testing.assert_allclose(w, g[f"{tag}_w_out"], **TIGHT)
+    else:
+        assert beta < 1e-8 and g[f"{tag}_beta"] < 1e-8
+
+
+def test_arnoldi_expand_mark10():
+    g = load_golden("g4_arnoldi")
+    A = csr_from(g, "mark10")
+    m = 6
+    V = np.zeros((A.shape[0], m + 1), C128, order="F")
+    H = np.zeros((m + 1, m), C128)
+    V[:, 0] = g["mark10_v0"]
+    _, _, n_iter = oracle.arnoldi_expand(A, V, H, 1e-8)
+    assert n_iter == int(g["mark10_niter"]) == m
+    np.testing.assert_allclose(V, g["mark10_V"], **TIGHT)
+    np.testing.assert_allclose(H, g["mark10_H"], **TIGHT)
+
+    # resume seam (start_dim), as used by every restart
+    V2 = np.zeros_like(V)
+    H2 = np.zeros_like(H)
+    V2[:, 0] = g["mark10_v0"]
+    oracle.arnoldi_expand(A, V2, H2, 1e-8, max_dim=3)
+    np.testing.assert_allclose(V2, g["mark10_V_first3"], **TIGHT)
+    np.testing.assert_allclose(H2, g["mark10_H_first3"], **TIGHT)
+    oracle.arnoldi_expand(A, V2, H2, 1e-8, start_dim=3, max_dim=m)
+    np.testing.assert_allclose(V2, g["mark10_V_resumed"], **TIGHT)
+    np.testing.assert_allclose(H2, g["mark10_H_resumed"], **TIGHT)
+
+
+def test_arnoldi_expand_complex_c_order_and_breakdown():
+    g = load_golden("g4_arnoldi")
+    A = csr_from(g, "cplx")
+    m = 6
+    V = np.zeros((10, m + 1), C128)  # C order, as tests/test_decomposition.py:81
+    H = np.zeros((m + 1, m), C128)
+    V[:, 0] = g["cplx_v0"]
+    _, _, n_iter = oracle.arnoldi_expand(A, V, H, 1e-8)
+    assert n_iter == int(g["cplx_niter"])
+    np.testing.assert_allclose(V, g["cplx_V"], **TIGHT)
+    np.testing.assert_allclose(H, g["cplx_H"], **TIGHT)
+
+    Vb = np.zeros((10, m + 1), C128, order="F")
+    Hb = np.zeros((m + 1, m), C128)
+    Vb[:, 0] = g["brk_v0"]
+    Vv, Hv, n_iter = oracle.arnoldi_expand(A, Vb, Hb, 1e-8)
+    assert n_iter == int(g["brk_niter"]) == 1
+    assert Vv.shape == tuple(g["brk_Vshape"]) and Hv.shape == tuple(g["brk_Hshape"])
+    np.testing.assert_allclose(Hb, g["brk_H"], **TIGHT)
+    np.testing.assert_allclose(Vb[:, 0], g["brk_V"][:, 0], **TIGHT)
+
+
+def test_ordered_schur():
+    g = load_golden("g6_ordered_schur")
+    for ch in ("F", "D"):
+        a = g[f"{ch}_a"]
+        T, Z = oracle.ordered_schur(a, output="complex", sort_function=lambda v: np.argsort(v))
+        assert T.dtype == np.dtype(ch) and Z.dtype == np.dtype(ch)
+        tol = 3000 * np.finfo(np.float32).eps if ch == "F" else 2000 * np.finfo(np.float64).eps
+        np.testing.assert_allclose(np.diag(T), [1, 2, 3, 4, 5], rtol=tol, atol=tol)
+        np.testing.assert_allclose(Z @ T @ Z.conj().T, a, rtol=tol, atol=tol)
+        np.testing.assert_allclose(T, g[f"{ch}_T"], rtol=tol, atol=tol)
+    a = g["hess_a"]
+    for tag, fn in (("lm", oracle.arg_largest_magnitude), ("lr", oracle.arg_largest_real)):
+        T, Z = oracle.ordered_schur(a, output="complex", sort_function=fn)
+        np.testing.assert_allclose(T, g[f"hess_{tag}_T"], **TIGHT)
+        np.testing.assert_allclose(Z, g[f"hess_{tag}_Z"], **TIGHT)
+    with pytest.raises(ValueError, match="not implemented"):
+        oracle.ordered_schur(np.eye(3), output="real")
+
+
+def _check_solve(A, g, prefix, seed, **kw):
+    np.random.seed(seed)
+    Q, T, hist = oracle.krylov_schur(A, **kw)
+    np.testing.assert_array_equal(hist.restarts, g[prefix + "hist_restarts"])
+    np.testing.assert_array_equal(hist.matvecs, g[prefix + "hist_matvecs"])
+    np.testing.assert_allclose(np.diag(T), np.diag(g[prefix + "T"]), rtol=1e-9, atol=1e-12)
+    _, _, rel = oracle.eig_residuals(A, Q, T)
+    ref_rel = g[prefix + "rel_residuals"]
+    assert rel.max() <= max(ref_rel.max() * 1.05, 1e-14)
+    return Q, T
+
+
+def test_krylov_schur_markov():
+    g = load_golden("g3_markov")
+    g1 = load_golden("g1_matrices")
+    A10 = csr_from(g1, "mark10")
+    _check_solve(A10, g, "mark10_s0_", 0, nev=3, max_dim=5,
+                 sort_function=oracle.arg_largest_real, max_restarts=1000)
+    A50 = csr_from(g1, "mark50")
+    for seed in (0, 1):
+        Q, T = _check_solve(A50, g, f"mark50_s{seed}_", seed, nev=5, max_dim=20,
+                            stopping_criterion=1e-8, sort_function=oracle.arg_largest_real)
+        np.testing.assert_allclose(T, g[f"mark50_s{seed}_T"], rtol=1e-6, atol=1e-9)
+    # survey G3 known answers (seed 0)
+    np.testing.assert_allclose(
+        np.diag(g["mark50_s0_T"]).real,
+        [1.0, 0.9975711513387, 0.9905798776378, 0.9798959915551, 0.9669245358333],
+        rtol=1e-10,
+    )
+    assert int(g["mark50_s0_hist_restarts"][0]) == 21
+    _check_solve(A50, g, "mark50_defaults_", 2, nev=4, sort_function=oracle.arg_largest_real)
+
+
+def test_krylov_schur_start_vector_stream():
+    g = load_golden("g3_markov")
+    np.random.seed(0)
+    v0 = oracle.random_unit_vector(1275, C128)
+    np.testing.assert_array_equal(v0, g["mark50_s0_v0"])  # bit-identical RNG stream
+
+
+def test_krylov_schur_dense_and_laplace_and_planted():
+    gd = load_golden("g2_dense_diag")
+    _check_solve(gd["diag_A"], gd, "diag_", 0, nev=3, max_dim=6,
+                 sort_function=oracle.arg_largest_real, max_restarts=1000)
+
+    g7 = load_golden("g7_laplace2d")
+    L = csr_from(g7, "lap")
+    _, T = _check_solve(L, g7, "lap_", 0, nev=10, max_dim=40,
+                        sort_function=oracle.arg_largest_magnitude)
+    got = np.sort(np.diag(T).real)
+    np.testing.assert_allclose(got, g7["lap_analytic"][:10], rtol=1e-8)
+
+
+def test_not_converged_message():
+    g = load_golden("g9_errors")
+    rng = np.random.default_rng(1234)
+    n = 2000
+    idx = np.sort(rng.integers(0, n, (n, 5)), axis=1).astype(np.int32)
+    A = sp.csr_matrix((rng.uniform(-1, 1, (n, 5)).ravel(), idx.ravel(),
+                       np.arange(0, 5 * n + 1, 5, dtype=np.int32)), shape=(n, n))
+    np.random.seed(0)
+    with pytest.raises(ValueError) as e:
+        oracle.krylov_schur(A, 5, max_dim=20, max_restarts=3)
+    assert str(e.value) == str(g["not_converged"]) == "Has not converged !"
