@@ -1,0 +1,123 @@
+"""ctypes binding of libarnoldi_hip.so (the C ABI in include/arnoldi_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this
+module raises.  Build with ``make -C arnoldi-py_amd`` (or
+``python -c "import __graft_entry__ as g; g.build()"``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+ABI_VERSION = 1
+MAX_DIM = 128          # AKS_MAX_DIM
+MAX_TRUNC = 96         # AKS_MAX_TRUNC
+SPMV_TILE_NNZ = 256    # AKS_SPMV_TILE_NNZ
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libarnoldi_hip.so")
+
+
+class HipLibraryError(RuntimeError):
+    """libarnoldi_hip.so is missing, stale, or returned an error status."""
+
+
+class WsLayout(C.Structure):
+    _fields_ = [
+        ("total_bytes", C.c_int64),
+        ("ctrl_off", C.c_int64),
+        ("red1_off", C.c_int64),
+        ("red2_off", C.c_int64),
+        ("red3_off", C.c_int64),
+        ("partial_off", C.c_int64),
+        ("n_blocks", C.c_int32),
+        ("ld_partial", C.c_int32),
+        ("red_len", C.c_int32),
+        ("pad_", C.c_int32),
+    ]
+
+
+class Ctrl(C.Structure):
+    """Mirror of ``aks_ctrl`` (64 bytes)."""
+
+    _fields_ = [
+        ("broken", C.c_int32),
+        ("n_iter", C.c_int32),
+        ("steps_done", C.c_int32),
+        ("second_passes", C.c_int32),
+        ("beta_in", C.c_double),
+        ("beta", C.c_double),
+        ("reserved", C.c_double * 4),
+    ]
+
+
+_P = C.c_void_p
+_I32, _I64, _F64 = C.c_int32, C.c_int64, C.c_double
+
+# name -> (restype, argtypes); one entry per function declared in include/arnoldi_hip.h
+SIGNATURES = {
+    "aks_last_error": (C.c_char_p, []),
+    "aks_abi_version": (_I32, []),
+    "aks_workspace_layout": (C.c_int, [_I64, _I32, C.POINTER(WsLayout)]),
+    "aks_workspace_init": (C.c_int, [_P, _I64, _I64, _I32, _P]),
+    "aks_csr_plan_tiles": (_I64, [_P, _I64, _I32, _P, _I64]),
+    "aks_csr_spmv": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P, _I32, _P, _P]),
+    "aks_gs_project": (C.c_int, [_I64, _I32, _P, _I64, _P, _P, _I64, _I32, _P]),
+    "aks_gs_update_project": (C.c_int, [_I64, _I32, _P, _I64, _P, _P, _I64, _I32, _P]),
+    "aks_gs_update_norm": (C.c_int, [_I64, _I32, _P, _I64, _P, _F64, _P, _I64, _I32, _P]),
+    "aks_gs_finish": (C.c_int, [_I64, _I32, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
+    "aks_dgks_gs": (C.c_int, [_I64, _I32, _P, _I64, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
+    "aks_arnoldi_expand": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, _P, _I64, _P, _I64,
+                                     _I32, _I32, _F64, _F64, _P, _I64, _I32, _P]),
+    "aks_truncate": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P]),
+    "aks_gather_c128": (C.c_int, [_I64, _P, _P, _P, _P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library with typed entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: the HIP extension has not been built "
+                "(run `make -C arnoldi-py_amd`). There is no CPU fallback."
+            )
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover - depends on the machine
+            raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise HipLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        if lib.aks_abi_version() != ABI_VERSION:
+            raise HipLibraryError(
+                f"ABI mismatch: library {lib.aks_abi_version()} vs binding {ABI_VERSION}; rebuild"
+            )
+        _lib = lib
+    return _lib
+
+
+def check(status, what):
+    """Raise HipLibraryError for a negative status code."""
+    if status < 0:
+        msg = load().aks_last_error()
+        raise HipLibraryError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
+    return status
+
+
+def workspace_layout(n_rows, max_dim):
+    lay = WsLayout()
+    check(load().aks_workspace_layout(n_rows, max_dim, C.byref(lay)), "aks_workspace_layout")
+    return lay

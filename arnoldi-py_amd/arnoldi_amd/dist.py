@@ -1,0 +1,148 @@
+"""Row sharding across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The reference has no distributed code; this is the layout SURVEY 8(e) fixes:
+
+  * rows of V, w and of the CSR matrix are split into contiguous blocks, one per
+    rank; H, Qp and the whole host dense step are replicated;
+  * the only data-path collectives are (1) a sum all-reduce of the (J+1) complex
+    numbers [V^H w ; ||w||^2] after each Gram-Schmidt stage and (2) an exchange
+    of the x entries other shards need before each SpMV (all-to-all of packed
+    "ghost" entries; the local (diagonal-block) SpMV runs while it is in flight).
+
+Everything in this file is host logic (numpy planning + torch.distributed calls);
+it never touches matrix values on the CPU after the plan is built.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+
+
+# --------------------------------------------------------------------------- partition
+def row_offsets(n, world, indptr=None):
+    """Contiguous row blocks: offsets[r]..offsets[r+1].  Balanced by non-zeros when the
+    full ``indptr`` is known, else by rows."""
+    if indptr is None:
+        base, extra = divmod(n, world)
+        sizes = np.full(world, base, np.int64)
+        sizes[:extra] += 1
+        return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    indptr = np.asarray(indptr, dtype=np.int64)
+    nnz = indptr[-1]
+    # weight = nnz + rows (rows also cost: V panel traffic dominates)
+    w = indptr + np.arange(n + 1, dtype=np.int64) * max(1, int(nnz // max(n, 1)) * 4)
+    targets = w[-1] * np.arange(1, world, dtype=np.float64) / world
+    cuts = np.searchsorted(w, targets, side="left")
+    offs = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    return np.maximum.accumulate(offs)
+
+
+class GhostPlan:
+    """What one rank needs from the others for  y = A_local x.
+
+    ``diag``   CSR block with local column ids (0 .. n_local-1)
+    ``off``    CSR block whose column ids index the ghost buffer (0 .. n_ghost-1), or None
+    ``ghost_cols``   global column id of each ghost entry, sorted (=> grouped by owner)
+    ``recv_counts``  ghosts owned by each rank
+    """
+
+    def __init__(self, diag, off, ghost_cols, recv_counts):
+        self.diag, self.off = diag, off
+        self.ghost_cols, self.recv_counts = ghost_cols, recv_counts
+        self.n_ghost = int(ghost_cols.shape[0])
+
+
+def split_local_rows(A_rows, offsets, rank):
+    """Split this rank's row block (global column ids) into diagonal / off-diagonal CSR."""
+    A_rows = sp.csr_matrix(A_rows)
+    r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
+    assert A_rows.shape[0] == r1 - r0
+    cols = A_rows.indices.astype(np.int64)
+    local = (cols >= r0) & (cols < r1)
+    row_of = np.repeat(np.arange(A_rows.shape[0], dtype=np.int64), np.diff(A_rows.indptr))
+
+    def build(mask, new_cols, ncols):
+        counts = np.bincount(row_of[mask], minlength=A_rows.shape[0])
+        indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        return sp.csr_matrix((A_rows.data[mask], new_cols.astype(np.int32), indptr),
+                             shape=(A_rows.shape[0], max(int(ncols), 1)))
+
+    diag = build(local, cols[local] - r0, r1 - r0)
+    ghost_cols = np.unique(cols[~local])
+    if ghost_cols.size == 0:
+        return GhostPlan(diag, None, ghost_cols, np.zeros(len(offsets) - 1, np.int64))
+    off = build(~local, np.searchsorted(ghost_cols, cols[~local]), ghost_cols.size)
+    owner = np.searchsorted(offsets, ghost_cols, side="right") - 1
+    recv_counts = np.bincount(owner, minlength=len(offsets) - 1).astype(np.int64)
+    return GhostPlan(diag, off, ghost_cols, recv_counts)
+
+
+# --------------------------------------------------------------------------- communicator
+class Comm:
+    """Thin wrapper over a torch.distributed process group.
+
+    ``backend == "nccl"`` is RCCL on ROCm: device tensors go straight to the
+    collectives.  With ``gloo`` (CPU tests, or several test ranks sharing one GPU)
+    device tensors are staged through host memory.
+    """
+
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+
+    # -- small host-side exchanges used while building plans -----------------
+    def allgather_int64(self, values):
+        values = np.asarray(values, dtype=np.int64)
+        objs = [None] * self.size
+        dist.all_gather_object(objs, values, group=self.group)
+        return objs
+
+    def exchange_requests(self, ghost_cols, recv_counts):
+        """Tell every owner which of its entries this rank needs.  Returns, per peer,
+        the global ids that peer asked from us."""
+        chunks, pos = [], 0
+        for r in range(self.size):
+            chunks.append(ghost_cols[pos: pos + int(recv_counts[r])])
+            pos += int(recv_counts[r])
+        everyone = [None] * self.size
+        dist.all_gather_object(everyone, chunks, group=self.group)
+        return [everyone[peer][self.rank] for peer in range(self.size)]
+
+    # -- data-path collectives ---------------------------------------------------
+    def allreduce_sum_(self, t):
+        """In-place sum all-reduce of a small float64 device tensor (stream ordered on nccl)."""
+        if self.size == 1:
+            return
+        if self.backend == "nccl" or not t.is_cuda:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+
+    def alltoallv_start(self, send, send_counts, recv, recv_counts):
+        """Start  recv <- all-to-all(send)  on float64 views (2 doubles per complex).
+        Returns a handle for ``alltoallv_finish``."""
+        ss = [2 * int(c) for c in send_counts]
+        rs = [2 * int(c) for c in recv_counts]
+        if self.backend == "nccl" or not send.is_cuda:
+            return dist.all_to_all_single(recv, send, rs, ss, group=self.group, async_op=True)
+        hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(hr, hs, rs, ss, group=self.group)
+        recv.copy_(hr)
+        return None
+
+    @staticmethod
+    def alltoallv_finish(handle):
+        if handle is not None:
+            handle.wait()
+
+    def barrier(self):
+        if self.size > 1:
+            dist.barrier(group=self.group)

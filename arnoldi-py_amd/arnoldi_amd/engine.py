@@ -1,0 +1,205 @@
+"""Device engine behind ``partial_schur`` / ``arnoldi_decomposition``.
+
+``ArnoldiContext`` owns one row shard's basis V, the device copy of H and the
+workspace, and exposes the two O(n) seams of the reference's driver:
+
+  * ``expand(H, start, end, tol)``  == arnoldi_decomposition(A, V, H, tol,
+    start_dim=start, max_dim=end)              (src/arnoldi/decomposition.py:13-68)
+  * ``truncate(Qp, m, p)``          == V[:, :p] = V[:, :m] @ Qp ; V[:, p] = V[:, m]
+                                                   (src/arnoldi/krylov_schur.py:78,81)
+
+With one rank and a CSR operator the whole expansion is one C call
+(``aks_arnoldi_expand``) that enqueues every kernel with no host round trip; with
+several ranks the same stage kernels are chained from Python with an RCCL
+all-reduce of the (J+1)-vector between stages.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _hip, device as dev
+from .dist import Comm, row_offsets, split_local_rows
+
+C128 = np.complex128
+
+
+class CsrOperator:
+    """CSR operator resident in HBM, row-sharded over ``comm`` (or whole on one GPU)."""
+
+    def __init__(self, A=None, *, local_rows=None, offsets=None, comm=None, device=None):
+        self.comm = comm
+        world = comm.size if comm is not None else 1
+        rank = comm.rank if comm is not None else 0
+        if local_rows is not None:
+            assert offsets is not None, "local_rows needs the global row offsets"
+            rows = dev.canonical_csr(local_rows)
+            self.offsets = np.asarray(offsets, dtype=np.int64)
+        else:
+            full = dev.canonical_csr(A)
+            assert full.shape[0] == full.shape[1]
+            self.offsets = (np.asarray(offsets, dtype=np.int64) if offsets is not None
+                            else row_offsets(full.shape[0], world, full.indptr if world > 1 else None))
+            rows = full[int(self.offsets[rank]): int(self.offsets[rank + 1])] if world > 1 else full
+        self.n = int(self.offsets[-1])
+        self.r0, self.r1 = int(self.offsets[rank]), int(self.offsets[rank + 1])
+        self.n_local = self.r1 - self.r0
+        self.dtype = rows.dtype
+        if world == 1:
+            self.diag = dev.DeviceCSR(rows, device)
+            self.off = None
+            self.n_ghost = 0
+            return
+        plan = split_local_rows(rows, self.offsets, rank)
+        self.diag = dev.DeviceCSR(plan.diag, device)
+        self.off = dev.DeviceCSR(plan.off, device) if plan.off is not None else None
+        self.n_ghost = plan.n_ghost
+        self.recv_counts = [int(c) for c in plan.recv_counts]
+        asked = comm.exchange_requests(plan.ghost_cols, plan.recv_counts)
+        self.send_counts = [int(a.shape[0]) for a in asked]
+        send_idx = (np.concatenate(asked) - self.r0).astype(np.int32) if sum(self.send_counts) else np.zeros(0, np.int32)
+        assert send_idx.size == 0 or (send_idx.min() >= 0 and send_idx.max() < self.n_local)
+        d = self.diag.device
+        self.send_idx = torch.from_numpy(send_idx).to(d)
+        self.n_send = int(send_idx.size)
+        self.sendbuf = torch.zeros(max(self.n_send, 1), dtype=torch.complex128, device=d)
+        self.ghostbuf = torch.zeros(max(self.n_ghost, 1), dtype=torch.complex128, device=d)
+        self.any_exchange = bool(sum(comm.allgather_int64([self.n_send + self.n_ghost])[r][0]
+                                     for r in range(world)))
+
+    @property
+    def nnz(self):
+        return self.diag.nnz + (self.off.nnz if self.off is not None else 0)
+
+    def algorithmic_bytes(self):
+        return self.diag.algorithmic_bytes() + (self.off.algorithmic_bytes() if self.off is not None else 0)
+
+    def apply(self, x, y, ws=None):
+        """y = A x for this shard's rows; x, y are columns of V (local rows)."""
+        if self.comm is None or self.comm.size == 1 or not self.any_exchange:
+            self.diag.spmv(x, y, False, ws)
+            return
+        if self.n_send:
+            dev.gather_c128(self.n_send, self.send_idx, x, self.sendbuf)
+        handle = self.comm.alltoallv_start(
+            self.sendbuf.view(torch.float64)[: 2 * self.n_send], self.send_counts,
+            self.ghostbuf.view(torch.float64)[: 2 * self.n_ghost], self.recv_counts)
+        self.diag.spmv(x, y, False, ws)          # overlaps the exchange
+        self.comm.alltoallv_finish(handle)
+        if self.off is not None:
+            self.off.spmv(self.ghostbuf, y, True, ws)
+
+
+class HostOperator:
+    """Opaque operator (LinearOperator, anything with ``@``): the matvec runs wherever the
+    caller's object runs it, through host memory.  Functional, not fast."""
+
+    def __init__(self, A, device=None):
+        self.A = A
+        self.n = int(A.shape[0])
+        self.n_local, self.r0, self.r1 = self.n, 0, self.n
+        self.comm = None
+        self.dtype = np.dtype(getattr(A, "dtype", C128))
+        self.offsets = np.array([0, self.n], np.int64)
+
+    def apply(self, x, y, ws=None):
+        hx = x[: self.n].cpu().numpy()
+        hy = np.asarray(self.A @ hx, dtype=C128).reshape(-1)
+        y[: self.n].copy_(torch.from_numpy(np.ascontiguousarray(hy)))
+
+
+def as_operator(A, comm=None, device=None):
+    if isinstance(A, (CsrOperator, HostOperator)):
+        return A
+    if dev.canonical_csr(A) is not None:
+        return CsrOperator(A, comm=comm, device=device)
+    if comm is not None and comm.size > 1:
+        raise TypeError("row-sharded solves need a sparse/dense matrix, not an opaque operator")
+    return HostOperator(A, device)
+
+
+class ArnoldiContext:
+    def __init__(self, op, max_dim, device=None):
+        if max_dim > _hip.MAX_DIM:
+            raise _hip.HipLibraryError(f"max_dim={max_dim} exceeds the kernels' limit {_hip.MAX_DIM}")
+        self.op = op
+        self.comm = op.comm
+        self.max_dim = int(max_dim)
+        self.basis = dev.KrylovBasis(op.n_local, max_dim, device)
+        self.ws = dev.Workspace(op.n_local, max_dim, device)
+        self.matvecs = 0
+
+    # -- seam 1 ------------------------------------------------------------------
+    def expand(self, H, start, end, tol, eta=dev.ETA_DGKS):
+        """Run Arnoldi steps j = start..end-1 on the device, then mirror the new columns
+        of H into the host array exactly as the reference's in-place writes would.
+        Returns n_iter (== end unless a step broke down)."""
+        b, ws, op = self.basis, self.ws, self.op
+        native = isinstance(op, CsrOperator) and (op.comm is None or op.comm.size == 1)
+        if native:
+            d = op.diag
+            rc = _hip.load().aks_arnoldi_expand(
+                b.n_rows, dev._ptr(d.indptr), dev._ptr(d.indices), dev._ptr(d.values), d.values_complex,
+                dev._ptr(d.tiles), d.n_tiles, d.lanes_per_row, dev._ptr(b.V), b.ldv, dev._ptr(b.H),
+                self.max_dim, start, end, tol, eta, dev._ptr(ws.buf), ws.nbytes, ws.max_dim, dev._stream())
+            _hip.check(rc, "aks_arnoldi_expand")
+        else:
+            hbase = b.H.data_ptr()
+            multi = self.comm is not None and self.comm.size > 1
+            for j in range(start, end):
+                J = j + 1
+                w = b.col(J)
+                op.apply(b.col(j), w, ws)
+                if not multi:
+                    dev.dgks_gs_device(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
+                    continue
+                dev.gs_project(b, J, w, ws)
+                self.comm.allreduce_sum_(ws.red(1, J + 1))
+                dev.gs_update_project(b, J, w, ws)
+                self.comm.allreduce_sum_(ws.red(2, J + 1))
+                dev.gs_update_norm(b, J, w, ws, eta)
+                self.comm.allreduce_sum_(ws.red(3, 1))
+                dev.gs_finish(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
+        Hd = b.download_H()
+        ctrl = ws.read_ctrl()
+        n_iter = int(ctrl.n_iter) if ctrl.broken else end
+        self.matvecs += n_iter - start
+        for j in range(start, n_iter):
+            rows = j + 1 if (ctrl.broken and j == n_iter - 1) else j + 2
+            H[:rows, j] = Hd[:rows, j]
+        self.last_ctrl = ctrl
+        return n_iter
+
+    # -- seam 2 ------------------------------------------------------------------
+    def truncate(self, Qp, m, p):
+        Qd = torch.from_numpy(np.ascontiguousarray(Qp, dtype=C128)).to(self.basis.device)
+        dev.truncate(self.basis, m, p, Qd)
+
+    # -- data movement --------------------------------------------------------------
+    def set_start_vector(self, v_full):
+        self.basis.set_col(0, v_full[self.op.r0: self.op.r1])
+
+    def local_columns(self, j0, j1):
+        return self.basis.get_cols(j0, j1)
+
+    def gather_columns(self, j0, j1):
+        """Full (n, j1-j0) host array on every rank."""
+        loc = self.local_columns(j0, j1)
+        if self.comm is None or self.comm.size == 1:
+            return np.asfortranarray(loc)
+        import torch.distributed as dist
+
+        parts = [None] * self.comm.size
+        dist.all_gather_object(parts, np.ascontiguousarray(loc), group=self.comm.group)
+        return np.asfortranarray(np.concatenate(parts, axis=0))
+
+
+def default_comm():
+    """Comm over the default process group when torch.distributed is up with > 1 rank."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return Comm()
+    return None

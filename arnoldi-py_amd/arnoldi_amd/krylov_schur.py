@@ -1,0 +1,120 @@
+"""Krylov-Schur partial Schur decomposition -- the drop-in entry point.
+
+Host driver with the reference's control flow (src/arnoldi/krylov_schur.py:10-114):
+argument defaults, assertions, the m x m Schur/reorder step (SciPy LAPACK on the
+host), H bookkeeping, convergence test, ``History`` and exceptions are the
+reference's; the two O(n) seams -- Arnoldi expansion and basis compression -- run on
+the MI355X through ``engine.ArnoldiContext``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+
+from .engine import ArnoldiContext, as_operator, default_comm
+from .history import History
+from .utils import arg_largest_magnitude, rand_normalized_vector, reorder_schur
+
+WORK_DTYPE = np.complex128  # krylov_schur.py:38: complex128 whatever A.dtype is
+
+
+def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts=100,
+                  sort_function=None, p=None, v0=None, comm=None, device=None, gather=True,
+                  stats=None):
+    """Compute ``nev`` Schur vectors ``Q`` and the ``nev x nev`` upper-triangular ``T``
+    with ``A Q ~= Q T`` by the Krylov-Schur algorithm.
+
+    Positional/keyword arguments up to ``p`` are the reference's.  Extra, optional,
+    keyword-only:
+
+    v0      start vector (length n); default ``rand_normalized_vector(n)`` (global RNG,
+            identical stream to the reference).
+    comm    ``dist.Comm`` for a row-sharded multi-GPU solve; default: the default
+            torch.distributed group if it is initialised with more than one rank.
+    device  torch device of this rank's GPU (default: current device).
+    gather  multi-GPU only: return the full ``Q`` on every rank (True) or just this
+            rank's rows (False).
+    stats   optional dict that receives ``restarts``, ``matvecs`` (true operator
+            applications), ``second_passes`` and the engine context (``ctx``).
+
+    Returns ``(Q, T, history)``; raises ``ValueError("Has not converged !")`` /
+    ``ValueError("Happy breakdown not supported yet")`` like the reference.
+    """
+    if stopping_criterion is None:
+        tol = np.sqrt(np.finfo(A.dtype).eps)        # krylov_schur.py:16-17
+    else:
+        tol = stopping_criterion
+    if sort_function is None:
+        sort_function = arg_largest_magnitude
+    assert max_restarts > 0
+
+    n = A.shape[0]
+    assert A.shape[1] == n
+    if max_dim is None:
+        max_dim = min(max(2 * nev + 1, 20), n)      # krylov_schur.py:29-30
+    if p is None:
+        p = min(nev + 5, max_dim - 1)               # size of the basis kept at a restart
+    assert nev <= p < max_dim
+
+    if comm is None:
+        comm = default_comm()
+    op = as_operator(A, comm=comm, device=device)
+    ctx = ArnoldiContext(op, max_dim, device)
+
+    # every rank draws the full vector so that the shards agree bit for bit with the
+    # single-GPU (and the reference's) start vector
+    start = rand_normalized_vector(n, WORK_DTYPE) if v0 is None else np.asarray(v0, dtype=WORK_DTYPE)
+    assert start.shape == (n,)
+    ctx.set_start_vector(start)
+
+    H = np.zeros((max_dim + 1, max_dim), dtype=WORK_DTYPE)
+    history = History.from_k(nev)
+    converged = False
+    restarts_run = 0
+
+    m = ctx.expand(H, 0, max_dim, tol)
+    for restart in range(max_restarts):
+        if m != max_dim:
+            raise ValueError("Happy breakdown not supported yet")   # krylov_schur.py:57-59
+        booked = restart * (max_dim - nev) + (m - nev)              # krylov_schur.py:63
+
+        # -- rotation: ordered Schur form of the projected matrix (host, LAPACK).
+        # The reference calls zgees twice (krylov_schur.py:69 and utils.py:45); the second
+        # call sees an upper-triangular matrix and returns (T, I) unchanged, so one call
+        # followed by the same ?trexc sequence gives the same (T, Q).
+        T, Q = scipy.linalg.schur(H[:m, :m], output="complex")
+        T, Q = reorder_schur(T, Q, sort_function(np.diag(T)))
+
+        # -- truncation (device): V[:, :p] <- V[:, :m] Q[:, :p];  V[:, p] <- V[:, m]
+        Qp = Q[:, :p]
+        ctx.truncate(Qp, m, p)
+
+        coupling = H[m, :m].copy()
+        last = H[m, m - 1]
+        H[:p, :p] = T[:p, :p]                                       # krylov_schur.py:83
+        H[p, :p] = coupling @ Qp                                    # krylov_schur.py:86-87
+        H[p, p:] = 0                                                # krylov_schur.py:88
+
+        # -- convergence (krylov_schur.py:91-101)
+        estimate = np.abs(last * Q[m - 1, :]) / np.abs(np.diag(T))
+        under = estimate[:nev] <= tol
+        history.matvecs[under] = booked
+        history.restarts[under] = restart + 1
+        restarts_run = restart + 1
+        converged = bool(np.all(estimate[:nev] < tol))
+        if converged:
+            break
+
+        m = ctx.expand(H, p, max_dim, tol)
+
+    if stats is not None:
+        stats.update(restarts=restarts_run, matvecs=ctx.matvecs, second_passes=int(ctx.last_ctrl.second_passes),
+                     ctx=ctx, tol=float(tol), max_dim=int(max_dim), p=int(p))
+    if not converged:
+        raise ValueError("Has not converged !")                      # krylov_schur.py:108-109
+
+    if comm is not None and comm.size > 1 and not gather:
+        Qout = np.asfortranarray(ctx.local_columns(0, nev))
+    else:
+        Qout = ctx.gather_columns(0, nev)
+    return Qout, H[:nev, :nev].copy(), history

@@ -1,0 +1,78 @@
+"""Host-side helpers of the Krylov-Schur driver (the O(m^3) part stays on the CPU by
+design: north_star "the small Hessenberg Schur/restart step left on the host via LAPACK").
+
+Interface mirror of src/arnoldi/utils.py: ``rand_normalized_vector`` (:7-13),
+``arg_largest_magnitude`` (:16-17), ``arg_largest_real`` (:20-21),
+``ordered_schur`` (:32-67).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+from scipy.linalg import lapack
+
+__all__ = [
+    "rand_normalized_vector",
+    "arg_largest_magnitude",
+    "arg_largest_real",
+    "ordered_schur",
+    "reorder_schur",
+]
+
+
+def rand_normalized_vector(n, dtype=np.float64):
+    """Unit 2-norm vector of ``n`` standard normals drawn from NumPy's *global* legacy
+    generator, so ``np.random.seed(s)`` gives the reference's start vector bit for bit."""
+    draws = np.random.randn(n)
+    vec = draws.astype(dtype)
+    vec /= np.linalg.norm(vec)
+    return vec
+
+
+def arg_largest_magnitude(x):
+    """Permutation that lists ``x`` by decreasing modulus ("LM")."""
+    return np.argsort(-np.abs(x))
+
+
+def arg_largest_real(x):
+    """Permutation that lists ``x`` by decreasing real part ("LR")."""
+    return np.argsort(-np.real(x))
+
+
+_SWAPPERS = {"F": lapack.ctrexc, "D": lapack.ztrexc, "f": lapack.strexc, "d": lapack.dtrexc}
+
+
+def reorder_schur(T, Z, order):
+    """Permute the diagonal of an upper-triangular (complex) Schur factor.
+
+    ``order[i]`` is the current diagonal position of the eigenvalue that must end up
+    at position ``i``.  Each misplaced eigenvalue is moved by one LAPACK ``?trexc``
+    call (1-based indices), front to back, exactly the sequence of unitary swaps the
+    reference performs (src/arnoldi/utils.py:49-63), so the resulting (T, Z) agree
+    with it to rounding and not merely up to a unitary change of basis.
+    """
+    swap = _SWAPPERS[np.asarray(T).dtype.char]
+    position = list(range(T.shape[0]))  # position[k] = original label sitting at slot k
+    for slot, label in enumerate(order):
+        at = position.index(label)
+        if at == slot:
+            continue
+        T, Z, info = swap(T, Z, at + 1, slot + 1)
+        if info != 0:
+            raise np.linalg.LinAlgError(f"?trexc failed with info={info}")
+        position.insert(slot, position.pop(at))
+    return T, Z
+
+
+def ordered_schur(a, output="real", *, sort_function=None):
+    """Schur decomposition ``a = Z T Z^H`` whose eigenvalues appear on ``diag(T)`` in the
+    order given by ``sort_function`` (default: largest magnitude first).
+
+    Only ``output="complex"`` is implemented, like the reference (utils.py:64-65).
+    """
+    if sort_function is None:
+        sort_function = arg_largest_magnitude
+    T, Z = scipy.linalg.schur(a, output=output)
+    if output != "complex":
+        raise ValueError("output!='complex' not implemented yet")
+    return reorder_schur(T, Z, sort_function(np.diag(T)))

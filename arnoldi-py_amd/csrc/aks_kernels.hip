@@ -1,0 +1,787 @@
+// libarnoldi_hip -- gfx950 (MI355X, CDNA4) kernels behind include/arnoldi_hip.h.
+//
+// Everything here is HBM-bound complex128 streaming work (0.17 - 5 flop/B):
+// the design goal is "every byte of V / CSR crosses HBM once per stage, in 16-byte
+// per-lane, 1-KiB per-wave coalesced loads, with enough of them in flight".
+//
+//   k_spmv          CSR-stream SpMV: one 64-lane wave per tile of <= 256 non-zeros;
+//                   indices/values are read coalesced, x is gathered (16 B/lane),
+//                   products are staged in LDS and rows are summed from LDS by
+//                   1..64 lanes per row.                (reference: decomposition.py:58)
+//   k_proj<NC>      tall-skinny  V[:, c0:c0+NC]^H w  with one lane per row and NC
+//                   complex accumulators per lane (exact NC: no masked loads), plus
+//                   ||w||^2.                            (ortho.py:92-94, 102)
+//   k_update_proj<NC>  w -= V h fused with the re-projection V^H w and ||w||^2: the
+//                   row's NC panel entries stay in registers between the two uses,
+//                   so the panel is read once instead of twice.   (ortho.py:96-98,102)
+//   k_update        w -= V h (any width) + ||w||^2.    (ortho.py:96-98 / 104-105)
+//   k_reduce        deterministic second stage of the block partial sums.
+//   k_finish        H column, beta, breakdown test, w /= beta.
+//                                                       (ortho.py:95,103,107; decomposition.py:61-66)
+//   k_truncate<PA>  V[:, :p] = V[:, :m] Qp in place (one lane owns a row), V[:, p] = V[:, m].
+//                                                       (krylov_schur.py:78,81)
+//
+// Reductions are two-stage (per-block partials, then one fixed-order sum): no float
+// atomics, so results are bitwise reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "arnoldi_hip.h"
+
+typedef double2 c128;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *what) {
+    g_err = what;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *where) {
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return AKS_ERR_HIP;
+}
+
+#define AKS_CHECK_LAUNCH(where)                                  \
+    do {                                                         \
+        hipError_t e_ = hipGetLastError();                       \
+        if (e_ != hipSuccess) return hip_fail(e_, where);        \
+    } while (0)
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+constexpr int MAX_ROW_BLOCKS = 1024;
+constexpr int NC_MAX = 32;  // widest exact-width panel kernel
+
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum `v` over the block's 4 waves; result valid in thread 0.  `scratch` holds >= WAVES doubles.
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) r += scratch[k];
+    }
+    return r;
+}
+
+__device__ __forceinline__ bool second_pass_needed(const c128 *red1, const c128 *red2, int J, double eta) {
+    // ortho.py:101   beta < beta_before * eta
+    return sqrt(red2[J].x) < sqrt(red1[J].x) * eta;
+}
+
+// ------------------------------------------------------------------ projection
+// partial[bx*ldp + c0 + c] = sum over this block's rows of conj(V[i, c0+c]) * w[i]
+// partial[bx*ldp + nrm_slot] = sum |w[i]|^2                    (only if nrm_slot >= 0)
+template <int NC>
+__global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *__restrict__ V, int64_t ldv,
+                                               const c128 *__restrict__ w, c128 *__restrict__ partial,
+                                               int ldp, int nrm_slot, const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl->broken) return;
+    __shared__ double red_re[WAVES][NC], red_im[WAVES][NC];
+    __shared__ double red_n[WAVES];
+    double ar[NC], ai[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ar[c] = ai[c] = 0.0;
+    double nrm = 0.0;
+    const c128 *Vc = V + (int64_t)c0 * ldv;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const c128 wv = w[i];
+        c128 v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = Vc[i + (int64_t)c * ldv];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            ar[c] = fma(v[c].x, wv.x, fma(v[c].y, wv.y, ar[c]));
+            ai[c] = fma(v[c].x, wv.y, fma(-v[c].y, wv.x, ai[c]));
+        }
+        nrm = fma(wv.x, wv.x, fma(wv.y, wv.y, nrm));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double sr = wave_sum(ar[c]);
+        const double si = wave_sum(ai[c]);
+        if (lane == 0) { red_re[wave][c] = sr; red_im[wave][c] = si; }
+    }
+    nrm = wave_sum(nrm);
+    if (lane == 0) red_n[wave] = nrm;
+    __syncthreads();
+    if (threadIdx.x < NC) {
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) { sr += red_re[k][threadIdx.x]; si += red_im[k][threadIdx.x]; }
+        partial[(int64_t)blockIdx.x * ldp + c0 + threadIdx.x] = make_double2(sr, si);
+    }
+    if (nrm_slot >= 0 && threadIdx.x == 64) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) s += red_n[k];
+        partial[(int64_t)blockIdx.x * ldp + nrm_slot] = make_double2(s, 0.0);
+    }
+}
+
+// ------------------------------------------------------------------ fused update + re-projection
+// w[i] -= sum_c V[i,c] h[c];  partial[.., c] = sum conj(V[i,c]) w'[i];  partial[.., NC] = sum |w'[i]|^2
+template <int NC>
+__global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__restrict__ V, int64_t ldv,
+                                                      c128 *__restrict__ w, const c128 *__restrict__ h,
+                                                      c128 *__restrict__ partial, int ldp,
+                                                      const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl->broken) return;
+    __shared__ double red_re[WAVES][NC], red_im[WAVES][NC];
+    __shared__ double red_n[WAVES];
+    __shared__ c128 hs[NC];
+    if (threadIdx.x < NC) hs[threadIdx.x] = h[threadIdx.x];
+    __syncthreads();
+    double ar[NC], ai[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ar[c] = ai[c] = 0.0;
+    double nrm = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        c128 wv = w[i];
+        c128 v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = V[i + (int64_t)c * ldv];
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const c128 hc = hs[c];
+            sr = fma(v[c].x, hc.x, fma(-v[c].y, hc.y, sr));
+            si = fma(v[c].x, hc.y, fma(v[c].y, hc.x, si));
+        }
+        wv.x -= sr;
+        wv.y -= si;
+        w[i] = wv;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            ar[c] = fma(v[c].x, wv.x, fma(v[c].y, wv.y, ar[c]));
+            ai[c] = fma(v[c].x, wv.y, fma(-v[c].y, wv.x, ai[c]));
+        }
+        nrm = fma(wv.x, wv.x, fma(wv.y, wv.y, nrm));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double sr = wave_sum(ar[c]);
+        const double si = wave_sum(ai[c]);
+        if (lane == 0) { red_re[wave][c] = sr; red_im[wave][c] = si; }
+    }
+    nrm = wave_sum(nrm);
+    if (lane == 0) red_n[wave] = nrm;
+    __syncthreads();
+    if (threadIdx.x < NC) {
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) { sr += red_re[k][threadIdx.x]; si += red_im[k][threadIdx.x]; }
+        partial[(int64_t)blockIdx.x * ldp + threadIdx.x] = make_double2(sr, si);
+    }
+    if (threadIdx.x == 64) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) s += red_n[k];
+        partial[(int64_t)blockIdx.x * ldp + NC] = make_double2(s, 0.0);
+    }
+}
+
+// ------------------------------------------------------------------ update (any width)
+// w[i] -= sum_{c<J} V[i,c] h[c];  partial[bx*ldp + nrm_slot] = sum |w'[i]|^2.
+// PRED: run only if the DGKS test asks for the second pass (ortho.py:101).
+template <bool PRED>
+__global__ __launch_bounds__(BLOCK) void k_update(int64_t n, int J, const c128 *__restrict__ V, int64_t ldv,
+                                                 c128 *__restrict__ w, const c128 *__restrict__ h,
+                                                 c128 *__restrict__ partial, int ldp, int nrm_slot,
+                                                 const c128 *__restrict__ red1, const c128 *__restrict__ red2,
+                                                 double eta, const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl->broken) return;
+    if (PRED && !second_pass_needed(red1, red2, J, eta)) return;
+    __shared__ c128 hs[AKS_MAX_DIM + 8];
+    __shared__ double red_n[WAVES];
+    const int Jpad = (J + 3) & ~3;
+    for (int c = threadIdx.x; c < Jpad; c += BLOCK) hs[c] = c < J ? h[c] : make_double2(0.0, 0.0);
+    __syncthreads();
+    double nrm = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        c128 wv = w[i];
+        double sr = 0.0, si = 0.0;
+        for (int c = 0; c < Jpad; c += 4) {
+            c128 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cc = min(c + u, J - 1);  // padded columns re-read a valid one; their h is 0
+                v[u] = V[i + (int64_t)cc * ldv];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const c128 hc = hs[c + u];
+                sr = fma(v[u].x, hc.x, fma(-v[u].y, hc.y, sr));
+                si = fma(v[u].x, hc.y, fma(v[u].y, hc.x, si));
+            }
+        }
+        wv.x -= sr;
+        wv.y -= si;
+        w[i] = wv;
+        nrm = fma(wv.x, wv.x, fma(wv.y, wv.y, nrm));
+    }
+    const double s = block_sum(nrm, red_n);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * ldp + nrm_slot] = make_double2(s, 0.0);
+}
+
+// ------------------------------------------------------------------ second-stage reduction
+// out[c] = sum_b partial[b*ldp + first + c], c = blockIdx.x < count; fixed order => reproducible.
+// PRED as in k_update (skips when no second pass ran, leaving `out` untouched).
+template <bool PRED>
+__global__ __launch_bounds__(BLOCK) void k_reduce(const c128 *__restrict__ partial, int n_blocks, int ldp,
+                                                 int first, c128 *__restrict__ out, int J,
+                                                 const c128 *__restrict__ red1, const c128 *__restrict__ red2,
+                                                 double eta, c128 *__restrict__ zero_slot,
+                                                 const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl->broken) return;
+    if (PRED && !second_pass_needed(red1, red2, J, eta)) return;
+    // keeps the (unconditionally all-reduced) red3 slot bounded when no second pass overwrites it
+    if (zero_slot != nullptr && blockIdx.x == 0 && threadIdx.x == 0) zero_slot[0] = make_double2(0.0, 0.0);
+    __shared__ double sc[WAVES];
+    const int c = blockIdx.x;
+    double sr = 0.0, si = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += BLOCK) {
+        const c128 p = partial[(int64_t)b * ldp + first + c];
+        sr += p.x;
+        si += p.y;
+    }
+    sr = block_sum(sr, sc);
+    si = block_sum(si, sc);
+    if (threadIdx.x == 0) out[c] = make_double2(sr, si);
+}
+
+// ------------------------------------------------------------------ finish
+__global__ __launch_bounds__(BLOCK) void k_finish(int64_t n, int J, c128 *__restrict__ w, c128 *__restrict__ Hcol,
+                                                 int64_t ldh, double tol, double eta, int normalize,
+                                                 const c128 *__restrict__ red1, const c128 *__restrict__ red2,
+                                                 const c128 *__restrict__ red3, aks_ctrl *__restrict__ ctrl) {
+    if (ctrl->broken) return;
+    const bool twice = second_pass_needed(red1, red2, J, eta);
+    const double beta = sqrt(twice ? red3[0].x : red2[J].x);
+    const bool broke = beta < tol;  // ortho.py:107
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < J; c += BLOCK) {
+            c128 hv = red1[c];  // ortho.py:95
+            if (twice) { hv.x += red2[c].x; hv.y += red2[c].y; }  // ortho.py:103
+            Hcol[(int64_t)c * ldh] = hv;
+        }
+        if (threadIdx.x == 0) {
+            if (!broke && normalize) Hcol[(int64_t)J * ldh] = make_double2(beta, 0.0);  // decomposition.py:65
+            ctrl->beta_in = sqrt(red1[J].x);
+            ctrl->beta = beta;
+            ctrl->steps_done += 1;
+            ctrl->second_passes += twice ? 1 : 0;
+            if (broke) { ctrl->n_iter = J; ctrl->broken = 1; }  // decomposition.py:61-63 (n_iter = j+1 = J)
+        }
+    }
+    if (broke || !normalize) return;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        c128 wv = w[i];
+        wv.x /= beta;  // decomposition.py:66 (true division, as numpy's complex / real)
+        wv.y /= beta;
+        w[i] = wv;
+    }
+}
+
+// ------------------------------------------------------------------ CSR-stream SpMV
+constexpr int TILE = AKS_SPMV_TILE_NNZ;  // non-zeros per wave tile
+constexpr int NPT = TILE / 64;           // per lane
+
+__device__ __forceinline__ c128 cmul(double a, c128 x) { return make_double2(a * x.x, a * x.y); }
+__device__ __forceinline__ c128 cmul(c128 a, c128 x) {
+    return make_double2(fma(a.x, x.x, -a.y * x.y), fma(a.x, x.y, a.y * x.x));
+}
+
+template <typename VT, bool ACC>
+__global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *__restrict__ indptr,
+                                               const int32_t *__restrict__ indices, const VT *__restrict__ vals,
+                                               const int32_t *__restrict__ tiles, int lpr,
+                                               const c128 *__restrict__ x, c128 *__restrict__ y,
+                                               const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl != nullptr && ctrl->broken) return;
+    __shared__ double pr[WAVES][TILE], pi[WAVES][TILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * WAVES + wave;
+    if (t >= n_tiles) return;  // waves are independent: no block-level barrier below
+    const int r0 = tiles[t], r1 = tiles[t + 1];
+    const int k0 = indptr[r0], k1 = indptr[r1];
+    const int nnz = k1 - k0;
+    if (nnz <= TILE) {
+        if (nnz > 0) {
+            int col[NPT];
+            VT a[NPT];
+            c128 xv[NPT];
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) {
+                const int k = min(k0 + q * 64 + lane, k1 - 1);
+                col[q] = indices[k];
+                a[q] = vals[k];
+            }
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) xv[q] = x[col[q]];
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) {
+                const int s = q * 64 + lane;
+                if (s < nnz) {
+                    const c128 p = cmul(a[q], xv[q]);
+                    pr[wave][s] = p.x;
+                    pi[wave][s] = p.y;
+                }
+            }
+        }
+        // LDS hand-off inside one wave: order the ds_writes before the ds_reads.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int rows_per_pass = 64 / lpr;
+        const int sub = lane % lpr;
+        for (int rb = r0; rb < r1; rb += rows_per_pass) {
+            const int r = rb + lane / lpr;
+            double sr = 0.0, si = 0.0;
+            if (r < r1) {
+                const int a0 = indptr[r] - k0, a1 = indptr[r + 1] - k0;
+                for (int s = a0 + sub; s < a1; s += lpr) {
+                    sr += pr[wave][s];
+                    si += pi[wave][s];
+                }
+            }
+            for (int off = lpr >> 1; off > 0; off >>= 1) {
+                sr += __shfl_xor(sr, off, 64);
+                si += __shfl_xor(si, off, 64);
+            }
+            if (r < r1 && sub == 0) {
+                if (ACC) {
+                    const c128 old = y[r];
+                    sr += old.x;
+                    si += old.y;
+                }
+                y[r] = make_double2(sr, si);
+            }
+        }
+    } else {
+        // one long row per tile: the wave strides over it
+        double sr = 0.0, si = 0.0;
+        for (int k = k0 + lane; k < k1; k += 64) {
+            const c128 p = cmul(vals[k], x[indices[k]]);
+            sr += p.x;
+            si += p.y;
+        }
+        sr = wave_sum(sr);
+        si = wave_sum(si);
+        if (lane == 0) {
+            if (ACC) {
+                const c128 old = y[r0];
+                sr += old.x;
+                si += old.y;
+            }
+            y[r0] = make_double2(sr, si);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ restart compression
+// One lane owns a row: it accumulates the p outputs while streaming the row's m inputs, and only
+// then overwrites columns 0..p-1 -- in place without an n x p temporary (krylov_schur.py:78).
+template <int PA>
+__global__ __launch_bounds__(BLOCK) void k_truncate(int64_t n, int m, int p, c128 *__restrict__ V, int64_t ldv,
+                                                   const c128 *__restrict__ Qp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    c128 *qs = reinterpret_cast<c128 *>(smem_raw);  // [m][PA], zero padded
+    for (int e = threadIdx.x; e < m * PA; e += BLOCK) {
+        const int k = e / PA, c = e - k * PA;
+        qs[e] = c < p ? Qp[(int64_t)k * p + c] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        double ar[PA], ai[PA];
+#pragma unroll
+        for (int c = 0; c < PA; ++c) ar[c] = ai[c] = 0.0;
+        int k = 0;
+        for (; k + 4 <= m; k += 4) {
+            c128 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = V[i + (int64_t)(k + u) * ldv];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const c128 *qrow = qs + (k + u) * PA;
+#pragma unroll
+                for (int c = 0; c < PA; ++c) {
+                    const c128 q = qrow[c];
+                    ar[c] = fma(v[u].x, q.x, fma(-v[u].y, q.y, ar[c]));
+                    ai[c] = fma(v[u].x, q.y, fma(v[u].y, q.x, ai[c]));
+                }
+            }
+        }
+        for (; k < m; ++k) {
+            const c128 v = V[i + (int64_t)k * ldv];
+            const c128 *qrow = qs + k * PA;
+#pragma unroll
+            for (int c = 0; c < PA; ++c) {
+                const c128 q = qrow[c];
+                ar[c] = fma(v.x, q.x, fma(-v.y, q.y, ar[c]));
+                ai[c] = fma(v.x, q.y, fma(v.y, q.x, ai[c]));
+            }
+        }
+        const c128 last = V[i + (int64_t)m * ldv];
+#pragma unroll
+        for (int c = 0; c < PA; ++c)
+            if (c < p) V[i + (int64_t)c * ldv] = make_double2(ar[c], ai[c]);
+        V[i + (int64_t)p * ldv] = last;  // krylov_schur.py:81
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gather(int64_t count, const int32_t *__restrict__ idx,
+                                                 const c128 *__restrict__ src, c128 *__restrict__ dst) {
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) dst[i] = src[idx[i]];
+}
+
+// ------------------------------------------------------------------ host-side plumbing
+struct Ws {
+    aks_ws_layout lay;
+    aks_ctrl *ctrl;
+    c128 *red1, *red2, *red3, *partial;
+};
+
+int bind_ws(void *d_ws, int64_t ws_bytes, int64_t n_rows, int32_t max_dim, Ws *out) {
+    if (d_ws == nullptr) return fail(AKS_ERR_ARG, "workspace pointer is null");
+    if ((reinterpret_cast<uintptr_t>(d_ws) & 255) != 0) return fail(AKS_ERR_ARG, "workspace must be 256-byte aligned");
+    int rc = aks_workspace_layout(n_rows, max_dim, &out->lay);
+    if (rc != AKS_OK) return rc;
+    if (ws_bytes < out->lay.total_bytes) return fail(AKS_ERR_ARG, "workspace too small (see aks_workspace_layout)");
+    char *base = static_cast<char *>(d_ws);
+    out->ctrl = reinterpret_cast<aks_ctrl *>(base + out->lay.ctrl_off);
+    out->red1 = reinterpret_cast<c128 *>(base + out->lay.red1_off);
+    out->red2 = reinterpret_cast<c128 *>(base + out->lay.red2_off);
+    out->red3 = reinterpret_cast<c128 *>(base + out->lay.red3_off);
+    out->partial = reinterpret_cast<c128 *>(base + out->lay.partial_off);
+    return AKS_OK;
+}
+
+int check_panel(int64_t n_rows, int32_t J, const void *V, int64_t ldv, const void *w, int32_t max_dim) {
+    if (n_rows <= 0) return fail(AKS_ERR_ARG, "n_rows must be positive");
+    if (J < 1 || J > max_dim) return fail(AKS_ERR_ARG, "J must satisfy 1 <= J <= max_dim");
+    if (max_dim > AKS_MAX_DIM) return fail(AKS_ERR_UNSUPPORTED, "max_dim exceeds AKS_MAX_DIM");
+    if (V == nullptr || w == nullptr) return fail(AKS_ERR_ARG, "null panel / vector pointer");
+    if (ldv < n_rows) return fail(AKS_ERR_ARG, "ldv < n_rows");
+    if ((reinterpret_cast<uintptr_t>(V) & 15) || (reinterpret_cast<uintptr_t>(w) & 15))
+        return fail(AKS_ERR_ARG, "complex128 arrays must be 16-byte aligned");
+    return AKS_OK;
+}
+
+template <int NC>
+void launch_proj_nc(dim3 grid, hipStream_t s, int64_t n, int c0, const c128 *V, int64_t ldv, const c128 *w,
+                    c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl) {
+    hipLaunchKernelGGL(k_proj<NC>, grid, dim3(BLOCK), 0, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl);
+}
+template <int NC>
+void launch_update_proj_nc(dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
+                           const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl) {
+    hipLaunchKernelGGL(k_update_proj<NC>, grid, dim3(BLOCK), 0, s, n, V, ldv, w, h, partial, ldp, ctrl);
+}
+
+#define AKS_NC_CASES(M) \
+    M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) \
+    M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31) M(32)
+
+void dispatch_proj(int nc, dim3 grid, hipStream_t s, int64_t n, int c0, const c128 *V, int64_t ldv,
+                   const c128 *w, c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl) {
+    switch (nc) {
+#define M(N) case N: launch_proj_nc<N>(grid, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl); break;
+        AKS_NC_CASES(M)
+#undef M
+        default: break;
+    }
+}
+
+void dispatch_update_proj(int nc, dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
+                          const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl) {
+    switch (nc) {
+#define M(N) case N: launch_update_proj_nc<N>(grid, s, n, V, ldv, w, h, partial, ldp, ctrl); break;
+        AKS_NC_CASES(M)
+#undef M
+        default: break;
+    }
+}
+
+// projection of all J columns in groups of <= NC_MAX columns of (nearly) equal width
+void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c128 *V, int64_t ldv,
+                        const c128 *w, c128 *red_out, c128 *zero_slot) {
+    const int groups = (J + NC_MAX - 1) / NC_MAX;
+    const int base = J / groups, extra = J % groups;
+    const dim3 grid(ws.lay.n_blocks);
+    int c0 = 0;
+    for (int g = 0; g < groups; ++g) {
+        const int nc = base + (g < extra ? 1 : 0);
+        dispatch_proj(nc, grid, s, n, c0, V, ldv, w, ws.partial, ws.lay.ld_partial, g == 0 ? J : -1, ws.ctrl);
+        c0 += nc;
+    }
+    hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
+                       ws.lay.ld_partial, 0, red_out, J, nullptr, nullptr, 0.0, zero_slot, ws.ctrl);
+}
+
+template <int PA>
+int launch_truncate(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_t ldv, const c128 *Qp) {
+    const size_t smem = (size_t)m * PA * sizeof(c128);
+    if (smem > 160 * 1024) return fail(AKS_ERR_UNSUPPORTED, "Qp does not fit the 160 KiB LDS");
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_truncate<PA>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_truncate)");
+    }
+    const int64_t want = (n + BLOCK - 1) / BLOCK;
+    const dim3 grid((unsigned)(want < 2048 ? want : 2048));
+    hipLaunchKernelGGL(k_truncate<PA>, grid, dim3(BLOCK), smem, s, n, m, p, V, ldv, Qp);
+    AKS_CHECK_LAUNCH("k_truncate");
+    return AKS_OK;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+const char *aks_last_error(void) { return g_err.c_str(); }
+int32_t aks_abi_version(void) { return AKS_ABI_VERSION; }
+
+int aks_workspace_layout(int64_t n_rows, int32_t max_dim, aks_ws_layout *out) {
+    if (out == nullptr) return fail(AKS_ERR_ARG, "layout pointer is null");
+    if (n_rows <= 0) return fail(AKS_ERR_ARG, "n_rows must be positive");
+    if (max_dim < 1 || max_dim > AKS_MAX_DIM) return fail(AKS_ERR_UNSUPPORTED, "max_dim outside [1, AKS_MAX_DIM]");
+    int64_t nb = (n_rows + BLOCK - 1) / BLOCK;
+    if (nb > MAX_ROW_BLOCKS) nb = MAX_ROW_BLOCKS;
+    const int32_t ld = max_dim + 2;
+    int64_t off = 0;
+    out->ctrl_off = off;                 off = align_up(off + (int64_t)sizeof(aks_ctrl), 256);
+    out->red1_off = off;                 off = align_up(off + (int64_t)ld * 16, 256);
+    out->red2_off = off;                 off = align_up(off + (int64_t)ld * 16, 256);
+    out->red3_off = off;                 off = align_up(off + 2 * 16, 256);
+    out->partial_off = off;              off = align_up(off + nb * ld * 16, 256);
+    out->total_bytes = off;
+    out->n_blocks = (int32_t)nb;
+    out->ld_partial = ld;
+    out->red_len = ld;
+    out->pad_ = 0;
+    return AKS_OK;
+}
+
+int aks_workspace_init(void *d_ws, int64_t ws_bytes, int64_t n_rows, int32_t max_dim, void *stream) {
+    Ws ws;
+    int rc = bind_ws(d_ws, ws_bytes, n_rows, max_dim, &ws);
+    if (rc != AKS_OK) return rc;
+    hipError_t e = hipMemsetAsync(d_ws, 0, (size_t)ws.lay.partial_off, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(workspace)");
+    return AKS_OK;
+}
+
+int64_t aks_csr_plan_tiles(const int32_t *indptr, int64_t n_rows, int32_t tile_nnz, int32_t *tiles_out,
+                           int64_t cap) {
+    if (indptr == nullptr || tiles_out == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    if (n_rows <= 0 || n_rows >= INT32_MAX) return fail(AKS_ERR_ARG, "n_rows out of range");
+    if (tile_nnz != AKS_SPMV_TILE_NNZ) return fail(AKS_ERR_ARG, "tile_nnz must be AKS_SPMV_TILE_NNZ");
+    const int64_t max_rows = 4 * tile_nnz;  // bounds the work of one wave on runs of empty rows
+    int64_t count = 0;
+    int64_t r = 0;
+    while (r < n_rows) {
+        if (count + 1 >= cap) return fail(AKS_ERR_ARG, "tiles_out too small");
+        tiles_out[count++] = (int32_t)r;
+        const int64_t k0 = indptr[r];
+        int64_t e = r + 1;  // a tile always holds at least one row (possibly longer than tile_nnz)
+        while (e < n_rows && e - r < max_rows && (int64_t)indptr[e + 1] - k0 <= tile_nnz) ++e;
+        r = e;
+    }
+    tiles_out[count] = (int32_t)n_rows;
+    return count;
+}
+
+int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const void *d_values,
+                 int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row,
+                 const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate, const void *d_ws, void *stream) {
+    if (n_rows <= 0 || n_tiles <= 0) return fail(AKS_ERR_ARG, "empty matrix");
+    if (!d_indptr || !d_indices || !d_values || !d_tiles || !d_x || !d_y) return fail(AKS_ERR_ARG, "null pointer");
+    if (d_x == d_y) return fail(AKS_ERR_ARG, "x and y must not alias");
+    int lpr = lanes_per_row;
+    if (lpr <= 0) lpr = 1;
+    if (lpr > 64 || (lpr & (lpr - 1)) != 0) return fail(AKS_ERR_ARG, "lanes_per_row must be a power of two <= 64");
+    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((n_tiles + WAVES - 1) / WAVES));
+    const c128 *x = reinterpret_cast<const c128 *>(d_x);
+    c128 *y = reinterpret_cast<c128 *>(d_y);
+    if (values_complex) {
+        const c128 *v = static_cast<const c128 *>(d_values);
+        if (accumulate)
+            hipLaunchKernelGGL((k_spmv<c128, true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
+        else
+            hipLaunchKernelGGL((k_spmv<c128, false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
+    } else {
+        const double *v = static_cast<const double *>(d_values);
+        if (accumulate)
+            hipLaunchKernelGGL((k_spmv<double, true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
+        else
+            hipLaunchKernelGGL((k_spmv<double, false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
+    }
+    AKS_CHECK_LAUNCH("k_spmv");
+    return AKS_OK;
+}
+
+int aks_gs_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, const aks_c128 *d_w,
+                   void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+    int rc = check_panel(n_rows, J, d_V, ldv, d_w, max_dim);
+    if (rc != AKS_OK) return rc;
+    Ws ws;
+    rc = bind_ws(d_ws, ws_bytes, n_rows, max_dim, &ws);
+    if (rc != AKS_OK) return rc;
+    enqueue_projection(static_cast<hipStream_t>(stream), ws, n_rows, J, reinterpret_cast<const c128 *>(d_V), ldv,
+                       reinterpret_cast<const c128 *>(d_w), ws.red1, ws.red3);
+    AKS_CHECK_LAUNCH("aks_gs_project");
+    return AKS_OK;
+}
+
+int aks_gs_update_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w,
+                          void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+    int rc = check_panel(n_rows, J, d_V, ldv, d_w, max_dim);
+    if (rc != AKS_OK) return rc;
+    Ws ws;
+    rc = bind_ws(d_ws, ws_bytes, n_rows, max_dim, &ws);
+    if (rc != AKS_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const c128 *V = reinterpret_cast<const c128 *>(d_V);
+    c128 *w = reinterpret_cast<c128 *>(d_w);
+    if (J <= NC_MAX) {
+        dispatch_update_proj(J, dim3(ws.lay.n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
+                             ws.lay.ld_partial, ws.ctrl);
+        hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
+                           ws.lay.ld_partial, 0, ws.red2, J, nullptr, nullptr, 0.0, nullptr, ws.ctrl);
+    } else {
+        // wide panel: update, then the grouped projection (one extra panel read)
+        hipLaunchKernelGGL(k_update<false>, dim3(ws.lay.n_blocks), dim3(BLOCK), 0, s, n_rows, J, V, ldv, w,
+                           ws.red1, ws.partial, ws.lay.ld_partial, J, nullptr, nullptr, 0.0, ws.ctrl);
+        enqueue_projection(s, ws, n_rows, J, V, ldv, w, ws.red2, nullptr);
+    }
+    AKS_CHECK_LAUNCH("aks_gs_update_project");
+    return AKS_OK;
+}
+
+int aks_gs_update_norm(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w, double eta,
+                       void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+    int rc = check_panel(n_rows, J, d_V, ldv, d_w, max_dim);
+    if (rc != AKS_OK) return rc;
+    Ws ws;
+    rc = bind_ws(d_ws, ws_bytes, n_rows, max_dim, &ws);
+    if (rc != AKS_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_update<true>, dim3(ws.lay.n_blocks), dim3(BLOCK), 0, s, n_rows, J,
+                       reinterpret_cast<const c128 *>(d_V), ldv, reinterpret_cast<c128 *>(d_w), ws.red2,
+                       ws.partial, ws.lay.ld_partial, 0, ws.red1, ws.red2, eta, ws.ctrl);
+    hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
+                       ws.lay.ld_partial, 0, ws.red3, J, ws.red1, ws.red2, eta, nullptr, ws.ctrl);
+    AKS_CHECK_LAUNCH("aks_gs_update_norm");
+    return AKS_OK;
+}
+
+int aks_gs_finish(int64_t n_rows, int32_t J, aks_c128 *d_w, aks_c128 *d_Hcol, int64_t ldh, double tol,
+                  double eta, int32_t normalize, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+    if (d_w == nullptr || d_Hcol == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    if (J < 1 || J > max_dim) return fail(AKS_ERR_ARG, "J must satisfy 1 <= J <= max_dim");
+    if (ldh < 1) return fail(AKS_ERR_ARG, "ldh must be positive");
+    Ws ws;
+    int rc = bind_ws(d_ws, ws_bytes, n_rows, max_dim, &ws);
+    if (rc != AKS_OK) return rc;
+    hipLaunchKernelGGL(k_finish, dim3(ws.lay.n_blocks), dim3(BLOCK), 0, static_cast<hipStream_t>(stream), n_rows, J,
+                       reinterpret_cast<c128 *>(d_w), reinterpret_cast<c128 *>(d_Hcol), ldh, tol, eta,
+                       (int)normalize, ws.red1, ws.red2, ws.red3, ws.ctrl);
+    AKS_CHECK_LAUNCH("k_finish");
+    return AKS_OK;
+}
+
+int aks_dgks_gs(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w, aks_c128 *d_Hcol,
+                int64_t ldh, double tol, double eta, int32_t normalize, void *d_ws, int64_t ws_bytes,
+                int32_t max_dim, void *stream) {
+    int rc = aks_gs_project(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream);
+    if (rc != AKS_OK) return rc;
+    rc = aks_gs_update_project(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream);
+    if (rc != AKS_OK) return rc;
+    rc = aks_gs_update_norm(n_rows, J, d_V, ldv, d_w, eta, d_ws, ws_bytes, max_dim, stream);
+    if (rc != AKS_OK) return rc;
+    return aks_gs_finish(n_rows, J, d_w, d_Hcol, ldh, tol, eta, normalize, d_ws, ws_bytes, max_dim, stream);
+}
+
+int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const void *d_values,
+                       int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row,
+                       aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh, int32_t start_dim,
+                       int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes, int32_t max_dim,
+                       void *stream) {
+    if (start_dim < 0 || end_dim > max_dim || start_dim > end_dim)
+        return fail(AKS_ERR_ARG, "need 0 <= start_dim <= end_dim <= max_dim");
+    if (d_V == nullptr || d_H == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    if (ldh < max_dim) return fail(AKS_ERR_ARG, "ldh < max_dim");
+    for (int32_t j = start_dim; j < end_dim; ++j) {
+        aks_c128 *x = d_V + (int64_t)j * ldv;
+        aks_c128 *w = d_V + (int64_t)(j + 1) * ldv;
+        int rc = aks_csr_spmv(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
+                              lanes_per_row, x, w, 0, d_ws, stream);
+        if (rc != AKS_OK) return rc;
+        rc = aks_dgks_gs(n_rows, j + 1, d_V, ldv, w, d_H + j, ldh, tol, eta, 1, d_ws, ws_bytes, max_dim, stream);
+        if (rc != AKS_OK) return rc;
+    }
+    return AKS_OK;
+}
+
+int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv, const aks_c128 *d_Qp,
+                 void *stream) {
+    if (n_rows <= 0 || d_V == nullptr || d_Qp == nullptr) return fail(AKS_ERR_ARG, "bad argument");
+    if (m < 1 || m > AKS_MAX_DIM) return fail(AKS_ERR_UNSUPPORTED, "m outside [1, AKS_MAX_DIM]");
+    if (p < 1 || p >= m + 1) return fail(AKS_ERR_ARG, "need 1 <= p <= m");
+    if (p > AKS_MAX_TRUNC) return fail(AKS_ERR_UNSUPPORTED, "p exceeds AKS_MAX_TRUNC");
+    if (ldv < n_rows) return fail(AKS_ERR_ARG, "ldv < n_rows");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    c128 *V = reinterpret_cast<c128 *>(d_V);
+    const c128 *Q = reinterpret_cast<const c128 *>(d_Qp);
+    if (p <= 8) return launch_truncate<8>(s, n_rows, m, p, V, ldv, Q);
+    if (p <= 16) return launch_truncate<16>(s, n_rows, m, p, V, ldv, Q);
+    if (p <= 24) return launch_truncate<24>(s, n_rows, m, p, V, ldv, Q);
+    if (p <= 32) return launch_truncate<32>(s, n_rows, m, p, V, ldv, Q);
+    if (p <= 48) return launch_truncate<48>(s, n_rows, m, p, V, ldv, Q);
+    if (p <= 64) return launch_truncate<64>(s, n_rows, m, p, V, ldv, Q);
+    return launch_truncate<96>(s, n_rows, m, p, V, ldv, Q);
+}
+
+int aks_gather_c128(int64_t count, const int32_t *d_idx, const aks_c128 *d_src, aks_c128 *d_dst, void *stream) {
+    if (count == 0) return AKS_OK;
+    if (count < 0 || !d_idx || !d_src || !d_dst) return fail(AKS_ERR_ARG, "bad argument");
+    const int64_t want = (count + BLOCK - 1) / BLOCK;
+    const dim3 grid((unsigned)(want < 4096 ? want : 4096));
+    hipLaunchKernelGGL(k_gather, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), count, d_idx,
+                       reinterpret_cast<const c128 *>(d_src), reinterpret_cast<c128 *>(d_dst));
+    AKS_CHECK_LAUNCH("k_gather");
+    return AKS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+/*
+ * arnoldi_hip.h -- C ABI of libarnoldi_hip.so (MI355X / gfx950).
+ *
+ * The library is the device half of a drop-in for
+ *     arnoldi.krylov_schur.partial_schur          (src/arnoldi/krylov_schur.py:10-114)
+ * of cournape/arnoldi-py.  Everything O(n) on that path runs in the HIP kernels
+ * behind these entry points; the O(m^3) Schur / reorder step stays on the host
+ * (LAPACK through SciPy) exactly as in the reference.
+ *
+ * Conventions
+ *   - Plain C types only.  Every pointer named  d_*  is DEVICE memory owned by
+ *     the caller (the Python host allocates it with torch; any hipMalloc'ed
+ *     buffer works).  `stream` is a hipStream_t passed as void* (NULL = the
+ *     default stream).  All launches are asynchronous on that stream; no entry
+ *     point synchronises or allocates, so a sequence of calls can be captured
+ *     into a hipGraph.
+ *   - complex128 is two consecutive doubles (re, im) -- numpy's layout.
+ *   - The Krylov basis V is column-major n x (m+1) with leading dimension ldv
+ *     (elements), i.e. numpy order="F" as in krylov_schur.py:42.  H is the
+ *     reference's row-major (m+1) x m array (krylov_schur.py:43), ld = ldh.
+ *   - Return value: AKS_OK (0) or a negative AKS_ERR_*; aks_last_error() gives
+ *     the text (thread-local).  No C++ exception crosses the boundary.
+ *   - Breakdown (reference: decomposition.py:61-63) is detected ON THE DEVICE:
+ *     the control block's `broken` word is set, `n_iter` records j+1, and every
+ *     later launch that is handed the same workspace becomes a no-op.  The host
+ *     reads the control block once per expansion.
+ */
+#ifndef ARNOLDI_HIP_H
+#define ARNOLDI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AKS_ABI_VERSION 1
+
+#define AKS_OK 0
+#define AKS_ERR_ARG (-1)         /* bad argument (null pointer, size, alignment) */
+#define AKS_ERR_HIP (-2)         /* a HIP runtime call / launch failed          */
+#define AKS_ERR_UNSUPPORTED (-3) /* size outside what the kernels are built for  */
+
+/* limits of this build */
+#define AKS_MAX_DIM 128          /* max_dim (m) supported by the kernels         */
+#define AKS_MAX_TRUNC 96         /* restart size p supported by aks_truncate     */
+#define AKS_SPMV_TILE_NNZ 256    /* non-zeros per wave tile (aks_csr_plan_tiles) */
+
+typedef struct aks_c128 { double re, im; } aks_c128;
+
+/* Device-resident control block at offset 0 of the workspace (64 bytes).
+ * Written only by kernels; the host copies it back after an expansion. */
+typedef struct aks_ctrl {
+    int32_t broken;        /* 1 once a step ended with beta < tol (breakdown)            */
+    int32_t n_iter;        /* j+1 of the step that broke down (valid iff broken)         */
+    int32_t steps_done;    /* Arnoldi steps completed since aks_workspace_init           */
+    int32_t second_passes; /* how many of them ran the DGKS second pass (ortho.py:101)   */
+    double beta_in;        /* ||w|| before orthogonalisation, last step (ortho.py:92)    */
+    double beta;           /* ||w|| after orthogonalisation, last step (ortho.py:98/105) */
+    double reserved[4];
+} aks_ctrl;
+
+/* Byte offsets of the workspace regions (all 256-byte aligned). */
+typedef struct aks_ws_layout {
+    int64_t total_bytes;
+    int64_t ctrl_off;      /* aks_ctrl                                                   */
+    int64_t red1_off;      /* (m+2) c128: [V^H w ; ||w||^2]       first projection       */
+    int64_t red2_off;      /* (m+2) c128: [V^H w'; ||w'||^2]      re-projection          */
+    int64_t red3_off;      /* 2 c128:     [||w''||^2]             norm after 2nd update  */
+    int64_t partial_off;   /* n_blocks x ld_partial c128 per-block partial sums          */
+    int32_t n_blocks;      /* row blocks used by the reduction kernels                   */
+    int32_t ld_partial;    /* m + 2                                                      */
+    int32_t red_len;       /* m + 2 (c128 elements in red1 / red2)                       */
+    int32_t pad_;
+} aks_ws_layout;
+
+const char *aks_last_error(void);
+int32_t aks_abi_version(void);
+
+/* ---- workspace ---------------------------------------------------------- */
+/* Pure host computation of the layout for a local row count and max_dim. */
+int aks_workspace_layout(int64_t n_rows, int32_t max_dim, aks_ws_layout *out);
+/* Zeroes the control block and the reduction slots (async on stream). */
+int aks_workspace_init(void *d_ws, int64_t ws_bytes, int64_t n_rows, int32_t max_dim, void *stream);
+
+/* ---- operator apply: replaces  w[:] = A @ V[:, j]  (decomposition.py:58) ---- */
+/* Host helper.  Cuts the rows of a CSR matrix into wave tiles of at most
+ * tile_nnz non-zeros (a longer row gets a tile of its own).  Writes the tile
+ * start rows, terminated by n_rows, to tiles_out (host memory, capacity `cap`
+ * entries) and returns the number of tiles, or a negative error. */
+int64_t aks_csr_plan_tiles(const int32_t *indptr_host, int64_t n_rows, int32_t tile_nnz,
+                           int32_t *tiles_out, int64_t cap);
+
+/* y = A x   (accumulate == 0)   or   y += A x   (accumulate != 0).
+ * CSR with int32 indptr/indices; values are float64 (values_complex == 0) or
+ * complex128; x, y are complex128.  d_tiles / n_tiles come from
+ * aks_csr_plan_tiles.  lanes_per_row is 1, 2, 4, ... 64 (0 = choose from the
+ * mean row length).  d_ws may be NULL; if given, the launch is a no-op once the
+ * control block says `broken`. */
+int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
+                 const void *d_values, int32_t values_complex, const int32_t *d_tiles,
+                 int64_t n_tiles, int32_t lanes_per_row, const aks_c128 *d_x, aks_c128 *d_y,
+                 int32_t accumulate, const void *d_ws, void *stream);
+
+/* ---- orthogonalisation: replaces dgks_gs (ortho.py:56-107) ---------------
+ * Stage entry points, in call order.  Between stages a multi-GPU host
+ * all-reduces the named slot over the row shards (RCCL); with one GPU the
+ * stages are simply chained (aks_dgks_gs below does that).
+ *
+ *   aks_gs_project        red1[0:J] = V[:, :J]^H w ; red1[J] = ||w||^2            (ortho.py:92-94)
+ *   aks_gs_update_project w -= V red1[0:J] ; red2[0:J] = V^H w ; red2[J] = ||w||^2 (ortho.py:96-98, 102)
+ *   aks_gs_update_norm    if sqrt(red2[J]) < eta*sqrt(red1[J]):                  (ortho.py:101,104-105)
+ *                              w -= V red2[0:J] ; red3[0] = ||w||^2
+ *   aks_gs_finish         h = red1 (+ red2 if second pass) -> H[0:J, j];         (ortho.py:95,103,107)
+ *                         beta -> ctrl; breakdown = beta < tol;
+ *                         if normalize != 0 and no breakdown, the caller's next two
+ *                         lines too: H[J, j] = beta and w /= beta              (decomposition.py:61-66)
+ */
+int aks_gs_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv,
+                   const aks_c128 *d_w, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream);
+int aks_gs_update_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv,
+                          aks_c128 *d_w, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream);
+int aks_gs_update_norm(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv,
+                       aks_c128 *d_w, double eta, void *d_ws, int64_t ws_bytes, int32_t max_dim,
+                       void *stream);
+int aks_gs_finish(int64_t n_rows, int32_t J, aks_c128 *d_w, aks_c128 *d_Hcol, int64_t ldh,
+                  double tol, double eta, int32_t normalize, void *d_ws, int64_t ws_bytes,
+                  int32_t max_dim, void *stream);
+
+/* All four stages chained (single GPU).  d_Hcol points at H[0, j]; the kernel
+ * writes H[i*ldh] for i <= J. */
+int aks_dgks_gs(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w,
+                aks_c128 *d_Hcol, int64_t ldh, double tol, double eta, int32_t normalize,
+                void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream);
+
+/* ---- Arnoldi expansion: replaces arnoldi_decomposition (decomposition.py:13-68)
+ * for j in [start_dim, end_dim):  V[:, j+1] = A V[:, j]; dgks_gs; normalise.
+ * Single GPU, no host synchronisation; results (H columns, control block) are
+ * read back by the caller afterwards. */
+int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
+                       const void *d_values, int32_t values_complex, const int32_t *d_tiles,
+                       int64_t n_tiles, int32_t lanes_per_row, aks_c128 *d_V, int64_t ldv,
+                       aks_c128 *d_H, int64_t ldh, int32_t start_dim, int32_t end_dim, double tol,
+                       double eta, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream);
+
+/* ---- restart compression: replaces krylov_schur.py:78 and :81 --------------
+ * V[:, :p] = V[:, :m] @ Qp   (in place, row-block by row-block)   and
+ * V[:, p]  = V[:, m].   d_Qp is m x p complex128, row-major (ld = p). */
+int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv,
+                 const aks_c128 *d_Qp, void *stream);
+
+/* ---- small utilities used by the host driver --------------------------------
+ * dst[i] = src[idx[i]]  -- packs the x entries another row shard needs
+ * before the SpMV exchange (multi-GPU). */
+int aks_gather_c128(int64_t count, const int32_t *d_idx, const aks_c128 *d_src, aks_c128 *d_dst,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARNOLDI_HIP_H */

@@ -1,0 +1,402 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures produced by the reference.  Run on the MI355X box: ``pytest -m gpu``.
+
+Tolerances: the kernels sum in a different order from OpenBLAS / sparsetools, so
+floating-point results are compared to a few ulps of the problem scale (1e-12
+relative), and solver-level results by the north_star criterion: same restart
+count, eigenvalues to 1e-9, and  max_k ||A v_k - l_k v_k|| / |l_k|  <= 1.05 x the
+reference's own residual (with a 1e-13 floor for residuals at rounding level).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from conftest import csr_from, load_golden
+
+pytestmark = pytest.mark.gpu
+
+C128 = np.complex128
+RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import arnoldi_amd
+    from arnoldi_amd import _hip
+
+    _hip.load()  # fail loudly if the extension is missing
+    return arnoldi_amd
+
+
+def _relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+# ---------------------------------------------------------------------------- SpMV
+def _ragged_matrix(n, seed, complex_vals):
+    """Rows of very different lengths: empty rows, short rows, one row longer than a tile,
+    a run of empty rows longer than a tile's row cap."""
+    rng = np.random.default_rng(seed)
+    lengths = rng.integers(0, 12, n)
+    lengths[rng.integers(0, n, n // 10)] = 0
+    lengths[5] = 700            # longer than AKS_SPMV_TILE_NNZ
+    lengths[17] = 256           # exactly one tile
+    lengths[18] = 257
+    lengths[100:1300] = 0       # > 4*256 consecutive empty rows
+    lengths = np.minimum(lengths, n)
+    indptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+    cols = np.concatenate([np.sort(rng.choice(n, L, replace=False)) for L in lengths if L > 0] or [np.zeros(0, int)])
+    vals = rng.standard_normal(cols.size)
+    if complex_vals:
+        vals = vals + 1j * rng.standard_normal(cols.size)
+    return sp.csr_matrix((vals, cols.astype(np.int32), indptr), shape=(n, n))
+
+
+@pytest.mark.parametrize("complex_vals", [False, True])
+@pytest.mark.parametrize("lanes", [0, 1, 4, 64])
+def test_spmv_ragged(amd, complex_vals, lanes):
+    import torch
+    from arnoldi_amd.device import DeviceCSR
+
+    n = 3000
+    A = _ragged_matrix(n, 3, complex_vals)
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(C128)
+    y0 = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(C128)
+    dA = DeviceCSR(A, lanes_per_row=lanes)
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.from_numpy(y0).cuda()
+    dA.spmv(dx, dy)
+    ref = oracle.csr_matvec(A, x)
+    assert _relerr(dy.cpu().numpy(), ref) < RTOL
+    # rows without entries must be written as zeros, not left alone
+    empty = np.diff(A.indptr) == 0
+    assert np.all(dy.cpu().numpy()[empty] == 0)
+    dA.spmv(dx, dy, accumulate=True)
+    assert _relerr(dy.cpu().numpy(), 2 * ref) < RTOL
+
+
+def test_spmv_configs_small(amd):
+    """Config-shaped matrices at oracle-friendly sizes: Markov, 2-D/3-D Laplace, random CSR."""
+    import torch
+    from arnoldi_amd import matrices
+    from arnoldi_amd.device import DeviceCSR
+
+    rng = np.random.default_rng(1)
+    for A in (matrices.mark(50), matrices.laplace2d(60, 67), matrices.laplace3d(11, 12, 13),
+              matrices.random_csr(50_000, 5, 1234), sp.csr_matrix(rng.standard_normal((40, 40)))):
+        A = sp.csr_matrix(A)
+        n = A.shape[0]
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(C128)
+        dA = DeviceCSR(A)
+        dx, dy = torch.from_numpy(x).cuda(), torch.empty(n, dtype=torch.complex128, device="cuda")
+        dA.spmv(dx, dy)
+        assert _relerr(dy.cpu().numpy(), oracle.csr_matvec(A, x)) < RTOL
+
+
+# ---------------------------------------------------------------------------- Gram-Schmidt
+@pytest.mark.parametrize("tag,second", [("generic", False), ("near", True), ("inside", True)])
+def test_dgks_gs_golden(amd, tag, second):
+    from arnoldi_amd.ortho import dgks_gs
+
+    g = load_golden("g5_dgks_gs")
+    V = g["V"]
+    w = g[f"{tag}_w_in"].copy()
+    h = np.zeros(V.shape[1], C128)
+    info = {}
+    beta, broke = dgks_gs(w, V, h, 1e-8, info=info)
+    assert info["second_pass"] == second
+    assert broke == bool(g[f"{tag}_breakdown"])
+    np.testing.assert_allclose(h, g[f"{tag}_h"], rtol=1e-11, atol=1e-13)
+    if not broke:
+        np.testing.assert_allclose(beta, g[f"{tag}_beta"], rtol=1e-9)
+        np.testing.assert_allclose(w, g[f"{tag}_w_out"], rtol=1e-9, atol=1e-13)
+    else:
+        assert beta < 1e-8
+
+
+@pytest.mark.parametrize("J", [1, 2, 7, 20, 31, 32, 33, 40, 64, 65, 100, 128])
+@pytest.mark.parametrize("n", [257, 5003])
+def test_dgks_gs_widths(amd, J, n):
+    """Every panel width class: exact-width fused kernels (J <= 32), grouped projections and
+    the un-fused update (J > 32); n not a multiple of the block size."""
+    from arnoldi_amd.ortho import dgks_gs
+
+    if J >= n:
+        pytest.skip("panel wider than tall")
+    rng = np.random.default_rng(J * 1000 + n)
+    Vq, _ = np.linalg.qr(rng.standard_normal((n, J)) + 1j * rng.standard_normal((n, J)))
+    V = np.asfortranarray(Vq.astype(C128))
+    for scale in (1.0, 1e-4):  # 1e-4: nearly in span(V) -> second pass
+        w0 = (V @ (rng.standard_normal(J) + 1j * rng.standard_normal(J))
+              + scale * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(C128)
+        w_ref, h_ref = w0.copy(), np.zeros(J, C128)
+        beta_ref, broke_ref, again_ref = oracle.dgks_gs(w_ref, V, h_ref, 1e-8)
+        w, h, info = w0.copy(), np.zeros(J, C128), {}
+        beta, broke = dgks_gs(w, V, h, 1e-8, info=info)
+        assert (broke, info["second_pass"]) == (broke_ref, again_ref)
+        np.testing.assert_allclose(h, h_ref, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(beta, beta_ref, rtol=1e-8)
+        assert _relerr(w, w_ref) < 1e-8
+        assert np.abs(V.conj().T @ w).max() < 1e-12 * max(1.0, np.linalg.norm(w0))
+
+
+# ---------------------------------------------------------------------------- Arnoldi seam
+def test_arnoldi_decomposition_golden(amd):
+    from arnoldi_amd.decomposition import arnoldi_decomposition
+
+    g = load_golden("g4_arnoldi")
+    A = csr_from(g, "mark10")
+    m = 6
+    V = np.zeros((A.shape[0], m + 1), C128, order="F")
+    H = np.zeros((m + 1, m), C128)
+    V[:, 0] = g["mark10_v0"]
+    Va, Ha, n_iter = arnoldi_decomposition(A, V, H, 1e-8)
+    assert n_iter == m and Va.shape == (55, m + 1) and Ha.shape == (m + 1, m)
+    np.testing.assert_allclose(V, g["mark10_V"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(H, g["mark10_H"], rtol=1e-10, atol=1e-12)
+
+    # max_dim truncation + resume from start_dim (the restart seam)
+    V2, H2 = np.zeros_like(V), np.zeros_like(H)
+    V2[:, 0] = g["mark10_v0"]
+    Va, Ha, k = arnoldi_decomposition(A, V2, H2, 1e-8, max_dim=3)
+    assert k == 3 and Va.shape == (55, 4) and Ha.shape == (4, 3)
+    np.testing.assert_allclose(V2, g["mark10_V_first3"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(H2, g["mark10_H_first3"], rtol=1e-10, atol=1e-12)
+    arnoldi_decomposition(A, V2, H2, 1e-8, start_dim=3, max_dim=m)
+    np.testing.assert_allclose(V2, g["mark10_V_resumed"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(H2, g["mark10_H_resumed"], rtol=1e-10, atol=1e-12)
+
+
+def test_arnoldi_decomposition_complex_c_order_and_breakdown(amd):
+    from arnoldi_amd.decomposition import arnoldi_decomposition
+
+    g = load_golden("g4_arnoldi")
+    A = csr_from(g, "cplx")
+    m = 6
+    V = np.zeros((10, m + 1), C128)  # C-ordered, as the reference's tests allocate it
+    H = np.zeros((m + 1, m), C128)
+    V[:, 0] = g["cplx_v0"]
+    _, _, n_iter = arnoldi_decomposition(A, V, H, 1e-8)
+    assert n_iter == int(g["cplx_niter"])
+    np.testing.assert_allclose(V, g["cplx_V"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(H, g["cplx_H"], rtol=1e-10, atol=1e-12)
+    # reference invariants (tests/test_decomposition.py:36-68)
+    Vm, Hm = V[:, :m], H[:m, :m]
+    np.testing.assert_allclose(Vm.conj().T @ Vm, np.eye(m), rtol=1e-4, atol=1e-8)
+    e_m = np.zeros(m); e_m[-1] = 1
+    np.testing.assert_allclose(A @ Vm, Vm @ Hm + H[-1, -1] * np.outer(V[:, -1], e_m), rtol=1e-4, atol=1e-8)
+
+    # start vector = eigenvector -> breakdown in the first step (test_decomposition.py:115-139)
+    Vb = np.zeros((10, m + 1), C128, order="F")
+    Hb = np.zeros((m + 1, m), C128)
+    Vb[:, 0] = g["brk_v0"]
+    Vv, Hv, n_iter = arnoldi_decomposition(A, Vb, Hb, 1e-8)
+    assert n_iter == 1
+    assert Vv.shape == tuple(g["brk_Vshape"]) and Hv.shape == tuple(g["brk_Hshape"])
+    np.testing.assert_allclose(Hb[0, 0], g["brk_H"][0, 0], rtol=1e-10)
+    assert Hb[1, 0] == 0  # H[j+1, j] is not written on breakdown (decomposition.py:61-63)
+    assert np.all(Vb[:, 2:] == 0)  # later steps were no-ops on the device
+
+
+# ---------------------------------------------------------------------------- truncation
+@pytest.mark.parametrize("m,p", [(5, 4), (6, 5), (20, 10), (40, 15), (41, 25), (50, 40), (80, 65), (100, 85)])
+def test_truncate(amd, m, p):
+    import torch
+    from arnoldi_amd import device as dev
+
+    n = 1500 if m < 60 else 700
+    rng = np.random.default_rng(m * 100 + p)
+    V = (rng.standard_normal((n, m + 1)) + 1j * rng.standard_normal((n, m + 1))).astype(C128)
+    Qp = (rng.standard_normal((m, p)) + 1j * rng.standard_normal((m, p))).astype(C128)
+    basis = dev.KrylovBasis(n, m)
+    basis.set_cols(0, V)
+    dev.truncate(basis, m, p, torch.from_numpy(Qp).cuda())
+    out = basis.get_cols(0, m + 1)
+    expect = V.copy()
+    expect[:, :p] = V[:, :m] @ Qp          # krylov_schur.py:78
+    expect[:, p] = V[:, m]                  # krylov_schur.py:81
+    assert _relerr(out[:, : p + 1], expect[:, : p + 1]) < RTOL
+    np.testing.assert_array_equal(out[:, p + 1:], V[:, p + 1:])  # untouched columns
+
+
+# ---------------------------------------------------------------------------- full solves
+def _solve_and_compare(amd, A, g, prefix, seed, expect_same_restarts=True, **kw):
+    np.random.seed(seed)
+    stats = {}
+    Q, T, hist = amd.partial_schur(A, stats=stats, **kw)
+    assert Q.shape == (A.shape[0], kw["nev"]) and Q.flags.f_contiguous and Q.dtype == C128
+    assert T.shape == (kw["nev"], kw["nev"]) and T.dtype == C128
+    if expect_same_restarts:
+        np.testing.assert_array_equal(hist.restarts, g[prefix + "hist_restarts"])
+        np.testing.assert_array_equal(hist.matvecs, g[prefix + "hist_matvecs"])
+    np.testing.assert_allclose(np.diag(T), np.diag(g[prefix + "T"]), rtol=1e-9, atol=1e-12)
+    _, _, rel = oracle.eig_residuals(A, Q, T)
+    ref_rel = g[prefix + "rel_residuals"]
+    assert rel.max() <= max(1.05 * ref_rel.max(), 1e-13), (rel, ref_rel)
+    np.testing.assert_allclose(Q.conj().T @ Q, np.eye(kw["nev"]), atol=1e-12)
+    return Q, T, hist, stats
+
+
+def test_partial_schur_markov_golden(amd):
+    g = load_golden("g3_markov")
+    g1 = load_golden("g1_matrices")
+    LR = oracle.arg_largest_real
+    _solve_and_compare(amd, csr_from(g1, "mark10"), g, "mark10_s0_", 0, nev=3, max_dim=5,
+                       sort_function=LR, max_restarts=1000)
+    A50 = csr_from(g1, "mark50")
+    for seed in (0, 1):  # README configuration (BASELINE config 1)
+        _, _, hist, stats = _solve_and_compare(amd, A50, g, f"mark50_s{seed}_", seed, nev=5, max_dim=20,
+                                               stopping_criterion=1e-8, sort_function=LR)
+        # true operator applications: m + R (m - p)   
+        assert stats["matvecs"] == 20 + (stats["restarts"] - 1) * 10
+    _solve_and_compare(amd, A50, g, "mark50_defaults_", 2, nev=4, sort_function=LR)
+
+
+def test_partial_schur_reference_tests(amd):
+    """tests/test_krylov_schur.py:12-49 restated on the drop-in."""
+    from arnoldi_amd.matrices import mark
+    from arnoldi_amd.utils import arg_largest_real
+
+    A = mark(10)
+    Q, T, _ = amd.partial_schur(A, 3, max_dim=5, sort_function=arg_largest_real, max_restarts=1000)
+    np.testing.assert_allclose(np.linalg.norm(A @ Q - Q @ T, axis=1), 0, rtol=1e-4, atol=1e-8)
+
+    D = np.diag([7, 7, 5, 4, 3, 2, 1])
+    M = np.random.randn(7, 7)
+    Qr, _ = np.linalg.qr(M)
+    Ad = Qr.T @ D @ Qr
+    Q, T, _ = amd.partial_schur(Ad, 3, max_dim=6, sort_function=arg_largest_real, max_restarts=1000)
+    np.testing.assert_allclose(np.linalg.norm(Ad @ Q - Q @ T, axis=1), 0, rtol=1e-4, atol=1e-8)
+
+
+def test_partial_schur_dense_laplace_planted_golden(amd):
+    gd = load_golden("g2_dense_diag")
+    # the double eigenvalue 7 makes the restart count rounding-sensitive: compare results only
+    _solve_and_compare(amd, gd["diag_A"], gd, "diag_", 0, expect_same_restarts=False, nev=3, max_dim=6,
+                       sort_function=oracle.arg_largest_real, max_restarts=1000)
+    g7 = load_golden("g7_laplace2d")
+    L = csr_from(g7, "lap")
+    _, T, _, _ = _solve_and_compare(amd, L, g7, "lap_", 0, nev=10, max_dim=40,
+                                    sort_function=oracle.arg_largest_magnitude)
+    np.testing.assert_allclose(np.sort(np.diag(T).real), g7["lap_analytic"][:10], rtol=1e-8)
+
+    from arnoldi_amd.matrices import random_csr
+
+    g8 = load_golden("g8_random_planted")
+    # same generator call as tests/golden/make_golden.py (seed 1234, planted spectrum)
+    A = _planted_like_golden(int(g8["n"]))
+    for seed in (0, 1):
+        _solve_and_compare(amd, A, g8, f"s{seed}_", seed, nev=5, max_dim=20,
+                           sort_function=oracle.arg_largest_magnitude)
+    assert random_csr(1000, 5, 1).shape == (1000, 1000)
+
+
+def _planted_like_golden(n):
+    rng = np.random.default_rng(1234)
+    idx = np.sort(rng.integers(0, n, (n, 5), dtype=np.int64), axis=1).astype(np.int32)
+    data = rng.uniform(-1.0, 1.0, (n, 5))
+    A = sp.csr_matrix((data.ravel(), idx.ravel(), np.arange(0, 5 * n + 1, 5, dtype=np.int32)), shape=(n, n))
+    A.sum_duplicates()
+    rows = rng.choice(n, size=6, replace=False)
+    A = A.tolil()
+    for r, val in zip(rows, (4.0, 3.7, 3.4, 3.1, 2.8, 2.5)):
+        A[r, r] = val
+    A = A.tocsr()
+    A.sort_indices()
+    return A
+
+
+def test_partial_schur_errors(amd):
+    g = load_golden("g9_errors")
+    from arnoldi_amd.matrices import random_csr
+
+    np.random.seed(0)
+    with pytest.raises(ValueError) as e:
+        amd.partial_schur(random_csr(2000, 5, 1234), 5, max_dim=20, max_restarts=3)
+    assert str(e.value) == str(g["not_converged"])
+    # happy breakdown: A = I makes the first residual vanish (krylov_schur.py:57-59)
+    with pytest.raises(ValueError, match="Happy breakdown not supported yet"):
+        amd.partial_schur(sp.identity(50, format="csr"), 2, max_dim=6)
+    with pytest.raises(AssertionError):
+        amd.partial_schur(sp.identity(50, format="csr"), 5, max_dim=4)
+    with pytest.raises(AssertionError):
+        amd.partial_schur(sp.csr_matrix((4, 5)), 1)
+
+
+def test_partial_schur_linear_operator(amd):
+    """Opaque operators (scripts/utils.py:55-68 MatvecCounter) go through the host callback."""
+    from scipy.sparse.linalg import LinearOperator
+    from arnoldi_amd.matrices import mark
+
+    A = mark(30)
+
+    class Counter(LinearOperator):
+        def __init__(self, M):
+            self.M, self.shape, self.dtype, self.count = M, M.shape, np.dtype(M.dtype), 0
+
+        def _matvec(self, x):
+            self.count += 1
+            return self.M @ x
+
+    np.random.seed(5)
+    op = Counter(A)
+    stats = {}
+    Q, T, _ = amd.partial_schur(op, 3, max_dim=12, stopping_criterion=1e-8,
+                                sort_function=oracle.arg_largest_real, stats=stats)
+    np.random.seed(5)
+    Q2, T2, _ = amd.partial_schur(A, 3, max_dim=12, stopping_criterion=1e-8,
+                                  sort_function=oracle.arg_largest_real)
+    assert op.count == stats["matvecs"]
+    np.testing.assert_allclose(np.diag(T), np.diag(T2), rtol=1e-9)
+    _, _, rel = oracle.eig_residuals(A, Q, T)
+    assert rel.max() < 5e-8
+
+
+# ---------------------------------------------------------------------------- full BASELINE sizes
+def test_full_size_config5_properties(amd):
+    """n = 10M, nnz = 50M, m = 20 (BASELINE config 5): properties that need no CPU solve.
+    SpMV against rocSPARSE-free torch arithmetic on sampled rows, linearity, and the Arnoldi
+    invariants  V^H V = I,  A V_m = V_{m+1} H  checked on the device in complex128."""
+    import torch
+    from arnoldi_amd import engine, matrices
+
+    n, m = 10_000_000, 20
+    A = matrices.random_csr(n, 5, 1234)
+    op = engine.CsrOperator(A)
+    ctx = engine.ArnoldiContext(op, m)
+    np.random.seed(0)
+    from arnoldi_amd.utils import rand_normalized_vector
+
+    ctx.set_start_vector(rand_normalized_vector(n, C128))
+    H = np.zeros((m + 1, m), C128)
+    assert ctx.expand(H, 0, m, 1e-8) == m
+    V = ctx.basis.V[:, :n]                                   # (m+1, n) device view
+    G = (V.conj() @ V.T).cpu().numpy()
+    assert np.abs(G - np.eye(m + 1)).max() < 1e-12
+    # A V_m - V_{m+1} H = 0, column by column through the SpMV kernel
+    Hd = torch.from_numpy(H).cuda()
+    y = torch.empty(ctx.basis.ldv, dtype=torch.complex128, device="cuda")
+    worst = 0.0
+    for j in (0, 7, m - 1):
+        op.apply(ctx.basis.col(j), y)
+        r = y[:n] - (Hd[: j + 2, j].unsqueeze(0) @ V[: j + 2]).squeeze(0)
+        worst = max(worst, float(torch.linalg.norm(r)))
+    assert worst < 1e-11
+    # SpMV vs independent arithmetic on a sample of rows
+    rows = np.random.default_rng(0).integers(0, n, 2000)
+    x = ctx.basis.col(3)[:n].cpu().numpy()
+    op.apply(ctx.basis.col(3), y)
+    got = y[:n].cpu().numpy()[rows]
+    want = np.array([A.data[A.indptr[r]:A.indptr[r + 1]] @ x[A.indices[A.indptr[r]:A.indptr[r + 1]]] for r in rows])
+    assert _relerr(got, want) < RTOL
+    # truncation keeps orthonormality for a unitary Qp
+    Qm, _ = np.linalg.qr(np.random.default_rng(1).standard_normal((m, m)) + 0j)
+    ctx.truncate(Qm[:, :10], m, 10)
+    Vp = ctx.basis.V[:11, :n]
+    G = (Vp.conj() @ Vp.T).cpu().numpy()
+    assert np.abs(G - np.eye(11)).max() < 1e-12
