@@ -68,9 +68,13 @@ SIGNATURES = {
     "aks_gs_finish": (C.c_int, [_I64, _I32, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
     "aks_dgks_gs": (C.c_int, [_I64, _I32, _P, _I64, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
     "aks_arnoldi_expand": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, _P, _I64, _P, _I64,
-                                     _I32, _I32, _F64, _F64, _P, _I64, _I32, _P]),
+                                     _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P]),
     "aks_truncate": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P]),
     "aks_gather_c128": (C.c_int, [_I64, _P, _P, _P, _P]),
+    "aks_probe_create": (C.c_int, [_I32, C.POINTER(_P)]),
+    "aks_probe_destroy": (C.c_int, [_P]),
+    "aks_probe_reset": (C.c_int, [_P]),
+    "aks_probe_read": (C.c_int, [_P, _I32, C.POINTER(_I32), C.POINTER(_F64)]),
 }
 
 _lock = threading.Lock()
@@ -115,6 +119,34 @@ def check(status, what):
         msg = load().aks_last_error()
         raise HipLibraryError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
     return status
+
+
+PROBE_SPMV, PROBE_ORTHO = 0, 1
+
+
+class Probe:
+    """hipEvent pairs recorded by ``aks_arnoldi_expand`` around every SpMV / orthogonalisation."""
+
+    def __init__(self, capacity=4096):
+        self.handle = _P()
+        check(load().aks_probe_create(capacity, C.byref(self.handle)), "aks_probe_create")
+
+    def reset(self):
+        check(load().aks_probe_reset(self.handle), "aks_probe_reset")
+
+    def read(self, tag):
+        """(count, total_ms) of the pairs recorded with ``tag``; waits for the last event."""
+        n, ms = _I32(0), _F64(0.0)
+        check(load().aks_probe_read(self.handle, tag, C.byref(n), C.byref(ms)), "aks_probe_read")
+        return n.value, ms.value
+
+    def __del__(self):
+        try:
+            if self.handle:
+                load().aks_probe_destroy(self.handle)
+                self.handle = _P()
+        except Exception:
+            pass
 
 
 def workspace_layout(n_rows, max_dim):

@@ -70,6 +70,10 @@ class CsrOperator:
                                      for r in range(world)))
 
     @property
+    def shape(self):
+        return (self.n, self.n)
+
+    @property
     def nnz(self):
         return self.diag.nnz + (self.off.nnz if self.off is not None else 0)
 
@@ -103,6 +107,7 @@ class HostOperator:
         self.comm = None
         self.dtype = np.dtype(getattr(A, "dtype", C128))
         self.offsets = np.array([0, self.n], np.int64)
+        self.shape = (self.n, self.n)
 
     def apply(self, x, y, ws=None):
         hx = x[: self.n].cpu().numpy()
@@ -130,6 +135,9 @@ class ArnoldiContext:
         self.basis = dev.KrylovBasis(op.n_local, max_dim, device)
         self.ws = dev.Workspace(op.n_local, max_dim, device)
         self.matvecs = 0
+        self.probe = None   # optional _hip.Probe (bench.py): device time of SpMV / ortho launches
+        self.spmv_events = None  # optional list (bench.py, Python-chained path): torch event pairs
+        self.force_chained = False  # run the Python-chained stage path even on one GPU (tests, bench)
 
     # -- seam 1 ------------------------------------------------------------------
     def expand(self, H, start, end, tol, eta=dev.ETA_DGKS):
@@ -137,13 +145,15 @@ class ArnoldiContext:
         of H into the host array exactly as the reference's in-place writes would.
         Returns n_iter (== end unless a step broke down)."""
         b, ws, op = self.basis, self.ws, self.op
-        native = isinstance(op, CsrOperator) and (op.comm is None or op.comm.size == 1)
+        native = (isinstance(op, CsrOperator) and (op.comm is None or op.comm.size == 1)
+                  and not self.force_chained)
         if native:
             d = op.diag
             rc = _hip.load().aks_arnoldi_expand(
                 b.n_rows, dev._ptr(d.indptr), dev._ptr(d.indices), dev._ptr(d.values), d.values_complex,
                 dev._ptr(d.tiles), d.n_tiles, d.lanes_per_row, dev._ptr(b.V), b.ldv, dev._ptr(b.H),
-                self.max_dim, start, end, tol, eta, dev._ptr(ws.buf), ws.nbytes, ws.max_dim, dev._stream())
+                self.max_dim, start, end, tol, eta, dev._ptr(ws.buf), ws.nbytes, ws.max_dim,
+                self.probe.handle if self.probe is not None else C.c_void_p(0), dev._stream())
             _hip.check(rc, "aks_arnoldi_expand")
         else:
             hbase = b.H.data_ptr()
@@ -151,7 +161,14 @@ class ArnoldiContext:
             for j in range(start, end):
                 J = j + 1
                 w = b.col(J)
-                op.apply(b.col(j), w, ws)
+                if self.spmv_events is not None:   # bench.py: device time of the sharded SpMV
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    op.apply(b.col(j), w, ws)
+                    e1.record()
+                    self.spmv_events.append((e0, e1))
+                else:
+                    op.apply(b.col(j), w, ws)
                 if not multi:
                     dev.dgks_gs_device(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
                     continue

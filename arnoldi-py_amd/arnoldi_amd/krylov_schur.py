@@ -18,6 +18,77 @@ from .utils import arg_largest_magnitude, rand_normalized_vector, reorder_schur
 WORK_DTYPE = np.complex128  # krylov_schur.py:38: complex128 whatever A.dtype is
 
 
+class KrylovSchurSolver:
+    """State machine of one solve: ``start()`` then alternate ``contract()`` /
+    ``expand()``.  ``partial_schur`` below is the reference-shaped loop over it; the
+    benchmark times the same two calls."""
+
+    def __init__(self, A, nev, max_dim, p, tol, sort_function, *, v0=None, comm=None, device=None):
+        n = A.shape[0]
+        self.n, self.nev, self.max_dim, self.p = n, nev, max_dim, p
+        self.tol, self.sort_function = tol, sort_function
+        self.op = as_operator(A, comm=comm, device=device)
+        self.ctx = ArnoldiContext(self.op, max_dim, device)
+        # every rank draws the full vector so that the shards agree bit for bit with the
+        # single-GPU (and the reference's) start vector
+        start = rand_normalized_vector(n, WORK_DTYPE) if v0 is None else np.asarray(v0, dtype=WORK_DTYPE)
+        assert start.shape == (n,)
+        self.ctx.set_start_vector(start)
+        self.H = np.zeros((max_dim + 1, max_dim), dtype=WORK_DTYPE)
+        self.history = History.from_k(nev)
+        self.m = 0
+        self.restarts_run = 0
+
+    def start(self):
+        """Initial m-step expansion (krylov_schur.py:51-54)."""
+        self.m = self.ctx.expand(self.H, 0, self.max_dim, self.tol)
+        return self.m
+
+    def contract(self, restart):
+        """Rotation, truncation and convergence test of restart number ``restart``
+        (krylov_schur.py:63-101).  Returns True when the first nev estimates are < tol."""
+        H, m, p, nev = self.H, self.m, self.p, self.nev
+        booked = restart * (self.max_dim - nev) + (m - nev)          # krylov_schur.py:63
+
+        # Ordered Schur form of the projected matrix (host, LAPACK).  The reference calls
+        # zgees twice (krylov_schur.py:69 and utils.py:45); the second call sees an upper-
+        # triangular matrix and returns (T, I) unchanged, so one call followed by the same
+        # ?trexc sequence gives the same (T, Q).
+        T, Q = scipy.linalg.schur(H[:m, :m], output="complex")
+        T, Q = reorder_schur(T, Q, self.sort_function(np.diag(T)))
+
+        # truncation on the device: V[:, :p] <- V[:, :m] Q[:, :p];  V[:, p] <- V[:, m]
+        Qp = Q[:, :p]
+        self.ctx.truncate(Qp, m, p)
+
+        coupling = H[m, :m].copy()
+        last = H[m, m - 1]
+        H[:p, :p] = T[:p, :p]                                        # krylov_schur.py:83
+        H[p, :p] = coupling @ Qp                                     # krylov_schur.py:86-87
+        H[p, p:] = 0                                                 # krylov_schur.py:88
+
+        estimate = np.abs(last * Q[m - 1, :]) / np.abs(np.diag(T))   # krylov_schur.py:91-92
+        under = estimate[:nev] <= self.tol
+        self.history.matvecs[under] = booked
+        self.history.restarts[under] = restart + 1
+        self.restarts_run = restart + 1
+        self.estimate = estimate[:nev]
+        return bool(np.all(estimate[:nev] < self.tol))               # krylov_schur.py:99
+
+    def expand(self):
+        """Re-expansion from p to max_dim (krylov_schur.py:103-106)."""
+        self.m = self.ctx.expand(self.H, self.p, self.max_dim, self.tol)
+        return self.m
+
+    def result(self, gather=True):
+        comm = self.ctx.comm
+        if comm is not None and comm.size > 1 and not gather:
+            Q = np.asfortranarray(self.ctx.local_columns(0, self.nev))
+        else:
+            Q = self.ctx.gather_columns(0, self.nev)
+        return Q, self.H[: self.nev, : self.nev].copy(), self.history
+
+
 def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts=100,
                   sort_function=None, p=None, v0=None, comm=None, device=None, gather=True,
                   stats=None):
@@ -35,7 +106,7 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
     gather  multi-GPU only: return the full ``Q`` on every rank (True) or just this
             rank's rows (False).
     stats   optional dict that receives ``restarts``, ``matvecs`` (true operator
-            applications), ``second_passes`` and the engine context (``ctx``).
+            applications), ``second_passes`` and the solver object.
 
     Returns ``(Q, T, history)``; raises ``ValueError("Has not converged !")`` /
     ``ValueError("Happy breakdown not supported yet")`` like the reference.
@@ -58,63 +129,23 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
 
     if comm is None:
         comm = default_comm()
-    op = as_operator(A, comm=comm, device=device)
-    ctx = ArnoldiContext(op, max_dim, device)
+    solver = KrylovSchurSolver(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)
 
-    # every rank draws the full vector so that the shards agree bit for bit with the
-    # single-GPU (and the reference's) start vector
-    start = rand_normalized_vector(n, WORK_DTYPE) if v0 is None else np.asarray(v0, dtype=WORK_DTYPE)
-    assert start.shape == (n,)
-    ctx.set_start_vector(start)
-
-    H = np.zeros((max_dim + 1, max_dim), dtype=WORK_DTYPE)
-    history = History.from_k(nev)
     converged = False
-    restarts_run = 0
-
-    m = ctx.expand(H, 0, max_dim, tol)
+    solver.start()
     for restart in range(max_restarts):
-        if m != max_dim:
+        if solver.m != max_dim:
             raise ValueError("Happy breakdown not supported yet")   # krylov_schur.py:57-59
-        booked = restart * (max_dim - nev) + (m - nev)              # krylov_schur.py:63
-
-        # -- rotation: ordered Schur form of the projected matrix (host, LAPACK).
-        # The reference calls zgees twice (krylov_schur.py:69 and utils.py:45); the second
-        # call sees an upper-triangular matrix and returns (T, I) unchanged, so one call
-        # followed by the same ?trexc sequence gives the same (T, Q).
-        T, Q = scipy.linalg.schur(H[:m, :m], output="complex")
-        T, Q = reorder_schur(T, Q, sort_function(np.diag(T)))
-
-        # -- truncation (device): V[:, :p] <- V[:, :m] Q[:, :p];  V[:, p] <- V[:, m]
-        Qp = Q[:, :p]
-        ctx.truncate(Qp, m, p)
-
-        coupling = H[m, :m].copy()
-        last = H[m, m - 1]
-        H[:p, :p] = T[:p, :p]                                       # krylov_schur.py:83
-        H[p, :p] = coupling @ Qp                                    # krylov_schur.py:86-87
-        H[p, p:] = 0                                                # krylov_schur.py:88
-
-        # -- convergence (krylov_schur.py:91-101)
-        estimate = np.abs(last * Q[m - 1, :]) / np.abs(np.diag(T))
-        under = estimate[:nev] <= tol
-        history.matvecs[under] = booked
-        history.restarts[under] = restart + 1
-        restarts_run = restart + 1
-        converged = bool(np.all(estimate[:nev] < tol))
+        converged = solver.contract(restart)
         if converged:
             break
-
-        m = ctx.expand(H, p, max_dim, tol)
+        solver.expand()
 
     if stats is not None:
-        stats.update(restarts=restarts_run, matvecs=ctx.matvecs, second_passes=int(ctx.last_ctrl.second_passes),
-                     ctx=ctx, tol=float(tol), max_dim=int(max_dim), p=int(p))
+        ctx = solver.ctx
+        stats.update(restarts=solver.restarts_run, matvecs=ctx.matvecs,
+                     second_passes=int(ctx.last_ctrl.second_passes), solver=solver,
+                     tol=float(tol), max_dim=int(max_dim), p=int(p))
     if not converged:
         raise ValueError("Has not converged !")                      # krylov_schur.py:108-109
-
-    if comm is not None and comm.size > 1 and not gather:
-        Qout = np.asfortranarray(ctx.local_columns(0, nev))
-    else:
-        Qout = ctx.gather_columns(0, nev)
-    return Qout, H[:nev, :nev].copy(), history
+    return solver.result(gather)

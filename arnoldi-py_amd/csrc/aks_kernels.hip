@@ -28,7 +28,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
+#include <vector>
 
 #include "arnoldi_hip.h"
 
@@ -562,6 +564,18 @@ int launch_truncate(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_t ldv
     return AKS_OK;
 }
 
+struct Probe {
+    std::vector<hipEvent_t> start, stop;
+    std::vector<int32_t> tag;
+    int32_t used = 0;
+    hipEvent_t begin(int32_t t, hipStream_t s) {
+        if (used >= (int32_t)start.size()) return nullptr;
+        tag[used] = t;
+        (void)hipEventRecord(start[used], s);
+        return stop[used++];
+    }
+};
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -737,18 +751,24 @@ int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d
                        int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row,
                        aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh, int32_t start_dim,
                        int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes, int32_t max_dim,
-                       void *stream) {
+                       void *probe, void *stream) {
     if (start_dim < 0 || end_dim > max_dim || start_dim > end_dim)
         return fail(AKS_ERR_ARG, "need 0 <= start_dim <= end_dim <= max_dim");
     if (d_V == nullptr || d_H == nullptr) return fail(AKS_ERR_ARG, "null pointer");
     if (ldh < max_dim) return fail(AKS_ERR_ARG, "ldh < max_dim");
+    Probe *pr = static_cast<Probe *>(probe);
+    hipStream_t s = static_cast<hipStream_t>(stream);
     for (int32_t j = start_dim; j < end_dim; ++j) {
         aks_c128 *x = d_V + (int64_t)j * ldv;
         aks_c128 *w = d_V + (int64_t)(j + 1) * ldv;
+        hipEvent_t done = pr ? pr->begin(AKS_PROBE_SPMV, s) : nullptr;
         int rc = aks_csr_spmv(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
                               lanes_per_row, x, w, 0, d_ws, stream);
+        if (done) (void)hipEventRecord(done, s);
         if (rc != AKS_OK) return rc;
+        done = pr ? pr->begin(AKS_PROBE_ORTHO, s) : nullptr;
         rc = aks_dgks_gs(n_rows, j + 1, d_V, ldv, w, d_H + j, ldh, tol, eta, 1, d_ws, ws_bytes, max_dim, stream);
+        if (done) (void)hipEventRecord(done, s);
         if (rc != AKS_OK) return rc;
     }
     return AKS_OK;
@@ -771,6 +791,64 @@ int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ld
     if (p <= 48) return launch_truncate<48>(s, n_rows, m, p, V, ldv, Q);
     if (p <= 64) return launch_truncate<64>(s, n_rows, m, p, V, ldv, Q);
     return launch_truncate<96>(s, n_rows, m, p, V, ldv, Q);
+}
+
+int aks_probe_create(int32_t capacity, void **probe_out) {
+    if (capacity < 1 || probe_out == nullptr) return fail(AKS_ERR_ARG, "bad probe capacity / pointer");
+    Probe *p = new (std::nothrow) Probe();
+    if (p == nullptr) return fail(AKS_ERR_ARG, "out of host memory");
+    p->start.resize(capacity);
+    p->stop.resize(capacity);
+    p->tag.assign(capacity, -1);
+    for (int32_t i = 0; i < capacity; ++i) {
+        hipError_t e = hipEventCreate(&p->start[i]);
+        if (e == hipSuccess) e = hipEventCreate(&p->stop[i]);
+        if (e != hipSuccess) {
+            delete p;
+            return hip_fail(e, "hipEventCreate");
+        }
+    }
+    *probe_out = p;
+    return AKS_OK;
+}
+
+int aks_probe_destroy(void *probe) {
+    Probe *p = static_cast<Probe *>(probe);
+    if (p == nullptr) return AKS_OK;
+    for (size_t i = 0; i < p->start.size(); ++i) {
+        (void)hipEventDestroy(p->start[i]);
+        (void)hipEventDestroy(p->stop[i]);
+    }
+    delete p;
+    return AKS_OK;
+}
+
+int aks_probe_reset(void *probe) {
+    if (probe == nullptr) return fail(AKS_ERR_ARG, "null probe");
+    static_cast<Probe *>(probe)->used = 0;
+    return AKS_OK;
+}
+
+int aks_probe_read(void *probe, int32_t tag, int32_t *count_out, double *total_ms_out) {
+    Probe *p = static_cast<Probe *>(probe);
+    if (p == nullptr || count_out == nullptr || total_ms_out == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    int32_t count = 0;
+    double total = 0.0;
+    if (p->used > 0) {
+        hipError_t e = hipEventSynchronize(p->stop[p->used - 1]);
+        if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");
+    }
+    for (int32_t i = 0; i < p->used; ++i) {
+        if (p->tag[i] != tag) continue;
+        float ms = 0.f;
+        hipError_t e = hipEventElapsedTime(&ms, p->start[i], p->stop[i]);
+        if (e != hipSuccess) return hip_fail(e, "hipEventElapsedTime");
+        total += ms;
+        ++count;
+    }
+    *count_out = count;
+    *total_ms_out = total;
+    return AKS_OK;
 }
 
 int aks_gather_c128(int64_t count, const int32_t *d_idx, const aks_c128 *d_src, aks_c128 *d_dst, void *stream) {

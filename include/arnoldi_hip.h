@@ -141,13 +141,28 @@ int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d
                        const void *d_values, int32_t values_complex, const int32_t *d_tiles,
                        int64_t n_tiles, int32_t lanes_per_row, aks_c128 *d_V, int64_t ldv,
                        aks_c128 *d_H, int64_t ldh, int32_t start_dim, int32_t end_dim, double tol,
-                       double eta, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream);
+                       double eta, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *probe,
+                       void *stream);
 
 /* ---- restart compression: replaces krylov_schur.py:78 and :81 --------------
  * V[:, :p] = V[:, :m] @ Qp   (in place, row-block by row-block)   and
  * V[:, p]  = V[:, m].   d_Qp is m x p complex128, row-major (ld = p). */
 int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv,
                  const aks_c128 *d_Qp, void *stream);
+
+/* ---- device-time probes (measurement only; bench.py's roofline figures) --------
+ * A probe owns `capacity` hipEvent pairs.  When one is handed to
+ * aks_arnoldi_expand, every SpMV launch is bracketed by a pair with tag
+ * AKS_PROBE_SPMV and every orthogonalisation (project .. finish) by a pair with
+ * tag AKS_PROBE_ORTHO, recorded on the launch stream.  aks_probe_read waits for
+ * the last recorded event and returns the number of pairs with `tag` and the
+ * sum of their elapsed times in milliseconds. */
+#define AKS_PROBE_SPMV 0
+#define AKS_PROBE_ORTHO 1
+int aks_probe_create(int32_t capacity, void **probe_out);
+int aks_probe_destroy(void *probe);
+int aks_probe_reset(void *probe);
+int aks_probe_read(void *probe, int32_t tag, int32_t *count_out, double *total_ms_out);
 
 /* ---- small utilities used by the host driver --------------------------------
  * dst[i] = src[idx[i]]  -- packs the x entries another row shard needs

@@ -12,6 +12,7 @@ oracle reproduces the reference's iterates to rounding.
 from __future__ import annotations
 
 import dataclasses
+import time
 
 import numpy as np
 import scipy.linalg as sla
@@ -244,6 +245,8 @@ def krylov_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts=
     _, _, m = arnoldi_expand(A, V, H, tol, start_dim=0, max_dim=max_dim)
     n_restarts = 0
     for restart in range(max_restarts):
+        if trace is not None:
+            trace.setdefault("t_restart", []).append(time.perf_counter())
         if m != max_dim:                               # krylov_schur.py:57-59
             raise ValueError("Happy breakdown not supported yet")
         matvecs = restart * (max_dim - nev) + (m - nev)   # krylov_schur.py:63
