@@ -119,7 +119,9 @@ class Workspace:
         self.n_rows, self.max_dim = int(n_rows), int(max_dim)
         self.layout = _hip.workspace_layout(self.n_rows, self.max_dim)
         self.nbytes = int(self.layout.total_bytes)
-        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+        self._raw = torch.empty(self.nbytes + 256, dtype=torch.uint8, device=device)
+        skew = (-self._raw.data_ptr()) % 256
+        self.buf = self._raw[skew: skew + self.nbytes]   # 256-byte aligned view
         assert self.buf.data_ptr() % 256 == 0
         self.reset()
 

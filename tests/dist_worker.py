@@ -1,0 +1,111 @@
+"""Worker of the multi-rank tests: one process per rank (torch.distributed.run).
+
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P \
+        tests/dist_worker.py --backend gloo --device cpu --out DIR
+
+``--device cpu``  : CPU tensors + tests/fake_hip.py (host logic of the row-sharded driver: partition,
+                    ghost plan, all-to-all, all-reduces, stage chaining) -- runs anywhere.
+``--device cuda`` : the real HIP kernels; every rank uses GPU 0 and ``gloo`` carries the collectives
+                    through host memory (how two ranks are rehearsed on the one-GPU box).
+Each case solves the same problem as a single-process CPU oracle run and writes its verdict.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "arnoldi-py_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import scipy.sparse as sp  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--device", default="cpu")
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+
+    dist.init_process_group(args.backend)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if args.device == "cpu":
+        import fake_hip
+
+        fake_hip.install()
+    else:
+        torch.cuda.set_device(0)
+
+    import oracle
+    from arnoldi_amd import matrices, partial_schur
+    from arnoldi_amd.dist import Comm, row_offsets
+    from arnoldi_amd.engine import CsrOperator
+
+    comm = Comm()
+    verdict = {}
+
+    def run_case(name, A_full, nev, seed, A_arg=None, **kw):
+        """Sharded solve vs the single-process oracle on the same start vector."""
+        np.random.seed(seed)
+        stats = {}
+        Q, T, hist = partial_schur(A_full if A_arg is None else A_arg, nev, comm=comm, stats=stats, **kw)
+        np.random.seed(seed)
+        okw = {k: v for k, v in kw.items()}
+        Qo, To, histo = oracle.krylov_schur(A_full, nev, **okw)
+        _, _, rel = oracle.eig_residuals(A_full, Q, T)
+        _, _, rel_o = oracle.eig_residuals(A_full, Qo, To)
+        verdict[name] = {
+            "restarts_equal": bool(np.array_equal(hist.restarts, histo.restarts)),
+            "matvec_hist_equal": bool(np.array_equal(hist.matvecs, histo.matvecs)),
+            "eig_err": float(np.abs(np.diag(T) - np.diag(To)).max()),
+            "rel_residual": float(rel.max()),
+            "rel_residual_oracle": float(rel_o.max()),
+            "q_shape": list(Q.shape),
+            "orth_err": float(np.abs(Q.conj().T @ Q - np.eye(nev)).max()),
+            "n_ghost": int(getattr(stats["solver"].op, "n_ghost", -1)),
+            "restarts": int(stats["restarts"]),
+        }
+
+    LR, LM = oracle.arg_largest_real, oracle.arg_largest_magnitude
+    # 1. Markov chain (README config): neighbours a few rows away -> small ghost sets
+    run_case("mark50", matrices.mark(50), 5, 0, max_dim=20, stopping_criterion=1e-8, sort_function=LR)
+    # 2. 2-D Laplace: halo of one grid line per side
+    run_case("laplace2d", matrices.laplace2d(30, 31), 10, 0, max_dim=40, sort_function=LM)
+    # 3. random CSR with planted spectrum: nearly every remote entry is needed
+    n = 6000
+    Ar = matrices.random_csr(n, 5, 1234, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5))
+    run_case("random_planted", Ar, 5, 0, max_dim=20, sort_function=LM)
+    # 4. each rank builds only its own rows (bench.py's construction)
+    offs = row_offsets(n, world)
+    rows = matrices.random_csr(n, 5, 1234, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5),
+                               row_range=(int(offs[rank]), int(offs[rank + 1])))
+    op = CsrOperator(local_rows=rows, offsets=offs, comm=comm)
+    run_case("local_rows", Ar, 5, 1, A_arg=op, max_dim=20, sort_function=LM)
+    # 5. block-diagonal operator: no exchange at all
+    blks = [matrices.mark(12 + r) * (1.0 - 0.1 * r) for r in range(world)]  # distinct spectra
+    Ab = sp.block_diag(blks, format="csr")
+    offs_b = np.concatenate([[0], np.cumsum([b.shape[0] for b in blks])])
+    opb = CsrOperator(Ab, offsets=offs_b, comm=comm)
+    assert not opb.any_exchange
+    run_case("block_diag", Ab, 2, 3, A_arg=opb, max_dim=10, stopping_criterion=1e-8, sort_function=LR)
+    # 6. complex matrix values
+    rng = np.random.default_rng(5)
+    Ac = (sp.random(400, 400, density=0.02, random_state=np.random.RandomState(3), dtype=np.float64)
+          + 1j * sp.random(400, 400, density=0.02, random_state=np.random.RandomState(4), dtype=np.float64)
+          + sp.diags_array(np.linspace(1, 6, 400))).tocsr()
+    run_case("complex", Ac, 3, 2, max_dim=16, stopping_criterion=1e-8, sort_function=LM)
+    del rng
+
+    with open(os.path.join(args.out, f"rank{rank}.json"), "w") as f:
+        json.dump(verdict, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

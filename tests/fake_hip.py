@@ -1,0 +1,201 @@
+"""TEST INFRASTRUCTURE: a NumPy stand-in for the *device* entry points of libarnoldi_hip.so.
+
+The product has no CPU path.  To exercise the host logic above the C ABI on a machine
+without a GPU (argument plumbing, the workspace protocol, the row-sharded driver with its
+all-reduces and ghost exchange over ``gloo``), the CPU tests swap ``_hip.load()`` for this
+object: it takes the same raw pointers the real library takes (here they point into CPU
+torch tensors) and performs each entry point's documented effect with NumPy/SciPy.  Pure
+host entry points (layout, tile planner, version) are forwarded to the real library.
+
+Never imported by anything under ``arnoldi-py_amd/``.
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+C128 = np.complex128
+
+
+def _addr(p):
+    if isinstance(p, C.c_void_p):
+        return p.value or 0
+    return int(p or 0)
+
+
+def _view(p, dtype, count):
+    dtype = np.dtype(dtype)
+    if count == 0:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (dtype.itemsize * count)).from_address(_addr(p))
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+class FakeHip:
+    def __init__(self, real):
+        self._real = real
+        for name in ("aks_last_error", "aks_abi_version", "aks_workspace_layout", "aks_csr_plan_tiles"):
+            setattr(self, name, getattr(real, name))
+        self.calls = []
+
+    # ---- workspace ---------------------------------------------------------------
+    def _ws(self, ws, n_rows, max_dim):
+        from arnoldi_amd import _hip
+
+        lay = _hip.WsLayout()
+        assert self._real.aks_workspace_layout(n_rows, max_dim, C.byref(lay)) == 0
+        base = _addr(ws)
+        ctrl_i = _view(base, np.int32, 4)
+        ctrl_d = _view(base + 16, np.float64, 2)
+        red = lambda off, k: _view(base + off, C128, k)  # noqa: E731
+        return lay, ctrl_i, ctrl_d, red(lay.red1_off, lay.red_len), red(lay.red2_off, lay.red_len), red(lay.red3_off, 2)
+
+    def aks_workspace_init(self, ws, nbytes, n_rows, max_dim, stream):
+        lay = self._ws(ws, n_rows, max_dim)[0]
+        _view(ws, np.uint8, lay.partial_off)[:] = 0
+        return 0
+
+    # ---- SpMV ----------------------------------------------------------------------
+    def aks_csr_spmv(self, n_rows, indptr, indices, values, cplx, tiles, n_tiles, lpr, x, y, acc, ws, stream):
+        self.calls.append("spmv")
+        if _addr(ws) and _view(ws, np.int32, 1)[0]:
+            return 0
+        ip = _view(indptr, np.int32, n_rows + 1)
+        nnz = int(ip[-1])
+        ix = _view(indices, np.int32, nnz)
+        vals = _view(values, C128 if cplx else np.float64, nnz)
+        n_cols = int(ix.max()) + 1 if nnz else 1
+        A = sp.csr_matrix((vals, ix, ip), shape=(n_rows, n_cols))
+        xv = _view(x, C128, n_cols)
+        yv = _view(y, C128, n_rows)
+        # the tile plan must cover every row exactly once
+        t = _view(tiles, np.int32, n_tiles + 1)
+        assert t[0] == 0 and t[-1] == n_rows and np.all(np.diff(t) > 0)
+        r = A @ xv
+        yv[:] = yv + r if acc else r
+        return 0
+
+    # ---- Gram-Schmidt stages ---------------------------------------------------------
+    @staticmethod
+    def _panel(V, ldv, J, n):
+        return _view(V, C128, ldv * J).reshape(J, ldv)[:, :n]
+
+    def aks_gs_project(self, n, J, V, ldv, w, ws, ws_bytes, max_dim, stream):
+        lay, ci, cd, r1, r2, r3 = self._ws(ws, n, max_dim)
+        if ci[0]:
+            return 0
+        P, wv = self._panel(V, ldv, J, n), _view(w, C128, n)
+        r1[:J] = P.conj() @ wv
+        r1[J] = np.vdot(wv, wv).real
+        r3[0] = 0
+        return 0
+
+    def aks_gs_update_project(self, n, J, V, ldv, w, ws, ws_bytes, max_dim, stream):
+        lay, ci, cd, r1, r2, r3 = self._ws(ws, n, max_dim)
+        if ci[0]:
+            return 0
+        P, wv = self._panel(V, ldv, J, n), _view(w, C128, n)
+        wv -= r1[:J] @ P
+        r2[:J] = P.conj() @ wv
+        r2[J] = np.vdot(wv, wv).real
+        return 0
+
+    @staticmethod
+    def _twice(r1, r2, J, eta):
+        return np.sqrt(r2[J].real) < np.sqrt(r1[J].real) * eta
+
+    def aks_gs_update_norm(self, n, J, V, ldv, w, eta, ws, ws_bytes, max_dim, stream):
+        lay, ci, cd, r1, r2, r3 = self._ws(ws, n, max_dim)
+        if ci[0] or not self._twice(r1, r2, J, eta):
+            return 0
+        P, wv = self._panel(V, ldv, J, n), _view(w, C128, n)
+        wv -= r2[:J] @ P
+        r3[0] = np.vdot(wv, wv).real
+        return 0
+
+    def aks_gs_finish(self, n, J, w, Hcol, ldh, tol, eta, normalize, ws, ws_bytes, max_dim, stream):
+        lay, ci, cd, r1, r2, r3 = self._ws(ws, n, max_dim)
+        if ci[0]:
+            return 0
+        twice = self._twice(r1, r2, J, eta)
+        beta = float(np.sqrt(r3[0].real if twice else r2[J].real))
+        broke = beta < tol
+        H = _view(Hcol, C128, ldh * J + 1)
+        H[: ldh * J: ldh] = r1[:J] + (r2[:J] if twice else 0)
+        if not broke and normalize:
+            H[ldh * J] = beta
+        cd[0], cd[1] = np.sqrt(r1[J].real), beta
+        ci[2] += 1
+        ci[3] += int(twice)
+        if broke:
+            ci[1], ci[0] = J, 1
+        elif normalize:
+            wv = _view(w, C128, n)
+            wv /= beta
+        return 0
+
+    def aks_dgks_gs(self, n, J, V, ldv, w, Hcol, ldh, tol, eta, normalize, ws, ws_bytes, max_dim, stream):
+        self.aks_gs_project(n, J, V, ldv, w, ws, ws_bytes, max_dim, stream)
+        self.aks_gs_update_project(n, J, V, ldv, w, ws, ws_bytes, max_dim, stream)
+        self.aks_gs_update_norm(n, J, V, ldv, w, eta, ws, ws_bytes, max_dim, stream)
+        return self.aks_gs_finish(n, J, w, Hcol, ldh, tol, eta, normalize, ws, ws_bytes, max_dim, stream)
+
+    def aks_arnoldi_expand(self, n, indptr, indices, values, cplx, tiles, n_tiles, lpr, V, ldv, H, ldh,
+                           start, end, tol, eta, ws, ws_bytes, max_dim, probe, stream):
+        self.calls.append("expand")
+        for j in range(start, end):
+            x = _addr(V) + 16 * ldv * j
+            w = _addr(V) + 16 * ldv * (j + 1)
+            self.aks_csr_spmv(n, indptr, indices, values, cplx, tiles, n_tiles, lpr, x, w, 0, ws, stream)
+            self.aks_dgks_gs(n, j + 1, V, ldv, w, _addr(H) + 16 * j, ldh, tol, eta, 1, ws, ws_bytes, max_dim, stream)
+        return 0
+
+    # ---- restart compression ---------------------------------------------------------------
+    def aks_truncate(self, n, m, p, V, ldv, Qp, stream):
+        self.calls.append("truncate")
+        Vv = _view(V, C128, ldv * (m + 1)).reshape(m + 1, ldv)
+        Q = _view(Qp, C128, m * p).reshape(m, p)
+        new = Q.T @ Vv[:m, :n]
+        last = Vv[m, :n].copy()
+        Vv[:p, :n] = new
+        Vv[p, :n] = last
+        return 0
+
+    def aks_gather_c128(self, count, idx, src, dst, stream):
+        if count == 0:
+            return 0
+        ix = _view(idx, np.int32, count)
+        _view(dst, C128, count)[:] = _view(src, C128, int(ix.max()) + 1)[ix]
+        return 0
+
+    # ---- probes: nothing to time on the CPU ---------------------------------------------------
+    def aks_probe_create(self, cap, out):
+        return 0
+
+    def aks_probe_destroy(self, p):
+        return 0
+
+    def aks_probe_reset(self, p):
+        return 0
+
+    def aks_probe_read(self, p, tag, n_out, ms_out):
+        return 0
+
+
+def install(monkeypatch=None):
+    """Route arnoldi_amd's device layer to CPU tensors + FakeHip.  Returns the fake."""
+    import torch
+    from arnoldi_amd import _hip, device as dev
+
+    fake = FakeHip(_hip.load())
+    patches = [
+        (_hip, "load", lambda: fake),
+        (dev, "_require_gpu", lambda device=None: torch.device("cpu")),
+        (dev, "_stream", lambda: C.c_void_p(0)),
+    ]
+    for obj, name, val in patches:
+        if monkeypatch is not None:
+            monkeypatch.setattr(obj, name, val)
+        else:
+            setattr(obj, name, val)
+    return fake
