@@ -54,6 +54,21 @@ class Ctrl(C.Structure):
 _P = C.c_void_p
 _I32, _I64, _F64 = C.c_int32, C.c_int64, C.c_double
 
+PB_SLAB_BITS = 16       # AKS_PB_SLAB_BITS
+PB_ROWBLOCK_BITS = 10   # AKS_PB_ROWBLOCK_BITS
+PB_CHUNK_NNZ = 2048     # AKS_PB_CHUNK_NNZ
+
+
+class PbMatrix(C.Structure):
+    """Mirror of ``aks_pb_matrix`` (device pointers of the slab-binned SpMV form)."""
+
+    _fields_ = [
+        ("n_rows", _I64), ("n_cols", _I64), ("nnz", _I64), ("n_chunks", _I64),
+        ("n_slabs", _I32), ("n_rowblocks", _I32), ("values_complex", _I32), ("pad_", _I32),
+        ("d_val", _P), ("d_lcol", _P), ("d_dest", _P), ("d_lrow", _P), ("d_rb_ptr", _P),
+        ("d_slab_ptr", _P), ("d_chunk_begin", _P), ("d_chunk_slab", _P), ("d_prod", _P),
+    ]
+
 # name -> (restype, argtypes); one entry per function declared in include/arnoldi_hip.h
 SIGNATURES = {
     "aks_last_error": (C.c_char_p, []),
@@ -67,8 +82,11 @@ SIGNATURES = {
     "aks_gs_update_norm": (C.c_int, [_I64, _I32, _P, _I64, _P, _F64, _P, _I64, _I32, _P]),
     "aks_gs_finish": (C.c_int, [_I64, _I32, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
     "aks_dgks_gs": (C.c_int, [_I64, _I32, _P, _I64, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
-    "aks_arnoldi_expand": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, _P, _I64, _P, _I64,
-                                     _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P]),
+    "aks_pb_plan_count": (_I64, [_P, _P, _I64, _I64, _P]),
+    "aks_pb_plan_fill": (C.c_int, [_P, _P, _P, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "aks_pb_spmv": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),
+    "aks_arnoldi_expand": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, C.POINTER(PbMatrix), _P, _I64,
+                                     _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P]),
     "aks_truncate": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P]),
     "aks_gather_c128": (C.c_int, [_I64, _P, _P, _P, _P]),
     "aks_probe_create": (C.c_int, [_I32, C.POINTER(_P)]),

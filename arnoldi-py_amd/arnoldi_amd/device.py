@@ -94,21 +94,139 @@ class DeviceCSR:
         self.values = torch.from_numpy(np.ascontiguousarray(M.data)).to(device)
         self.tiles = torch.from_numpy(tiles[: self.n_tiles + 1].copy()).to(device)
 
+        self._host = M            # kept until the SpMV form has been chosen (autotune)
+        self.binned = None        # BinnedCSR once built
+        self.use_binned = False   # which form spmv() / aks_arnoldi_expand use
+
     def algorithmic_bytes(self):
         """12 nnz + 36 n + 4 (f64 values) or 20 nnz + 36 n + 4 (c128 values)."""
         per_nnz = 20 if self.values_complex else 12
         return per_nnz * self.nnz + 36 * self.n_rows + 4
+
+    # -- choice of SpMV form ------------------------------------------------------------------
+    def scatter_ratio(self, sample_windows=64):
+        """Distinct 128-byte lines of x touched per non-zero in windows of 64 consecutive rows
+        (~0.1 for stencils, ~1 for random graphs): how little L2 reuse the CSR kernel can get."""
+        M = self._host
+        if M is None or self.nnz == 0:
+            return 0.0
+        starts = np.linspace(0, max(self.n_rows - 64, 0), sample_windows).astype(np.int64)
+        lines = nnz = 0
+        for r in starts:
+            k0, k1 = M.indptr[r], M.indptr[min(r + 64, self.n_rows)]
+            if k1 > k0:
+                lines += np.unique(M.indices[k0:k1] >> 3).size
+                nnz += k1 - k0
+        return lines / max(nnz, 1)
+
+    def build_binned(self):
+        if self.binned is None:
+            if self._host is None:
+                raise _hip.HipLibraryError("host copy of the matrix already released")
+            self.binned = BinnedCSR(self._host, self.device)
+        return self.binned
+
+    def autotune(self, min_nnz=2_000_000, reps=3, force=None):
+        """Pick the CSR-stream or the slab-binned SpMV by timing both on this device.
+        Only matrices that are large and scattered enough to miss L2 are candidates.
+        ``force`` = "csr" | "binned" skips the measurement.  Frees the host copy."""
+        choice = force
+        if choice is None:
+            candidate = self.nnz >= min_nnz and self.n_cols * 16 > (4 << 20) and self.scatter_ratio() > 0.5
+            if not candidate:
+                choice = "csr"
+        if choice is None:
+            self.build_binned()
+            x = torch.zeros(self.n_cols, dtype=torch.complex128, device=self.device)
+            y = torch.empty(self.n_rows, dtype=torch.complex128, device=self.device)
+            times = {}
+            for form in ("csr", "binned"):
+                self.use_binned = form == "binned"
+                self.spmv(x, y)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    self.spmv(x, y)
+                e1.record()
+                torch.cuda.synchronize()
+                times[form] = e0.elapsed_time(e1) / reps
+            self.tune_ms = times
+            choice = "binned" if times["binned"] < 0.9 * times["csr"] else "csr"
+        if choice == "binned":
+            self.build_binned()
+        else:
+            self.binned = None
+        self.use_binned = choice == "binned"
+        self._host = None
+        return choice
 
     def spmv(self, x, y, accumulate=False, ws=None):
         """y (=|+=) A x on the current stream; x, y are complex128 device tensors."""
         assert x.dtype == torch.complex128 and y.dtype == torch.complex128
         assert x.numel() >= self.n_cols and y.numel() >= self.n_rows
         assert x.is_contiguous() and y.is_contiguous()
+        if self.use_binned:
+            rc = _hip.load().aks_pb_spmv(C.byref(self.binned.desc), _ptr(x), _ptr(y), int(accumulate),
+                                         _ptr(ws.buf) if ws is not None else C.c_void_p(0), _stream())
+            _hip.check(rc, "aks_pb_spmv")
+            return
         rc = _hip.load().aks_csr_spmv(
             self.n_rows, _ptr(self.indptr), _ptr(self.indices), _ptr(self.values), self.values_complex,
             _ptr(self.tiles), self.n_tiles, self.lanes_per_row, _ptr(x), _ptr(y), int(accumulate),
             _ptr(ws.buf) if ws is not None else C.c_void_p(0), _stream())
         _hip.check(rc, "aks_csr_spmv")
+
+
+class BinnedCSR:
+    """Slab-binned two-phase form of a CSR block (``aks_pb_matrix``): arrays planned on the
+    host by ``aks_pb_plan_count`` / ``aks_pb_plan_fill``, uploaded, plus the product scratch."""
+
+    def __init__(self, M, device):
+        lib = _hip.load()
+        n_rows, n_cols = M.shape
+        nnz = int(M.nnz)
+        indptr = np.ascontiguousarray(M.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(M.indices, dtype=np.int32)
+        cplx = int(M.data.dtype == C128)
+        values = np.ascontiguousarray(M.data)
+        n_slabs = (n_cols + (1 << _hip.PB_SLAB_BITS) - 1) >> _hip.PB_SLAB_BITS
+        n_rb = (n_rows + (1 << _hip.PB_ROWBLOCK_BITS) - 1) >> _hip.PB_ROWBLOCK_BITS
+        slab_ptr = np.empty(n_slabs + 1, np.int32)
+        n_chunks = lib.aks_pb_plan_count(indptr.ctypes.data, indices.ctypes.data, n_rows, n_cols,
+                                         slab_ptr.ctypes.data)
+        _hip.check(n_chunks, "aks_pb_plan_count")
+        val = np.empty(nnz, values.dtype)
+        lcol = np.empty(nnz, np.uint16)
+        dest = np.empty(nnz, np.int32)
+        lrow = np.empty(nnz, np.uint16)
+        rb_ptr = np.empty(n_rb + 1, np.int32)
+        chunk_begin = np.empty(max(n_chunks, 1), np.int32)
+        chunk_slab = np.empty(max(n_chunks, 1), np.int32)
+        rc = lib.aks_pb_plan_fill(indptr.ctypes.data, indices.ctypes.data, values.ctypes.data, cplx, n_rows,
+                                  n_cols, slab_ptr.ctypes.data, val.ctypes.data, lcol.ctypes.data,
+                                  dest.ctypes.data, lrow.ctypes.data, rb_ptr.ctypes.data,
+                                  chunk_begin.ctypes.data, chunk_slab.ctypes.data)
+        _hip.check(rc, "aks_pb_plan_fill")
+        up = lambda a: torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to(device)  # noqa: E731
+        self.val, self.lcol, self.dest, self.lrow = up(val), up(lcol), up(dest), up(lrow)
+        self.rb_ptr, self.slab_ptr = up(rb_ptr), up(slab_ptr)
+        self.chunk_begin, self.chunk_slab = up(chunk_begin), up(chunk_slab)
+        self.prod = torch.empty(max(nnz, 1), dtype=torch.complex128, device=device)
+        self.n_chunks, self.n_slabs, self.n_rowblocks = int(n_chunks), int(n_slabs), int(n_rb)
+        d = _hip.PbMatrix()
+        d.n_rows, d.n_cols, d.nnz, d.n_chunks = n_rows, n_cols, nnz, n_chunks
+        d.n_slabs, d.n_rowblocks, d.values_complex, d.pad_ = n_slabs, n_rb, cplx, 0
+        d.d_val, d.d_lcol, d.d_dest, d.d_lrow = (t.data_ptr() for t in (self.val, self.lcol, self.dest, self.lrow))
+        d.d_rb_ptr, d.d_slab_ptr = self.rb_ptr.data_ptr(), self.slab_ptr.data_ptr()
+        d.d_chunk_begin, d.d_chunk_slab = self.chunk_begin.data_ptr(), self.chunk_slab.data_ptr()
+        d.d_prod = self.prod.data_ptr()
+        self.desc = d
+
+    def moved_bytes(self):
+        """Bytes the two phases stream per SpMV (excluding x and y): 8|16 + 2 + 4 + 16 written,
+        then 16 + 2 read, per non-zero."""
+        per = (16 if self.desc.values_complex else 8) + 2 + 4 + 16 + 16 + 2
+        return per * int(self.desc.nnz)
 
 
 class Workspace:

@@ -29,7 +29,14 @@ C128 = np.complex128
 class CsrOperator:
     """CSR operator resident in HBM, row-sharded over ``comm`` (or whole on one GPU)."""
 
-    def __init__(self, A=None, *, local_rows=None, offsets=None, comm=None, device=None):
+    def __init__(self, A=None, *, local_rows=None, offsets=None, comm=None, device=None, spmv_form=None):
+        """``spmv_form``: None/"auto" (time the CSR-stream and the slab-binned kernels on large
+        scattered matrices and keep the faster), "csr" or "binned".  Environment override:
+        AKS_SPMV_FORM."""
+        import os
+
+        form = os.environ.get("AKS_SPMV_FORM", spmv_form or "auto")
+        force = None if form == "auto" else form
         self.comm = comm
         world = comm.size if comm is not None else 1
         rank = comm.rank if comm is not None else 0
@@ -49,12 +56,16 @@ class CsrOperator:
         self.dtype = rows.dtype
         if world == 1:
             self.diag = dev.DeviceCSR(rows, device)
+            self.spmv_form = self.diag.autotune(force=force)
             self.off = None
             self.n_ghost = 0
             return
         plan = split_local_rows(rows, self.offsets, rank)
         self.diag = dev.DeviceCSR(plan.diag, device)
         self.off = dev.DeviceCSR(plan.off, device) if plan.off is not None else None
+        self.spmv_form = self.diag.autotune(force=force)
+        if self.off is not None:
+            self.off.autotune(force=force)
         self.n_ghost = plan.n_ghost
         self.recv_counts = [int(c) for c in plan.recv_counts]
         asked = comm.exchange_requests(plan.ghost_cols, plan.recv_counts)
@@ -151,7 +162,8 @@ class ArnoldiContext:
             d = op.diag
             rc = _hip.load().aks_arnoldi_expand(
                 b.n_rows, dev._ptr(d.indptr), dev._ptr(d.indices), dev._ptr(d.values), d.values_complex,
-                dev._ptr(d.tiles), d.n_tiles, d.lanes_per_row, dev._ptr(b.V), b.ldv, dev._ptr(b.H),
+                dev._ptr(d.tiles), d.n_tiles, d.lanes_per_row,
+                C.byref(d.binned.desc) if d.use_binned else None, dev._ptr(b.V), b.ldv, dev._ptr(b.H),
                 self.max_dim, start, end, tol, eta, dev._ptr(ws.buf), ws.nbytes, ws.max_dim,
                 self.probe.handle if self.probe is not None else C.c_void_p(0), dev._stream())
             _hip.check(rc, "aks_arnoldi_expand")

@@ -464,6 +464,107 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int64_t count, const int32_t *
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) dst[i] = src[idx[i]];
 }
 
+// ------------------------------------------------------------------ slab-binned two-phase SpMV
+constexpr int PB_SLAB_BITS = AKS_PB_SLAB_BITS;
+constexpr int PB_RB_BITS = AKS_PB_ROWBLOCK_BITS;
+constexpr int PB_RB = 1 << PB_RB_BITS;
+constexpr int PB_CHUNK = AKS_PB_CHUNK_NNZ;
+constexpr int PB_PER_THREAD = PB_CHUNK / BLOCK;
+
+// Phase 1: prod[dest[k]] = val[k] * x[slab*65536 + lcol[k]] for the chunk's entries.
+// Chunks are dealt so that the workgroups of one XCD (blockIdx % 8, observed placement; speed
+// only) walk a contiguous range of slabs: the slab's 1 MiB of x stays in that XCD's L2.
+template <typename VT>
+__global__ __launch_bounds__(BLOCK) void k_pb_phase1(int64_t n_chunks, int64_t chunks_per_xcd,
+                                                    const int32_t *__restrict__ chunk_begin,
+                                                    const int32_t *__restrict__ chunk_slab,
+                                                    const int32_t *__restrict__ slab_ptr,
+                                                    const VT *__restrict__ val, const uint16_t *__restrict__ lcol,
+                                                    const int32_t *__restrict__ dest, const c128 *__restrict__ x,
+                                                    c128 *__restrict__ prod, const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl != nullptr && ctrl->broken) return;
+    const int64_t c = (int64_t)(blockIdx.x & 7) * chunks_per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= chunks_per_xcd || c >= n_chunks) return;
+    const int slab = chunk_slab[c];
+    const int b = chunk_begin[c];
+    const int e = min(b + PB_CHUNK, slab_ptr[slab + 1]);
+    const c128 *xs = x + ((int64_t)slab << PB_SLAB_BITS);
+    int lc[PB_PER_THREAD], d[PB_PER_THREAD];
+    VT a[PB_PER_THREAD];
+    c128 xv[PB_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < PB_PER_THREAD; ++q) {
+        const int k = min(b + q * BLOCK + (int)threadIdx.x, e - 1);
+        lc[q] = lcol[k];
+        a[q] = val[k];
+        d[q] = dest[k];
+    }
+#pragma unroll
+    for (int q = 0; q < PB_PER_THREAD; ++q) xv[q] = xs[lc[q]];
+#pragma unroll
+    for (int q = 0; q < PB_PER_THREAD; ++q)
+        if (b + q * BLOCK + (int)threadIdx.x < e) prod[d[q]] = cmul(a[q], xv[q]);
+}
+
+// Phase 2: one wave per block of 1024 rows; its products are one contiguous range.  Sums go
+// through LDS float64 atomics issued by that wave only, in program order, so the result does
+// not depend on timing.
+template <bool ACC>
+__global__ __launch_bounds__(BLOCK) void k_pb_phase2(int64_t n_rows, int n_rowblocks,
+                                                    const int32_t *__restrict__ rb_ptr,
+                                                    const uint16_t *__restrict__ lrow,
+                                                    const c128 *__restrict__ prod, c128 *__restrict__ y,
+                                                    const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl != nullptr && ctrl->broken) return;
+    __shared__ double acc_re[WAVES][PB_RB], acc_im[WAVES][PB_RB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rb = blockIdx.x * WAVES + wave;
+    if (rb >= n_rowblocks) return;  // waves are independent
+    double *are = acc_re[wave], *aim = acc_im[wave];
+#pragma unroll
+    for (int q = 0; q < PB_RB / 64; ++q) { are[q * 64 + lane] = 0.0; aim[q * 64 + lane] = 0.0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int k0 = rb_ptr[rb], k1 = rb_ptr[rb + 1];
+    constexpr int U = 8;
+    for (int base = k0; base < k1; base += 64 * U) {
+        c128 p[U];
+        int r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = min(base + u * 64 + lane, k1 - 1);
+            p[u] = prod[k];
+            r[u] = lrow[k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + u * 64 + lane < k1) {
+                unsafeAtomicAdd(&are[r[u]], p[u].x);
+                unsafeAtomicAdd(&aim[r[u]], p[u].y);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int64_t row0 = (int64_t)rb << PB_RB_BITS;
+#pragma unroll 4
+    for (int q = 0; q < PB_RB / 64; ++q) {
+        const int i = q * 64 + lane;
+        const int64_t row = row0 + i;
+        if (row < n_rows) {
+            double sr = are[i], si = aim[i];
+            if (ACC) {
+                const c128 old = y[row];
+                sr += old.x;
+                si += old.y;
+            }
+            y[row] = make_double2(sr, si);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host-side plumbing
 struct Ws {
     aks_ws_layout lay;
@@ -747,23 +848,169 @@ int aks_dgks_gs(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks
     return aks_gs_finish(n_rows, J, d_w, d_Hcol, ldh, tol, eta, normalize, d_ws, ws_bytes, max_dim, stream);
 }
 
+// ---- slab-binned form: host planner -------------------------------------------------------
+int64_t aks_pb_plan_count(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                          int32_t *slab_ptr_out) {
+    if (!indptr || !indices || !slab_ptr_out) return fail(AKS_ERR_ARG, "null pointer");
+    if (n_rows <= 0 || n_cols <= 0 || n_rows >= INT32_MAX || n_cols >= INT32_MAX)
+        return fail(AKS_ERR_ARG, "matrix shape out of range");
+    const int64_t n_slabs = (n_cols + (1 << PB_SLAB_BITS) - 1) >> PB_SLAB_BITS;
+    const int64_t nnz = indptr[n_rows];
+    std::vector<int64_t> cnt(n_slabs, 0);
+    for (int64_t k = 0; k < nnz; ++k) {
+        const int32_t c = indices[k];
+        if (c < 0 || c >= n_cols) return fail(AKS_ERR_ARG, "column index out of range");
+        ++cnt[c >> PB_SLAB_BITS];
+    }
+    int64_t acc = 0, chunks = 0;
+    for (int64_t s = 0; s < n_slabs; ++s) {
+        slab_ptr_out[s] = (int32_t)acc;
+        acc += cnt[s];
+        chunks += (cnt[s] + PB_CHUNK - 1) / PB_CHUNK;
+    }
+    slab_ptr_out[n_slabs] = (int32_t)acc;
+    return chunks;
+}
+
+int aks_pb_plan_fill(const int32_t *indptr, const int32_t *indices, const void *values, int32_t values_complex,
+                     int64_t n_rows, int64_t n_cols, const int32_t *slab_ptr, void *val_out, uint16_t *lcol_out,
+                     int32_t *dest_out, uint16_t *lrow_out, int32_t *rb_ptr_out, int32_t *chunk_begin_out,
+                     int32_t *chunk_slab_out) {
+    if (!indptr || !indices || !values || !slab_ptr || !val_out || !lcol_out || !dest_out || !lrow_out ||
+        !rb_ptr_out || !chunk_begin_out || !chunk_slab_out)
+        return fail(AKS_ERR_ARG, "null pointer");
+    const int64_t n_slabs = (n_cols + (1 << PB_SLAB_BITS) - 1) >> PB_SLAB_BITS;
+    const int64_t n_rb = (n_rows + PB_RB - 1) >> PB_RB_BITS;
+    const int64_t nnz = indptr[n_rows];
+    // tile (slab, rowblock) sizes; rows are visited in order, so entries keep (row, column) order
+    // inside a tile.  Visiting by row block keeps the counter array small: one row block at a time.
+    std::vector<int32_t> p1_next(n_slabs * n_rb + 1, 0);   // becomes the phase-1 write cursor per tile
+    {
+        std::vector<int32_t> &cnt = p1_next;
+        for (int64_t r = 0; r < n_rows; ++r) {
+            const int64_t rb = r >> PB_RB_BITS;
+            for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k)
+                ++cnt[(int64_t)(indices[k] >> PB_SLAB_BITS) * n_rb + rb];
+        }
+    }
+    // phase-2 start of every tile (order: rowblock-major) and rb_ptr
+    std::vector<int32_t> p2_next(n_slabs * n_rb, 0);
+    {
+        int64_t acc = 0;
+        for (int64_t rb = 0; rb < n_rb; ++rb) {
+            rb_ptr_out[rb] = (int32_t)acc;
+            for (int64_t s = 0; s < n_slabs; ++s) {
+                p2_next[s * n_rb + rb] = (int32_t)acc;
+                acc += p1_next[s * n_rb + rb];
+            }
+        }
+        rb_ptr_out[n_rb] = (int32_t)acc;
+        if (acc != nnz) return fail(AKS_ERR_ARG, "inconsistent CSR arrays");
+    }
+    // phase-1 start of every tile (order: slab-major) -- exclusive scan in place
+    {
+        int64_t acc = 0;
+        for (int64_t t = 0; t < n_slabs * n_rb; ++t) {
+            const int32_t c = p1_next[t];
+            p1_next[t] = (int32_t)acc;
+            acc += c;
+        }
+        for (int64_t s = 0; s <= n_slabs; ++s) {
+            const int64_t at = s < n_slabs ? p1_next[s * n_rb] : nnz;
+            if (at != slab_ptr[s]) return fail(AKS_ERR_ARG, "slab_ptr does not match the matrix");
+        }
+    }
+    const double *vr = static_cast<const double *>(values);
+    double *vo = static_cast<double *>(val_out);
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t rb = r >> PB_RB_BITS;
+        const uint16_t lr = (uint16_t)(r & (PB_RB - 1));
+        for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
+            const int32_t c = indices[k];
+            const int64_t t = (int64_t)(c >> PB_SLAB_BITS) * n_rb + rb;
+            const int32_t k1 = p1_next[t]++;
+            const int32_t k2 = p2_next[t]++;
+            lcol_out[k1] = (uint16_t)(c & ((1 << PB_SLAB_BITS) - 1));
+            dest_out[k1] = k2;
+            lrow_out[k2] = lr;
+            if (values_complex) {
+                vo[2 * (int64_t)k1] = vr[2 * (int64_t)k];
+                vo[2 * (int64_t)k1 + 1] = vr[2 * (int64_t)k + 1];
+            } else {
+                vo[k1] = vr[k];
+            }
+        }
+    }
+    int64_t c = 0;
+    for (int64_t s = 0; s < n_slabs; ++s)
+        for (int32_t b = slab_ptr[s]; b < slab_ptr[s + 1]; b += PB_CHUNK) {
+            chunk_begin_out[c] = b;
+            chunk_slab_out[c] = (int32_t)s;
+            ++c;
+        }
+    return AKS_OK;
+}
+
+int aks_pb_spmv(const aks_pb_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate, const void *d_ws,
+                void *stream) {
+    if (A == nullptr || d_x == nullptr || d_y == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    if (A->n_rows <= 0 || A->n_cols <= 0 || A->nnz < 0 || A->n_chunks < 0) return fail(AKS_ERR_ARG, "bad sizes");
+    if (A->n_slabs != (int32_t)((A->n_cols + (1 << PB_SLAB_BITS) - 1) >> PB_SLAB_BITS) ||
+        A->n_rowblocks != (int32_t)((A->n_rows + PB_RB - 1) >> PB_RB_BITS))
+        return fail(AKS_ERR_ARG, "n_slabs / n_rowblocks do not match the shape");
+    if (!A->d_rb_ptr || (A->nnz > 0 && (!A->d_val || !A->d_lcol || !A->d_dest || !A->d_lrow || !A->d_slab_ptr ||
+                                        !A->d_chunk_begin || !A->d_chunk_slab || !A->d_prod)))
+        return fail(AKS_ERR_ARG, "null array in aks_pb_matrix");
+    if (d_x == d_y) return fail(AKS_ERR_ARG, "x and y must not alias");
+    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const c128 *x = reinterpret_cast<const c128 *>(d_x);
+    c128 *y = reinterpret_cast<c128 *>(d_y);
+    c128 *prod = reinterpret_cast<c128 *>(A->d_prod);
+    if (A->n_chunks > 0) {
+        const int64_t cpx = (A->n_chunks + 7) / 8;
+        const dim3 grid((unsigned)(cpx * 8));
+        if (A->values_complex)
+            hipLaunchKernelGGL(k_pb_phase1<c128>, grid, dim3(BLOCK), 0, s, A->n_chunks, cpx, A->d_chunk_begin,
+                               A->d_chunk_slab, A->d_slab_ptr, static_cast<const c128 *>(A->d_val), A->d_lcol,
+                               A->d_dest, x, prod, ctrl);
+        else
+            hipLaunchKernelGGL(k_pb_phase1<double>, grid, dim3(BLOCK), 0, s, A->n_chunks, cpx, A->d_chunk_begin,
+                               A->d_chunk_slab, A->d_slab_ptr, static_cast<const double *>(A->d_val), A->d_lcol,
+                               A->d_dest, x, prod, ctrl);
+    }
+    const dim3 grid2((unsigned)((A->n_rowblocks + WAVES - 1) / WAVES));
+    if (accumulate)
+        hipLaunchKernelGGL(k_pb_phase2<true>, grid2, dim3(BLOCK), 0, s, A->n_rows, A->n_rowblocks, A->d_rb_ptr,
+                           A->d_lrow, prod, y, ctrl);
+    else
+        hipLaunchKernelGGL(k_pb_phase2<false>, grid2, dim3(BLOCK), 0, s, A->n_rows, A->n_rowblocks, A->d_rb_ptr,
+                           A->d_lrow, prod, y, ctrl);
+    AKS_CHECK_LAUNCH("aks_pb_spmv");
+    return AKS_OK;
+}
+
 int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const void *d_values,
                        int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row,
-                       aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh, int32_t start_dim,
-                       int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes, int32_t max_dim,
-                       void *probe, void *stream) {
+                       const aks_pb_matrix *pb, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
+                       int32_t start_dim, int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
+                       int32_t max_dim, void *probe, void *stream) {
     if (start_dim < 0 || end_dim > max_dim || start_dim > end_dim)
         return fail(AKS_ERR_ARG, "need 0 <= start_dim <= end_dim <= max_dim");
     if (d_V == nullptr || d_H == nullptr) return fail(AKS_ERR_ARG, "null pointer");
     if (ldh < max_dim) return fail(AKS_ERR_ARG, "ldh < max_dim");
+    if (pb != nullptr && (pb->n_rows != n_rows || pb->n_cols != n_rows))
+        return fail(AKS_ERR_ARG, "binned matrix shape does not match n_rows");
     Probe *pr = static_cast<Probe *>(probe);
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (int32_t j = start_dim; j < end_dim; ++j) {
         aks_c128 *x = d_V + (int64_t)j * ldv;
         aks_c128 *w = d_V + (int64_t)(j + 1) * ldv;
         hipEvent_t done = pr ? pr->begin(AKS_PROBE_SPMV, s) : nullptr;
-        int rc = aks_csr_spmv(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
-                              lanes_per_row, x, w, 0, d_ws, stream);
+        int rc = pb != nullptr
+                     ? aks_pb_spmv(pb, x, w, 0, d_ws, stream)
+                     : aks_csr_spmv(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
+                                    lanes_per_row, x, w, 0, d_ws, stream);
         if (done) (void)hipEventRecord(done, s);
         if (rc != AKS_OK) return rc;
         done = pr ? pr->begin(AKS_PROBE_ORTHO, s) : nullptr;

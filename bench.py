@@ -265,7 +265,12 @@ def main():
             "setup_s": round(t_setup, 2),
             "arnoldi_steps_timed": steps_done,
             "roofline": {
-                "kernel": "k_spmv<double,false>" if world == 1 else "sharded SpMV (pack + all-to-all + diag + off-diag), rank 0",
+                "kernel": (("k_pb_phase1<double> + k_pb_phase2<false> (slab-binned SpMV, one pair per launch)"
+                            if op.spmv_form == "binned" else "k_spmv<double,false> (CSR-stream SpMV)")
+                           if world == 1 else
+                           f"sharded SpMV, rank 0 (pack + all-to-all + diag[{op.spmv_form}] + off-diag)"),
+                "spmv_form": op.spmv_form,
+                "spmv_autotune_ms": getattr(op.diag, "tune_ms", None),
                 "bound": "hbm",
                 "achieved": round(achieved, 1) if achieved else None,
                 "peak": HBM_PEAK_GBS,

@@ -102,6 +102,48 @@ int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indic
                  int64_t n_tiles, int32_t lanes_per_row, const aks_c128 *d_x, aks_c128 *d_y,
                  int32_t accumulate, const void *d_ws, void *stream);
 
+/* ---- slab-binned two-phase SpMV (same operation, for matrices without column locality) ----
+ * When the columns of a row are scattered over all of x (random graphs), every 16-B gather of
+ * the CSR kernel misses the 4 MiB L2 of its XCD and the kernel runs at the fabric's request
+ * rate.  The binned form trades that for two streaming passes:
+ *   phase 1  non-zeros ordered by (column slab of 2^16 entries = 1 MiB of x, row block, row):
+ *            workgroups of one XCD sweep one slab at a time, so gathers hit L2; each product
+ *            val * x[col] is written to its slot in phase-2 order (runs of one tile);
+ *   phase 2  one wave per block of 1024 rows streams its products (contiguous) and sums them
+ *            into LDS accumulators, then writes y.
+ * aks_pb_plan_* are pure host functions that build the arrays from a canonical CSR matrix
+ * (int32 indices); the caller uploads them and fills aks_pb_matrix with device pointers.     */
+#define AKS_PB_SLAB_BITS 16      /* columns per slab = 65536                                  */
+#define AKS_PB_ROWBLOCK_BITS 10  /* rows per phase-2 wave = 1024                              */
+#define AKS_PB_CHUNK_NNZ 2048    /* non-zeros per phase-1 workgroup                           */
+
+typedef struct aks_pb_matrix {
+    int64_t n_rows, n_cols, nnz, n_chunks;
+    int32_t n_slabs, n_rowblocks, values_complex, pad_;
+    const void *d_val;              /* nnz values (f64 or c128), phase-1 order                */
+    const uint16_t *d_lcol;         /* nnz: column - slab * 65536, phase-1 order              */
+    const int32_t *d_dest;          /* nnz: phase-2 position of each phase-1 entry            */
+    const uint16_t *d_lrow;         /* nnz: row - rowblock * 1024, phase-2 order              */
+    const int32_t *d_rb_ptr;        /* n_rowblocks + 1: phase-2 range of each row block       */
+    const int32_t *d_slab_ptr;      /* n_slabs + 1: phase-1 range of each slab                */
+    const int32_t *d_chunk_begin;   /* n_chunks: first phase-1 entry of each workgroup chunk  */
+    const int32_t *d_chunk_slab;    /* n_chunks: slab the chunk lies in                       */
+    aks_c128 *d_prod;               /* nnz complex128 scratch (the products)                  */
+} aks_pb_matrix;
+
+/* Pass 1 (host): entries per slab -> slab_ptr_out[0 .. n_slabs] (n_slabs = ceil(n_cols / 65536)).
+ * Returns the number of phase-1 chunks, or a negative error. */
+int64_t aks_pb_plan_count(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
+                          int32_t *slab_ptr_out);
+/* Pass 2 (host): fills every array of the binned form (sizes as in aks_pb_matrix). */
+int aks_pb_plan_fill(const int32_t *indptr, const int32_t *indices, const void *values,
+                     int32_t values_complex, int64_t n_rows, int64_t n_cols, const int32_t *slab_ptr,
+                     void *val_out, uint16_t *lcol_out, int32_t *dest_out, uint16_t *lrow_out,
+                     int32_t *rb_ptr_out, int32_t *chunk_begin_out, int32_t *chunk_slab_out);
+/* y = A x or y += A x with the binned form (two launches on `stream`). */
+int aks_pb_spmv(const aks_pb_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate,
+                const void *d_ws, void *stream);
+
 /* ---- orthogonalisation: replaces dgks_gs (ortho.py:56-107) ---------------
  * Stage entry points, in call order.  Between stages a multi-GPU host
  * all-reduces the named slot over the row shards (RCCL); with one GPU the
@@ -136,13 +178,14 @@ int aks_dgks_gs(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks
 /* ---- Arnoldi expansion: replaces arnoldi_decomposition (decomposition.py:13-68)
  * for j in [start_dim, end_dim):  V[:, j+1] = A V[:, j]; dgks_gs; normalise.
  * Single GPU, no host synchronisation; results (H columns, control block) are
- * read back by the caller afterwards. */
+ * read back by the caller afterwards.  If `pb` is not NULL the operator is applied with
+ * aks_pb_spmv(pb, ...) and the CSR arguments are ignored. */
 int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
                        const void *d_values, int32_t values_complex, const int32_t *d_tiles,
-                       int64_t n_tiles, int32_t lanes_per_row, aks_c128 *d_V, int64_t ldv,
-                       aks_c128 *d_H, int64_t ldh, int32_t start_dim, int32_t end_dim, double tol,
-                       double eta, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *probe,
-                       void *stream);
+                       int64_t n_tiles, int32_t lanes_per_row, const aks_pb_matrix *pb,
+                       aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh, int32_t start_dim,
+                       int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
+                       int32_t max_dim, void *probe, void *stream);
 
 /* ---- restart compression: replaces krylov_schur.py:78 and :81 --------------
  * V[:, :p] = V[:, :m] @ Qp   (in place, row-block by row-block)   and

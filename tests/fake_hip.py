@@ -34,7 +34,8 @@ def _view(p, dtype, count):
 class FakeHip:
     def __init__(self, real):
         self._real = real
-        for name in ("aks_last_error", "aks_abi_version", "aks_workspace_layout", "aks_csr_plan_tiles"):
+        for name in ("aks_last_error", "aks_abi_version", "aks_workspace_layout", "aks_csr_plan_tiles",
+                     "aks_pb_plan_count", "aks_pb_plan_fill"):
             setattr(self, name, getattr(real, name))
         self.calls = []
 
@@ -73,6 +74,34 @@ class FakeHip:
         assert t[0] == 0 and t[-1] == n_rows and np.all(np.diff(t) > 0)
         r = A @ xv
         yv[:] = yv + r if acc else r
+        return 0
+
+    def aks_pb_spmv(self, A, x, y, acc, ws, stream):
+        """The two phases of the slab-binned form, replayed with NumPy on the planned arrays."""
+        self.calls.append("pb_spmv")
+        if _addr(ws) and _view(ws, np.int32, 1)[0]:
+            return 0
+        d = A._obj if hasattr(A, "_obj") else A.contents
+        nnz, n_rows, n_cols = int(d.nnz), int(d.n_rows), int(d.n_cols)
+        yv = _view(y, C128, n_rows)
+        out = np.zeros(n_rows, C128)
+        if nnz:
+            val = _view(d.d_val, C128 if d.values_complex else np.float64, nnz)
+            lcol = _view(d.d_lcol, np.uint16, nnz).astype(np.int64)
+            dest = _view(d.d_dest, np.int32, nnz)
+            lrow = _view(d.d_lrow, np.uint16, nnz).astype(np.int64)
+            slab_ptr = _view(d.d_slab_ptr, np.int32, d.n_slabs + 1)
+            rb_ptr = _view(d.d_rb_ptr, np.int32, d.n_rowblocks + 1)
+            cb = _view(d.d_chunk_begin, np.int32, d.n_chunks)
+            cs = _view(d.d_chunk_slab, np.int32, d.n_chunks)
+            assert np.all(slab_ptr[cs] <= cb) and np.all(cb < slab_ptr[cs + 1])
+            slab_of = np.repeat(np.arange(d.n_slabs, dtype=np.int64), np.diff(slab_ptr))
+            xv = _view(x, C128, n_cols)
+            prod = _view(d.d_prod, C128, nnz)
+            prod[dest] = val * xv[(slab_of << 16) + lcol]                      # phase 1
+            rb_of = np.repeat(np.arange(d.n_rowblocks, dtype=np.int64), np.diff(rb_ptr))
+            np.add.at(out, (rb_of << 10) + lrow, prod)                          # phase 2
+        yv[:] = yv + out if acc else out
         return 0
 
     # ---- Gram-Schmidt stages ---------------------------------------------------------
@@ -140,13 +169,16 @@ class FakeHip:
         self.aks_gs_update_norm(n, J, V, ldv, w, eta, ws, ws_bytes, max_dim, stream)
         return self.aks_gs_finish(n, J, w, Hcol, ldh, tol, eta, normalize, ws, ws_bytes, max_dim, stream)
 
-    def aks_arnoldi_expand(self, n, indptr, indices, values, cplx, tiles, n_tiles, lpr, V, ldv, H, ldh,
+    def aks_arnoldi_expand(self, n, indptr, indices, values, cplx, tiles, n_tiles, lpr, pb, V, ldv, H, ldh,
                            start, end, tol, eta, ws, ws_bytes, max_dim, probe, stream):
         self.calls.append("expand")
         for j in range(start, end):
             x = _addr(V) + 16 * ldv * j
             w = _addr(V) + 16 * ldv * (j + 1)
-            self.aks_csr_spmv(n, indptr, indices, values, cplx, tiles, n_tiles, lpr, x, w, 0, ws, stream)
+            if pb is not None:
+                self.aks_pb_spmv(pb, x, w, 0, ws, stream)
+            else:
+                self.aks_csr_spmv(n, indptr, indices, values, cplx, tiles, n_tiles, lpr, x, w, 0, ws, stream)
             self.aks_dgks_gs(n, j + 1, V, ldv, w, _addr(H) + 16 * j, ldh, tol, eta, 1, ws, ws_bytes, max_dim, stream)
         return 0
 

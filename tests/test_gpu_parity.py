@@ -98,6 +98,72 @@ def test_spmv_configs_small(amd):
         assert _relerr(dy.cpu().numpy(), oracle.csr_matvec(A, x)) < RTOL
 
 
+@pytest.mark.parametrize("kind", ["ragged_real", "ragged_complex", "random", "wide", "tall", "laplace"])
+def test_spmv_binned_form(amd, kind):
+    """The slab-binned two-phase kernels (aks_pb_spmv) against the oracle: several slabs and row
+    blocks, empty rows, a long row, complex values, non-square blocks, accumulate; and bitwise
+    run-to-run reproducibility (LDS atomics are issued by one wave in program order)."""
+    import torch
+    from arnoldi_amd import matrices
+    from arnoldi_amd.device import DeviceCSR
+
+    rng = np.random.default_rng(11)
+    if kind.startswith("ragged"):
+        A = _ragged_matrix(3000, 5, kind.endswith("complex"))
+    elif kind == "random":
+        A = matrices.random_csr(300_000, 5, 77)
+    elif kind == "wide":      # few rows, many slabs (an off-diagonal block of a row shard)
+        A = sp.random(2500, 400_000, density=2e-5, random_state=np.random.RandomState(1), format="csr")
+    elif kind == "tall":
+        A = sp.random(150_000, 700, density=4e-3, random_state=np.random.RandomState(2), format="csr")
+    else:
+        A = matrices.laplace2d(300, 311)
+    A = sp.csr_matrix(A)
+    n_rows, n_cols = A.shape
+    x = (rng.standard_normal(n_cols) + 1j * rng.standard_normal(n_cols)).astype(C128)
+    y0 = (rng.standard_normal(n_rows) + 1j * rng.standard_normal(n_rows)).astype(C128)
+    dA = DeviceCSR(A)
+    assert dA.autotune(force="binned") == "binned" and dA.use_binned
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.from_numpy(y0).cuda()
+    dA.spmv(dx, dy)
+    first = dy.cpu().numpy().copy()
+    ref = oracle.csr_matvec(A, x)
+    assert _relerr(first, ref) < RTOL
+    assert np.all(first[np.diff(A.indptr) == 0] == 0)
+    dA.spmv(dx, dy, accumulate=True)
+    assert _relerr(dy.cpu().numpy(), 2 * ref) < RTOL
+    dy2 = torch.empty_like(dy)
+    for _ in range(3):
+        dA.spmv(dx, dy2)
+        np.testing.assert_array_equal(dy2.cpu().numpy(), first)
+
+
+def test_spmv_autotune_picks_by_measurement(amd):
+    from arnoldi_amd import matrices
+    from arnoldi_amd.device import DeviceCSR
+
+    lap = DeviceCSR(matrices.laplace2d(1500, 1501))
+    assert lap.autotune() == "csr" and lap.binned is None          # stencil: not even a candidate
+    rnd = DeviceCSR(matrices.random_csr(4_000_000, 5, 3))
+    choice = rnd.autotune()
+    assert set(rnd.tune_ms) == {"csr", "binned"} and choice in ("csr", "binned")
+    assert (choice == "binned") == (rnd.tune_ms["binned"] < 0.9 * rnd.tune_ms["csr"])
+
+
+def test_partial_schur_with_binned_spmv(amd):
+    """Same solve through both SpMV forms: identical restart counts and eigenvalues."""
+    from arnoldi_amd.engine import CsrOperator
+
+    g8 = load_golden("g8_random_planted")
+    A = _planted_like_golden(int(g8["n"]))
+    for form in ("csr", "binned"):
+        op = CsrOperator(A, spmv_form=form)
+        assert op.spmv_form == form
+        _solve_and_compare(amd, op, g8, "s0_", 0, nev=5, max_dim=20, sort_function=oracle.arg_largest_magnitude,
+                           residual_matrix=A)
+
+
 # ---------------------------------------------------------------------------- Gram-Schmidt
 @pytest.mark.parametrize("tag,second", [("generic", False), ("near", True), ("inside", True)])
 def test_dgks_gs_golden(amd, tag, second):
@@ -225,10 +291,12 @@ def test_truncate(amd, m, p):
 
 
 # ---------------------------------------------------------------------------- full solves
-def _solve_and_compare(amd, A, g, prefix, seed, expect_same_restarts=True, **kw):
+def _solve_and_compare(amd, A, g, prefix, seed, expect_same_restarts=True, residual_matrix=None, **kw):
     np.random.seed(seed)
     stats = {}
     Q, T, hist = amd.partial_schur(A, stats=stats, **kw)
+    if residual_matrix is not None:
+        A = residual_matrix
     assert Q.shape == (A.shape[0], kw["nev"]) and Q.flags.f_contiguous and Q.dtype == C128
     assert T.shape == (kw["nev"], kw["nev"]) and T.dtype == C128
     if expect_same_restarts:

@@ -385,3 +385,52 @@ def test_row_sharded_solve_two_ranks_gloo(tmp_path):
     """world_size = 2 over gloo on CPU tensors: partition, ghost exchange, all-reduces and the
     stage chaining of the multi-GPU driver, against single-process oracle solves."""
     check_dist_verdicts(run_dist_worker(tmp_path, 2, "gloo", "cpu"))
+
+
+# ---------------------------------------------------------------------------- slab-binned SpMV form
+@pytest.mark.parametrize("shape,complex_vals", [((5000, 5000), False), ((3000, 200_000), True), ((70_000, 900), False)])
+def test_binned_plan_represents_the_matrix(fake, shape, complex_vals):
+    """aks_pb_plan_count / aks_pb_plan_fill are host code: replaying the two phases on the planned
+    arrays (tests/fake_hip.py) must reproduce A @ x, including empty rows, several slabs, several
+    row blocks and non-square shapes (the off-diagonal blocks of a row shard)."""
+    import torch
+    from arnoldi_amd import _hip
+    from arnoldi_amd.device import DeviceCSR
+
+    rng = np.random.default_rng(shape[0])
+    n_rows, n_cols = shape
+    nnz = 6 * n_rows
+    rows = rng.integers(0, n_rows, nnz)
+    rows[rows % 7 == 0] = 1                       # empty rows + one long row
+    cols = rng.integers(0, n_cols, nnz)
+    vals = rng.standard_normal(nnz) + (1j * rng.standard_normal(nnz) if complex_vals else 0)
+    A = sp.csr_matrix((vals, (rows, cols)), shape=shape)
+    A.sum_duplicates()
+    dA = DeviceCSR(A)
+    b = dA.build_binned()
+    d = b.desc
+    assert d.n_slabs == -(-n_cols // 65536) and d.n_rowblocks == -(-n_rows // 1024) and d.nnz == A.nnz
+    slab_ptr, rb_ptr = b.slab_ptr.numpy(), b.rb_ptr.numpy()
+    assert slab_ptr[0] == 0 and slab_ptr[-1] == A.nnz and rb_ptr[-1] == A.nnz
+    assert d.n_chunks == sum(-(-int(c) // _hip.PB_CHUNK_NNZ) for c in np.diff(slab_ptr))
+    assert sorted(b.dest.numpy().tolist()) == list(range(A.nnz))          # a permutation
+    x = torch.from_numpy((rng.standard_normal(n_cols) + 1j * rng.standard_normal(n_cols)).astype(C128))
+    y = torch.from_numpy((rng.standard_normal(n_rows) + 0j).astype(C128))
+    y0 = y.numpy().copy()
+    dA.use_binned = True
+    dA.spmv(x, y)
+    np.testing.assert_allclose(y.numpy(), A @ x.numpy(), rtol=1e-12, atol=1e-12)
+    dA.spmv(x, y, accumulate=True)
+    np.testing.assert_allclose(y.numpy(), 2 * (A @ x.numpy()), rtol=1e-12, atol=1e-12)
+    assert "pb_spmv" in fake.calls and not np.array_equal(y0, y.numpy())
+
+
+def test_scatter_ratio_separates_stencils_from_random_graphs():
+    from arnoldi_amd import matrices
+    from arnoldi_amd.device import DeviceCSR
+
+    ratio = lambda A: DeviceCSR.scatter_ratio(type("S", (), {"_host": sp.csr_matrix(A), "nnz": A.nnz,  # noqa: E731
+                                                              "n_rows": A.shape[0]})())
+    assert ratio(matrices.laplace2d(300, 301)) < 0.2
+    assert ratio(matrices.laplace3d(40, 41, 42)) < 0.3
+    assert ratio(matrices.random_csr(200_000, 5, 1)) > 0.9
