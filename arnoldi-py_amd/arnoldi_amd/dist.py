@@ -88,13 +88,21 @@ class Comm:
     device tensors are staged through host memory.
     """
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
+        """``force``: issue the collectives even in a one-rank group (lets a single GPU exercise
+        the RCCL calls of the multi-rank path)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
+        self.force = bool(force)
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+
+    @property
+    def active(self):
+        """True when collectives have to be issued (more than one rank, or forced)."""
+        return self.size > 1 or self.force
 
     # -- small host-side exchanges used while building plans -----------------
     def allgather_int64(self, values):
@@ -103,21 +111,33 @@ class Comm:
         dist.all_gather_object(objs, values, group=self.group)
         return objs
 
+    def _wire_device(self):
+        """Where tensors handed to the collectives must live (nccl: this rank's GPU)."""
+        return torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+
     def exchange_requests(self, ghost_cols, recv_counts):
-        """Tell every owner which of its entries this rank needs.  Returns, per peer,
-        the global ids that peer asked from us."""
-        chunks, pos = [], 0
-        for r in range(self.size):
-            chunks.append(ghost_cols[pos: pos + int(recv_counts[r])])
-            pos += int(recv_counts[r])
-        everyone = [None] * self.size
-        dist.all_gather_object(everyone, chunks, group=self.group)
-        return [everyone[peer][self.rank] for peer in range(self.size)]
+        """Tell every owner which of its entries this rank needs (``ghost_cols`` is sorted, so
+        it is already grouped by owner; ``recv_counts[r]`` of them belong to rank r).  Returns,
+        per peer, the global ids that peer asked from us.  Two all-to-alls: counts, then ids."""
+        dev = self._wire_device()
+        want = torch.as_tensor(np.asarray(recv_counts, dtype=np.int64), device=dev)
+        asked = torch.empty_like(want)
+        dist.all_to_all_single(asked, want, group=self.group)
+        send_counts = [int(c) for c in asked.cpu().tolist()]
+        ids_out = torch.as_tensor(np.ascontiguousarray(ghost_cols, dtype=np.int64), device=dev)
+        ids_in = torch.empty(sum(send_counts), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(ids_in, ids_out, send_counts, [int(c) for c in recv_counts], group=self.group)
+        ids_in = ids_in.cpu().numpy()
+        out, pos = [], 0
+        for c in send_counts:
+            out.append(ids_in[pos: pos + c])
+            pos += c
+        return out
 
     # -- data-path collectives ---------------------------------------------------
     def allreduce_sum_(self, t):
         """In-place sum all-reduce of a small float64 device tensor (stream ordered on nccl)."""
-        if self.size == 1:
+        if not self.active:
             return
         if self.backend == "nccl" or not t.is_cuda:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

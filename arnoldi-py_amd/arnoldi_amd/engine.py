@@ -156,7 +156,7 @@ class ArnoldiContext:
         of H into the host array exactly as the reference's in-place writes would.
         Returns n_iter (== end unless a step broke down)."""
         b, ws, op = self.basis, self.ws, self.op
-        native = (isinstance(op, CsrOperator) and (op.comm is None or op.comm.size == 1)
+        native = (isinstance(op, CsrOperator) and (op.comm is None or not op.comm.active)
                   and not self.force_chained)
         if native:
             d = op.diag
@@ -169,7 +169,7 @@ class ArnoldiContext:
             _hip.check(rc, "aks_arnoldi_expand")
         else:
             hbase = b.H.data_ptr()
-            multi = self.comm is not None and self.comm.size > 1
+            multi = self.comm is not None and self.comm.active
             for j in range(start, end):
                 J = j + 1
                 w = b.col(J)

@@ -479,3 +479,25 @@ def test_row_sharded_two_ranks_share_the_gpu(amd, tmp_path):
     from test_host_logic import check_dist_verdicts, run_dist_worker
 
     check_dist_verdicts(run_dist_worker(tmp_path, 2, "gloo", "cuda"))
+
+
+def test_rccl_collectives_one_rank(amd, tmp_path):
+    """The collectives of the multi-rank path issued through RCCL (torch 'nccl') on a one-rank
+    group, real kernels: workspace-slot all-reduces, uneven all-to-all incl. empty messages, the
+    request exchange, and a full staged solve against the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+
+    out = os.path.join(tmp_path, "nccl1.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_single_worker.py"), out],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    r = json.load(open(out))
+    assert r["backend"] == "nccl"
+    assert r["allreduce_ok"] and r["alltoall_ok"] and r["requests_ok"] and r["allgather_ok"]
+    s = r["solve"]
+    assert s["restarts_equal"] and s["eig_err"] < 1e-9 and s["rel"] <= max(1.05 * s["rel_oracle"], 1e-13)
