@@ -143,3 +143,23 @@ def random_csr(n, per_row=5, seed=1234, planted=None, row_range=None):
     if A.nnz < 2**31 - 1 and n < 2**31 - 1:
         A = sp.csr_matrix((A.data, A.indices.astype(np.int32), A.indptr.astype(np.int32)), shape=A.shape)
     return A
+
+
+def banded_csr(n, per_row=35, seed=1234, planted=None, dtype=np.float64):
+    """Stand-in for BASELINE config 3 (SuiteSparse af_shell10 is not available offline): a
+    symmetric-pattern band of ``per_row`` entries per row (offsets -h..h, h = per_row // 2,
+    clipped at the ends), off-diagonal values U(-1, 1), diagonal U(0, 1) * per_row / 4.
+    ``planted``: diagonal values written on evenly spaced rows (dominant eigenvalues)."""
+    rng = np.random.default_rng(seed)
+    h = per_row // 2
+    offs = np.arange(-h, h + 1, dtype=np.int64)
+    rows = np.arange(n, dtype=np.int64)
+    cols = rows[:, None] + offs[None, :]
+    ok = (cols >= 0) & (cols < n)
+    vals = rng.uniform(-1.0, 1.0, cols.shape).astype(dtype)
+    vals[:, h] = rng.uniform(0.0, 1.0, n) * per_row / 4
+    if planted is not None:
+        where = np.linspace(n // 7, n - n // 7, len(planted)).astype(np.int64)
+        vals[where, h] = planted
+    indptr = np.concatenate([[0], np.cumsum(ok.sum(axis=1))])
+    return sp.csr_matrix((vals[ok], cols[ok].astype(np.int32), indptr.astype(np.int32)), shape=(n, n))

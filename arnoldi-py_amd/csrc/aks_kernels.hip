@@ -59,7 +59,9 @@ int hip_fail(hipError_t e, const char *where) {
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 constexpr int MAX_ROW_BLOCKS = 1024;
-constexpr int NC_MAX = 32;  // widest exact-width panel kernel
+constexpr int NC_MAX = 32;        // widest exact-width projection kernel (accumulators only)
+constexpr int NC_FUSED_MAX = 41;  // widest fused update + re-projection kernel (panel row + accumulators
+                                  // in registers: 8 NC VGPRs; 41 is the last width without scratch spills)
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -623,11 +625,15 @@ void dispatch_proj(int nc, dim3 grid, hipStream_t s, int64_t n, int c0, const c1
     }
 }
 
+#define AKS_NC_WIDE_CASES(M) \
+    M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40) M(41)
+
 void dispatch_update_proj(int nc, dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
                           const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl) {
     switch (nc) {
 #define M(N) case N: launch_update_proj_nc<N>(grid, s, n, V, ldv, w, h, partial, ldp, ctrl); break;
         AKS_NC_CASES(M)
+        AKS_NC_WIDE_CASES(M)
 #undef M
         default: break;
     }
@@ -789,7 +795,7 @@ int aks_gs_update_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_
     hipStream_t s = static_cast<hipStream_t>(stream);
     const c128 *V = reinterpret_cast<const c128 *>(d_V);
     c128 *w = reinterpret_cast<c128 *>(d_w);
-    if (J <= NC_MAX) {
+    if (J <= NC_FUSED_MAX) {
         dispatch_update_proj(J, dim3(ws.lay.n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
                              ws.lay.ld_partial, ws.ctrl);
         hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,

@@ -185,11 +185,12 @@ def test_dgks_gs_golden(amd, tag, second):
         assert beta < 1e-8
 
 
-@pytest.mark.parametrize("J", [1, 2, 7, 20, 31, 32, 33, 40, 64, 65, 100, 128])
+@pytest.mark.parametrize("J", [1, 2, 7, 20, 31, 32, 33, 40, 41, 42, 64, 65, 100, 128])
 @pytest.mark.parametrize("n", [257, 5003])
 def test_dgks_gs_widths(amd, J, n):
-    """Every panel width class: exact-width fused kernels (J <= 32), grouped projections and
-    the un-fused update (J > 32); n not a multiple of the block size."""
+    """Every panel width class: exact-width projection (J <= 32) and fused update + re-projection
+    kernels (J <= 41), grouped projections and the un-fused update beyond; n not a multiple of
+    the block size."""
     from arnoldi_amd.ortho import dgks_gs
 
     if J >= n:
