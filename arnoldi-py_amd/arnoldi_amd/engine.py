@@ -16,6 +16,7 @@ all-reduce of the (J+1)-vector between stages.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -33,8 +34,6 @@ class CsrOperator:
         """``spmv_form``: None/"auto" (time the CSR-stream and the slab-binned kernels on large
         scattered matrices and keep the faster), "csr" or "binned".  Environment override:
         AKS_SPMV_FORM."""
-        import os
-
         form = os.environ.get("AKS_SPMV_FORM", spmv_form or "auto")
         force = None if form == "auto" else form
         self.comm = comm
@@ -149,6 +148,8 @@ class ArnoldiContext:
         self.probe = None   # optional _hip.Probe (bench.py): device time of SpMV / ortho launches
         self.spmv_events = None  # optional list (bench.py, Python-chained path): torch event pairs
         self.force_chained = False  # run the Python-chained stage path even on one GPU (tests, bench)
+        self.use_graph = os.environ.get("AKS_GRAPH", "1") != "0"   # hipGraph replay of re-expansions
+        self._graphs = {}
 
     # -- seam 1 ------------------------------------------------------------------
     def expand(self, H, start, end, tol, eta=dev.ETA_DGKS):
@@ -160,13 +161,31 @@ class ArnoldiContext:
                   and not self.force_chained)
         if native:
             d = op.diag
-            rc = _hip.load().aks_arnoldi_expand(
-                b.n_rows, dev._ptr(d.indptr), dev._ptr(d.indices), dev._ptr(d.values), d.values_complex,
-                dev._ptr(d.tiles), d.n_tiles, d.lanes_per_row,
-                C.byref(d.binned.desc) if d.use_binned else None, dev._ptr(b.V), b.ldv, dev._ptr(b.H),
-                self.max_dim, start, end, tol, eta, dev._ptr(ws.buf), ws.nbytes, ws.max_dim,
-                self.probe.handle if self.probe is not None else C.c_void_p(0), dev._stream())
-            _hip.check(rc, "aks_arnoldi_expand")
+
+            def enqueue():
+                rc = _hip.load().aks_arnoldi_expand(
+                    b.n_rows, dev._ptr(d.indptr), dev._ptr(d.indices), dev._ptr(d.values), d.values_complex,
+                    dev._ptr(d.tiles), d.n_tiles, d.lanes_per_row,
+                    C.byref(d.binned.desc) if d.use_binned else None, dev._ptr(b.V), b.ldv, dev._ptr(b.H),
+                    self.max_dim, start, end, tol, eta, dev._ptr(ws.buf), ws.nbytes, ws.max_dim,
+                    self.probe.handle if self.probe is not None else C.c_void_p(0), dev._stream())
+                _hip.check(rc, "aks_arnoldi_expand")
+
+            # The re-expansion (start = p) is the same launch sequence with the same arguments at
+            # every restart (DGKS decisions and breakdown are taken on the device), so it is
+            # captured once into a hipGraph and replayed: one host call per restart instead of
+            # ~10 launches per Arnoldi step.  Not used while a probe records per-kernel events.
+            key = (start, end, float(tol), float(eta))
+            if self.use_graph and self.probe is None and start > 0:
+                g = self._graphs.get(key)
+                if g is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        enqueue()
+                    self._graphs[key] = g
+                g.replay()
+            else:
+                enqueue()
         else:
             hbase = b.H.data_ptr()
             multi = self.comm is not None and self.comm.active

@@ -219,12 +219,12 @@ def main():
     steps_done = int(ctx.last_ctrl.steps_done) - steps0
     seconds = int(ctx.last_ctrl.second_passes) - second0
     ortho = None
+    frac_second = seconds / max(steps_done, 1)
+    per_cycle = 0.0   # Gram-Schmidt bytes of one restart's m - p steps, at the measured second-pass rate
+    for J in range(p + 1, m + 1):
+        per_cycle += (frac_second * ortho_algorithmic_bytes(op.n_local, J, True)
+                      + (1 - frac_second) * ortho_algorithmic_bytes(op.n_local, J, False))
     if n_ortho:
-        frac_second = seconds / max(steps_done, 1)
-        per_cycle = 0.0
-        for J in range(p + 1, m + 1):
-            per_cycle += (frac_second * ortho_algorithmic_bytes(op.n_local, J, True)
-                          + (1 - frac_second) * ortho_algorithmic_bytes(op.n_local, J, False))
         total = per_cycle * args.steps
         a = total / (ortho_ms * 1e-3) / 1e9
         ortho = {"bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -233,11 +233,22 @@ def main():
                  "second_pass_fraction": round(frac_second, 3), "traffic": None}
 
     if rank == 0:
+        # HBM bytes per SpMV from the committed rocprofv3 --pmc passes of this same command on the
+        # default workload (profiles/collect_pmc.sh -> profiles/pmc_summary.json): FETCH_SIZE is
+        # doubled for the coalesced streams of the binned kernels (gfx950 counts their 128-B
+        # requests as 64 B, MI355X_MICROARCH.md "HBM"); the CSR kernel's 16-B gathers are
+        # reported raw (64-B requests).
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc_path):
+        default_workload = args.workload == "random" and n == 10_000_000 and world == 1
+        if os.path.exists(pmc_path) and default_workload:
             try:
-                traffic = json.load(open(pmc_path)).get("k_spmv", {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path))
+                if op.spmv_form == "binned":
+                    traffic = (pmc["k_pb_phase1"]["hbm_bytes_per_launch_fetch_x2"]
+                               + pmc["k_pb_phase2"]["hbm_bytes_per_launch_fetch_x2"])
+                else:
+                    traffic = pmc["k_spmv"]["hbm_bytes_per_launch_raw"]
             except Exception:
                 traffic = None
         out = {
@@ -284,9 +295,8 @@ def main():
             "roofline_ortho": ortho,
             "restart_roofline": {
                 "algorithmic_GB_per_restart": round(
-                    ((m - p) * spmv_bytes
-                     + sum(ortho_algorithmic_bytes(op.n_local, J, True) for J in range(p + 1, m + 1))
-                     + 16 * op.n_local * (m + p) + 32 * op.n_local) / 1e9, 2),
+                    ((m - p) * spmv_bytes + per_cycle + 16 * op.n_local * (m + p) + 32 * op.n_local) / 1e9, 2),
+                "second_pass_fraction": round(frac_second, 3),
             },
         }
         out["restart_roofline"]["achieved_GBs"] = round(

@@ -21,7 +21,7 @@ from collections import defaultdict
 def family(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     name = re.sub(r"\(.*$", "", name)
-    m = re.match(r"(k_[a-z_]+)(<.*>)?", name)
+    m = re.match(r"(k_[a-z0-9_]+)(<.*>)?", name)
     if not m:
         return name[:40]
     fam = m.group(1)

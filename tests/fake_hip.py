@@ -219,7 +219,13 @@ def install(monkeypatch=None):
     import torch
     from arnoldi_amd import _hip, device as dev
 
+    import os
+
     fake = FakeHip(_hip.load())
+    if monkeypatch is not None:
+        monkeypatch.setenv("AKS_GRAPH", "0")    # no hipGraph capture on CPU tensors
+    else:
+        os.environ["AKS_GRAPH"] = "0"
     patches = [
         (_hip, "load", lambda: fake),
         (dev, "_require_gpu", lambda device=None: torch.device("cpu")),
