@@ -502,3 +502,38 @@ def test_rccl_collectives_one_rank(amd, tmp_path):
     assert r["allreduce_ok"] and r["alltoall_ok"] and r["requests_ok"] and r["allgather_ok"]
     s = r["solve"]
     assert s["restarts_equal"] and s["eig_err"] < 1e-9 and s["rel"] <= max(1.05 * s["rel_oracle"], 1e-13)
+
+
+# ---------------------------------------------------------------------------- the reference's stress grid
+# scripts/stress-test.py:29-41: (nev, ncv, p) x {LM, LR}
+STRESS_GRID = [(3, 20, 10), (6, 20, 12), (10, 20, 16), (12, 30, 21), (20, 40, 30), (30, 50, 40), (50, 80, 65),
+               (50, 100, 75), (75, 100, 85)]
+
+
+@pytest.mark.parametrize("which", ["LM", "LR"])
+@pytest.mark.parametrize("nev,ncv,p", STRESS_GRID)
+def test_stress_grid_against_oracle(amd, nev, ncv, p, which):
+    """Every (nev, ncv, p) of the reference's stress test, both sort keys, against the CPU oracle on
+    the same start vector: restart counts, History, eigenvalues, residual bound.  Widths up to
+    J = 100 and restart sizes up to p = 85 go through the grouped-projection / un-fused update
+    kernels and the widest truncation buckets."""
+    from arnoldi_amd import matrices
+
+    if which == "LM":
+        A, sort_o, tol = matrices.laplace2d(30, 31), oracle.arg_largest_magnitude, None
+    else:
+        A, sort_o, tol = matrices.mark(44), oracle.arg_largest_real, 1e-8
+    kw = dict(max_dim=ncv, p=p, stopping_criterion=tol, max_restarts=4000)
+    np.random.seed(nev + ncv)
+    Qo, To, ho = oracle.krylov_schur(A, nev, sort_function=sort_o, **kw)
+    np.random.seed(nev + ncv)
+    st = {}
+    Q, T, h = amd.partial_schur(A, nev, sort_function=sort_o, stats=st, **kw)
+    assert st["p"] == p and st["max_dim"] == ncv
+    np.testing.assert_array_equal(h.restarts, ho.restarts)
+    np.testing.assert_array_equal(h.matvecs, ho.matvecs)
+    np.testing.assert_allclose(np.diag(T), np.diag(To), rtol=1e-8, atol=1e-10)
+    _, _, rel = oracle.eig_residuals(A, Q, T)
+    _, _, rel_o = oracle.eig_residuals(A, Qo, To)
+    assert rel.max() <= max(1.05 * rel_o.max(), 1e-12), (rel.max(), rel_o.max())
+    np.testing.assert_allclose(Q.conj().T @ Q, np.eye(nev), atol=1e-11)
