@@ -87,6 +87,74 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
     return r;
 }
 
+// ---- many-value wave reduction ------------------------------------------------------------
+// Summing K per-lane values over the 64 lanes with K independent butterflies costs 6 K dependent
+// cross-lane moves (2 ds_bpermute each for a double).  Here every step HALVES the values a lane
+// still carries: lanes with the mask bit set keep the upper half and send the lower one to
+// their partner (and vice versa), so K values need K - 1 exchanges in 6 rounds whose moves are
+// all independent.  After the last round lane l holds the total of value  l >> (6 - log2 KP).
+constexpr int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+template <int KP, int S>
+__device__ __forceinline__ void transpose_reduce_step(double (&v)[KP], int lane) {
+    if constexpr (S < 6) {
+        constexpr int mask = 32 >> S;
+        constexpr int half = KP >> (S + 1);
+        if constexpr (half >= 1) {
+            const bool upper = (lane & mask) != 0;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const double send = upper ? v[i] : v[i + half];
+                const double keep = upper ? v[i + half] : v[i];
+                v[i] = keep + __shfl_xor(send, mask, 64);
+            }
+        } else {
+            v[0] += __shfl_xor(v[0], mask, 64);
+        }
+        transpose_reduce_step<KP, S + 1>(v, lane);
+    }
+}
+
+// Block-wide sums of the 2 NC + 1 accumulators of the panel kernels:
+//   out[c] = (sum ar[c], sum ai[c]) for c < NC, and *nrm_out = sum nrm (if nrm_out != nullptr).
+// Fixed evaluation order => bitwise reproducible.  Must be called by all 256 threads.
+template <int NC>
+__device__ __forceinline__ void block_reduce_panel(const double (&ar)[NC], const double (&ai)[NC], double nrm,
+                                                   c128 *__restrict__ out, c128 *__restrict__ nrm_out) {
+    constexpr int K = 2 * NC + 1;
+    constexpr int ROUNDS = (K + 63) / 64;
+    constexpr int KP = ROUNDS == 1 ? next_pow2(K) : 64;   // values per round
+    __shared__ double red[WAVES][ROUNDS * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        double v[KP];
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            const int idx = r * 64 + i;   // constant after unrolling: static register selection
+            v[i] = idx < 2 * NC ? ((idx & 1) ? ai[idx >> 1 < NC ? idx >> 1 : 0] : ar[idx >> 1 < NC ? idx >> 1 : 0])
+                                : (idx == 2 * NC ? nrm : 0.0);
+        }
+        transpose_reduce_step<KP, 0>(v, lane);
+        constexpr int G = 64 / KP;       // lanes that end up with the same value
+        if ((lane & (G - 1)) == 0) red[wave][r * 64 + lane / G] = v[0];
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < NC) {
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) { sr += red[k][2 * t]; si += red[k][2 * t + 1]; }
+        out[t] = make_double2(sr, si);
+    }
+    if (nrm_out != nullptr && t == 64) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) s += red[k][2 * NC];
+        *nrm_out = make_double2(s, 0.0);
+    }
+}
+
 __device__ __forceinline__ bool second_pass_needed(const c128 *red1, const c128 *red2, int J, double eta) {
     // ortho.py:101   beta < beta_before * eta
     return sqrt(red2[J].x) < sqrt(red1[J].x) * eta;
@@ -100,8 +168,6 @@ __global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *_
                                                const c128 *__restrict__ w, c128 *__restrict__ partial,
                                                int ldp, int nrm_slot, const aks_ctrl *__restrict__ ctrl) {
     if (ctrl->broken) return;
-    __shared__ double red_re[WAVES][NC], red_im[WAVES][NC];
-    __shared__ double red_n[WAVES];
     double ar[NC], ai[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) ar[c] = ai[c] = 0.0;
@@ -120,28 +186,8 @@ __global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *_
         }
         nrm = fma(wv.x, wv.x, fma(wv.y, wv.y, nrm));
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const double sr = wave_sum(ar[c]);
-        const double si = wave_sum(ai[c]);
-        if (lane == 0) { red_re[wave][c] = sr; red_im[wave][c] = si; }
-    }
-    nrm = wave_sum(nrm);
-    if (lane == 0) red_n[wave] = nrm;
-    __syncthreads();
-    if (threadIdx.x < NC) {
-        double sr = 0.0, si = 0.0;
-#pragma unroll
-        for (int k = 0; k < WAVES; ++k) { sr += red_re[k][threadIdx.x]; si += red_im[k][threadIdx.x]; }
-        partial[(int64_t)blockIdx.x * ldp + c0 + threadIdx.x] = make_double2(sr, si);
-    }
-    if (nrm_slot >= 0 && threadIdx.x == 64) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < WAVES; ++k) s += red_n[k];
-        partial[(int64_t)blockIdx.x * ldp + nrm_slot] = make_double2(s, 0.0);
-    }
+    c128 *row = partial + (int64_t)blockIdx.x * ldp;
+    block_reduce_panel<NC>(ar, ai, nrm, row + c0, nrm_slot >= 0 ? row + nrm_slot : nullptr);
 }
 
 // ------------------------------------------------------------------ fused update + re-projection
@@ -152,8 +198,6 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__
                                                       c128 *__restrict__ partial, int ldp,
                                                       const aks_ctrl *__restrict__ ctrl) {
     if (ctrl->broken) return;
-    __shared__ double red_re[WAVES][NC], red_im[WAVES][NC];
-    __shared__ double red_n[WAVES];
     __shared__ c128 hs[NC];
     if (threadIdx.x < NC) hs[threadIdx.x] = h[threadIdx.x];
     __syncthreads();
@@ -184,28 +228,8 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__
         }
         nrm = fma(wv.x, wv.x, fma(wv.y, wv.y, nrm));
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const double sr = wave_sum(ar[c]);
-        const double si = wave_sum(ai[c]);
-        if (lane == 0) { red_re[wave][c] = sr; red_im[wave][c] = si; }
-    }
-    nrm = wave_sum(nrm);
-    if (lane == 0) red_n[wave] = nrm;
-    __syncthreads();
-    if (threadIdx.x < NC) {
-        double sr = 0.0, si = 0.0;
-#pragma unroll
-        for (int k = 0; k < WAVES; ++k) { sr += red_re[k][threadIdx.x]; si += red_im[k][threadIdx.x]; }
-        partial[(int64_t)blockIdx.x * ldp + threadIdx.x] = make_double2(sr, si);
-    }
-    if (threadIdx.x == 64) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < WAVES; ++k) s += red_n[k];
-        partial[(int64_t)blockIdx.x * ldp + NC] = make_double2(s, 0.0);
-    }
+    c128 *row = partial + (int64_t)blockIdx.x * ldp;
+    block_reduce_panel<NC>(ar, ai, nrm, row, row + NC);
 }
 
 // ------------------------------------------------------------------ update (any width)
