@@ -16,6 +16,7 @@ all-reduce of the (J+1)-vector between stages.
 from __future__ import annotations
 
 import ctypes as C
+import gc
 import os
 
 import numpy as np
@@ -148,7 +149,7 @@ class ArnoldiContext:
         self.probe = None   # optional _hip.Probe (bench.py): device time of SpMV / ortho launches
         self.spmv_events = None  # optional list (bench.py, Python-chained path): torch event pairs
         self.force_chained = False  # run the Python-chained stage path even on one GPU (tests, bench)
-        self.use_graph = os.environ.get("AKS_GRAPH", "1") != "0"   # hipGraph replay of re-expansions
+        self.use_graph = os.environ.get("AKS_GRAPH", "0") == "1"   # hipGraph replay of re-expansions (opt-in)
         self._graphs = {}
 
     # -- seam 1 ------------------------------------------------------------------
@@ -172,16 +173,23 @@ class ArnoldiContext:
                 _hip.check(rc, "aks_arnoldi_expand")
 
             # The re-expansion (start = p) is the same launch sequence with the same arguments at
-            # every restart (DGKS decisions and breakdown are taken on the device), so it is
+            # every restart (DGKS decisions and breakdown are taken on the device), so it can be
             # captured once into a hipGraph and replayed: one host call per restart instead of
-            # ~10 launches per Arnoldi step.  Not used while a probe records per-kernel events.
+            # ~10 launches per Arnoldi step (opt-in: AKS_GRAPH=1; pays off when the host is slow
+            # relative to the kernels).  Not used while a probe records per-kernel events.
             key = (start, end, float(tol), float(eta))
             if self.use_graph and self.probe is None and start > 0:
                 g = self._graphs.get(key)
                 if g is None:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        enqueue()
+                    gc_was_on = gc.isenabled()
+                    gc.disable()     # a collection during capture could free device objects (illegal in capture)
+                    try:
+                        with torch.cuda.graph(g, capture_error_mode="relaxed"):
+                            enqueue()
+                    finally:
+                        if gc_was_on:
+                            gc.enable()
                     self._graphs[key] = g
                 g.replay()
             else:

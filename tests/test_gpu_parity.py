@@ -504,6 +504,27 @@ def test_rccl_collectives_one_rank(amd, tmp_path):
     assert s["restarts_equal"] and s["eig_err"] < 1e-9 and s["rel"] <= max(1.05 * s["rel_oracle"], 1e-13)
 
 
+def test_graph_replay_gives_identical_results(amd, monkeypatch):
+    """Opt-in hipGraph replay of the re-expansion (AKS_GRAPH=1): bit-identical Q, T and History."""
+    from arnoldi_amd.matrices import mark
+    from arnoldi_amd.utils import arg_largest_real
+
+    A = mark(50)
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("AKS_GRAPH", flag)
+        np.random.seed(0)
+        st = {}
+        Q, T, h = amd.partial_schur(A, 5, max_dim=20, stopping_criterion=1e-8, sort_function=arg_largest_real,
+                                    stats=st)
+        assert st["solver"].ctx.use_graph == (flag == "1")
+        assert bool(st["solver"].ctx._graphs) == (flag == "1")
+        out.append((Q, T, h.restarts.copy()))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
 # ---------------------------------------------------------------------------- the reference's stress grid
 # scripts/stress-test.py:29-41: (nev, ncv, p) x {LM, LR}
 STRESS_GRID = [(3, 20, 10), (6, 20, 12), (10, 20, 16), (12, 30, 21), (20, 40, 30), (30, 50, 40), (50, 80, 65),
