@@ -28,11 +28,37 @@ def _require_gpu(device):
 
 
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    """Device pointer argument: a torch tensor, a raw address (int) or None."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t if isinstance(t, int) else t.data_ptr())
+
+
+_stream_cache = None
 
 
 def _stream():
+    """Current HIP stream as a void*.  ``cached_stream()`` pins the lookup for a hot loop."""
+    if _stream_cache is not None:
+        return _stream_cache
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class cached_stream:
+    """Context manager: resolve torch's current stream once for a sequence of launches (the
+    lookup costs several microseconds per call, comparable to a launch)."""
+
+    def __enter__(self):
+        global _stream_cache
+        self._prev = _stream_cache
+        _stream_cache = None
+        _stream_cache = _stream()
+        return self
+
+    def __exit__(self, *exc):
+        global _stream_cache
+        _stream_cache = self._prev
+        return False
 
 
 def canonical_csr(A):
@@ -162,9 +188,9 @@ class DeviceCSR:
 
     def spmv(self, x, y, accumulate=False, ws=None):
         """y (=|+=) A x on the current stream; x, y are complex128 device tensors."""
-        assert x.dtype == torch.complex128 and y.dtype == torch.complex128
-        assert x.numel() >= self.n_cols and y.numel() >= self.n_rows
-        assert x.is_contiguous() and y.is_contiguous()
+        for t, need in ((x, self.n_cols), (y, self.n_rows)):   # raw addresses (hot loop) skip the checks
+            if not isinstance(t, int):
+                assert t.dtype == torch.complex128 and t.numel() >= need and t.is_contiguous()
         if self.use_binned:
             rc = _hip.load().aks_pb_spmv(C.byref(self.binned.desc), _ptr(x), _ptr(y), int(accumulate),
                                          _ptr(ws.buf) if ws is not None else C.c_void_p(0), _stream())
@@ -241,6 +267,7 @@ class Workspace:
         skew = (-self._raw.data_ptr()) % 256
         self.buf = self._raw[skew: skew + self.nbytes]   # 256-byte aligned view
         assert self.buf.data_ptr() % 256 == 0
+        self._red_views = {}
         self.reset()
 
     def reset(self):
@@ -253,8 +280,12 @@ class Workspace:
     def red(self, which, n_c128):
         """float64 view (2 doubles per complex) of reduction slot 1, 2 or 3 -- what a
         multi-GPU host all-reduces between the Gram-Schmidt stages."""
-        off = {1: self.layout.red1_off, 2: self.layout.red2_off, 3: self.layout.red3_off}[which]
-        return self._slot(off, n_c128)
+        key = (which, n_c128)
+        view = self._red_views.get(key)
+        if view is None:
+            off = {1: self.layout.red1_off, 2: self.layout.red2_off, 3: self.layout.red3_off}[which]
+            view = self._red_views[key] = self._slot(off, n_c128)
+        return view
 
     def read_ctrl(self):
         """Synchronising read-back of the 64-byte control block."""

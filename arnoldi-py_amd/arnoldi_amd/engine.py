@@ -197,27 +197,31 @@ class ArnoldiContext:
         else:
             hbase = b.H.data_ptr()
             multi = self.comm is not None and self.comm.active
-            for j in range(start, end):
-                J = j + 1
-                w = b.col(J)
-                if self.spmv_events is not None:   # bench.py: device time of the sharded SpMV
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    op.apply(b.col(j), w, ws)
-                    e1.record()
-                    self.spmv_events.append((e0, e1))
-                else:
-                    op.apply(b.col(j), w, ws)
-                if not multi:
-                    dev.dgks_gs_device(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
-                    continue
-                dev.gs_project(b, J, w, ws)
-                self.comm.allreduce_sum_(ws.red(1, J + 1))
-                dev.gs_update_project(b, J, w, ws)
-                self.comm.allreduce_sum_(ws.red(2, J + 1))
-                dev.gs_update_norm(b, J, w, ws, eta)
-                self.comm.allreduce_sum_(ws.red(3, 1))
-                dev.gs_finish(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
+            raw = isinstance(op, CsrOperator)      # columns as raw addresses: no per-step tensor views
+            vbase, stride = b.V.data_ptr(), 16 * b.ldv
+            with dev.cached_stream():
+                for j in range(start, end):
+                    J = j + 1
+                    x = vbase + stride * j if raw else b.col(j)
+                    w = vbase + stride * J if raw else b.col(J)
+                    if self.spmv_events is not None:   # bench.py: device time of the sharded SpMV
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        op.apply(x, w, ws)
+                        e1.record()
+                        self.spmv_events.append((e0, e1))
+                    else:
+                        op.apply(x, w, ws)
+                    if not multi:
+                        dev.dgks_gs_device(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
+                        continue
+                    dev.gs_project(b, J, w, ws)
+                    self.comm.allreduce_sum_(ws.red(1, J + 1))
+                    dev.gs_update_project(b, J, w, ws)
+                    self.comm.allreduce_sum_(ws.red(2, J + 1))
+                    dev.gs_update_norm(b, J, w, ws, eta)
+                    self.comm.allreduce_sum_(ws.red(3, 1))
+                    dev.gs_finish(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
         Hd = b.download_H()
         ctrl = ws.read_ctrl()
         n_iter = int(ctrl.n_iter) if ctrl.broken else end

@@ -145,6 +145,13 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         comm = Comm()
+    elif os.environ.get("AKS_FORCE_COMM") == "1":
+        # rehearsal of the multi-rank host path on one GPU: a one-rank RCCL group whose
+        # all-reduces are really issued (measures the per-step host + collective latency)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        comm = Comm(force=True)
 
     n = args.n
     if args.workload != "random":
@@ -162,7 +169,7 @@ def main():
     np.random.seed(0)
     solver = KrylovSchurSolver(op, nev, m, p, 1e-8, arg_largest_magnitude, comm=comm)
     ctx = solver.ctx
-    native = world == 1 and not args.chained
+    native = world == 1 and not args.chained and comm is None
     if not native:
         ctx.force_chained = True
     t_setup = time.perf_counter() - t_setup
