@@ -80,6 +80,11 @@ class KrylovSchurSolver:
         self.m = self.ctx.expand(self.H, self.p, self.max_dim, self.tol)
         return self.m
 
+    def true_residuals(self):
+        """Eigenvalues of the converged partial Schur form with ``||A v - l v||`` and
+        ``||A v - l v|| / |l|`` evaluated on the device (no n-vector leaves the GPU)."""
+        return self.ctx.true_residuals(self.H[: self.nev, : self.nev])
+
     def result(self, gather=True):
         comm = self.ctx.comm
         if comm is not None and comm.size > 1 and not gather:

@@ -59,7 +59,9 @@ def main():
         Qo, To, histo = oracle.krylov_schur(A_full, nev, **okw)
         _, _, rel = oracle.eig_residuals(A_full, Q, T)
         _, _, rel_o = oracle.eig_residuals(A_full, Qo, To)
+        _, _, drel = stats["solver"].true_residuals()      # evaluated shard-wise on the device(s)
         verdict[name] = {
+            "device_residual_err": float(np.abs(np.sort(drel) - np.sort(rel)).max()),
             "restarts_equal": bool(np.array_equal(hist.restarts, histo.restarts)),
             "matvec_hist_equal": bool(np.array_equal(hist.matvecs, histo.matvecs)),
             "eig_err": float(np.abs(np.diag(T) - np.diag(To)).max()),

@@ -142,6 +142,11 @@ def test_config5_random_10m_planted_converges(amd):
     # the planted diagonal entries dominate the bulk (radius ~ sqrt(5/3)); each eigenvalue sits
     # within O(bulk^2 / lambda) of its planted value
     np.testing.assert_allclose(np.sort(vals.real)[::-1], planted[:5], atol=0.2)
+    # the same residuals evaluated on the device agree with the host's
+    dvals, dres, drel = st["solver"].true_residuals()
+    order_h, order_d = np.argsort(-vals.real), np.argsort(-dvals.real)
+    np.testing.assert_allclose(dvals[order_d], vals[order_h], rtol=1e-12)
+    np.testing.assert_allclose(drel[order_d], rel[order_h], rtol=1e-3, atol=1e-12)
     np.testing.assert_allclose(Q.conj().T @ Q, np.eye(5), atol=1e-11)
     assert st["restarts"] <= 30
     print(f"C5 planted: {st['restarts']} restarts, spmv form {st['solver'].op.spmv_form}, "

@@ -376,6 +376,7 @@ def check_dist_verdicts(verdicts):
             assert c["eig_err"] < 1e-9, (name, c)
             assert c["rel_residual"] <= max(1.05 * c["rel_residual_oracle"], 1e-13), (name, c)
             assert c["orth_err"] < 1e-12, (name, c)
+            assert c["device_residual_err"] < 1e-11, (name, c)
         assert v["random_planted"]["n_ghost"] > 1000 and v["block_diag"]["n_ghost"] == 0
         assert 0 < v["laplace2d"]["n_ghost"] <= 60
     assert all(v == verdicts[0] or v["mark50"]["restarts"] == verdicts[0]["mark50"]["restarts"] for v in verdicts)
