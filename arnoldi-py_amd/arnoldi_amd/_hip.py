@@ -15,7 +15,8 @@ MAX_DIM = 128          # AKS_MAX_DIM
 MAX_TRUNC = 96         # AKS_MAX_TRUNC
 SPMV_TILE_NNZ = 256    # AKS_SPMV_TILE_NNZ
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libarnoldi_hip.so")
+LIB_PATH = os.environ.get(  # AKS_LIB_PATH: A/B a differently built library (profiles/ab_kernels.py)
+    "AKS_LIB_PATH", os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libarnoldi_hip.so"))
 
 
 class HipLibraryError(RuntimeError):
