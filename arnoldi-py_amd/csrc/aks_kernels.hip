@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <vector>
@@ -60,8 +61,6 @@ constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 constexpr int MAX_ROW_BLOCKS = 1024;
 constexpr int NC_MAX = 32;        // widest exact-width projection kernel (accumulators only)
-constexpr int NC_FUSED_MAX = 41;  // widest fused update + re-projection kernel (panel row + accumulators
-                                  // in registers: 8 NC VGPRs; 41 is the last width without scratch spills)
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -234,6 +233,101 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__
     }
     c128 *row = partial + (int64_t)blockIdx.x * ldp;
     block_reduce_panel<NC>(ar, ai, nrm, row, row + NC);
+}
+
+// ------------------------------------------------------------------ fused update + re-projection, wide panels
+// Same operation as k_update_proj for J > 20: the J columns are dealt to the 4 waves of the block
+// (NQ = ceil(J / 4) per wave, all four on the SAME 64 rows), so a wave holds 8 NQ instead of 8 J
+// VGPRs and several waves per SIMD overlap loads with arithmetic.  The row's update needs all
+// columns: each wave puts its partial  sum_c V[i,c] h[c]  in LDS, one barrier per 64-row tile
+// (double-buffered), and every wave adds the four partials in the same order.  The re-projection
+// accumulators of a wave belong to its own columns, so no cross-wave sum is needed at the end.
+template <int NQ>
+__global__ __launch_bounds__(BLOCK) void k_update_proj_split(int64_t n, int J, const c128 *__restrict__ V,
+                                                            int64_t ldv, c128 *__restrict__ w,
+                                                            const c128 *__restrict__ h, c128 *__restrict__ partial,
+                                                            int ldp, const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl->broken) return;
+    __shared__ c128 hs[AKS_MAX_DIM + 4];
+    __shared__ double ps_re[2][WAVES][64], ps_im[2][WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int base = J / WAVES, extra = J % WAVES;
+    const int c_begin = wave * base + min(wave, extra);
+    const int cnt = base + (wave < extra ? 1 : 0);      // <= NQ
+    for (int c = threadIdx.x; c < J; c += BLOCK) hs[c] = h[c];
+    __syncthreads();
+    if (threadIdx.x < 4) hs[J + threadIdx.x] = make_double2(0.0, 0.0);   // coefficient of padding slots
+    __syncthreads();
+    const c128 *hq = hs + c_begin;                     // this wave's coefficients, re-read per tile
+    const int pad = J - c_begin;                       // hq[pad] == 0
+    double ar[NQ], ai[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) ar[q] = ai[q] = 0.0;
+    double nrm = 0.0;
+    const c128 *Vw = V + (int64_t)c_begin * ldv;
+    const int64_t n_tiles = (n + 63) / 64;
+    int buf = 0;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {   // same trip count for the 4 waves
+        const int64_t row = t * 64 + lane;
+        const bool valid = row < n;
+        const int64_t i = valid ? row : n - 1;
+        asm volatile("" ::: "memory");                 // keep the coefficients in LDS, not in 4 NQ VGPRs
+        c128 wv = w[i];
+        c128 v[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[q] = Vw[i + (int64_t)min(q, cnt - 1) * ldv];
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const c128 hc = hq[q < cnt ? q : pad];
+            sr = fma(v[q].x, hc.x, fma(-v[q].y, hc.y, sr));
+            si = fma(v[q].x, hc.y, fma(v[q].y, hc.x, si));
+        }
+        ps_re[buf][wave][lane] = sr;
+        ps_im[buf][wave][lane] = si;
+        __syncthreads();
+        double tr = 0.0, ti = 0.0;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) { tr += ps_re[buf][k][lane]; ti += ps_im[buf][k][lane]; }
+        wv.x -= tr;
+        wv.y -= ti;
+        if (wave == 0 && valid) w[row] = wv;
+        if (!valid) wv = make_double2(0.0, 0.0);       // rows past the end contribute nothing
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            ar[q] = fma(v[q].x, wv.x, fma(v[q].y, wv.y, ar[q]));
+            ai[q] = fma(v[q].x, wv.y, fma(-v[q].y, wv.x, ai[q]));
+        }
+        nrm = fma(wv.x, wv.x, fma(wv.y, wv.y, nrm));
+        buf ^= 1;
+    }
+    // per-wave totals of this wave's columns (+ ||w'||^2, reported by wave 0)
+    constexpr int K = 2 * NQ + 1;
+    constexpr int ROUNDS = (K + 63) / 64;
+    constexpr int KP = ROUNDS == 1 ? next_pow2(K) : 64;
+    c128 *prow = partial + (int64_t)blockIdx.x * ldp;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        double x[KP];
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+            const int idx = r * 64 + e;
+            x[e] = idx < 2 * NQ ? ((idx & 1) ? ai[idx >> 1 < NQ ? idx >> 1 : 0] : ar[idx >> 1 < NQ ? idx >> 1 : 0])
+                                : (idx == 2 * NQ ? nrm : 0.0);
+        }
+        transpose_reduce_step<KP, 0>(x, lane);
+        constexpr int G = 64 / KP;
+        const int idx = r * 64 + lane / G;              // value this lane ended up with
+        if ((lane & (G - 1)) == 0) {
+            double *out = reinterpret_cast<double *>(prow);
+            if (idx < 2 * NQ) {
+                const int q = idx >> 1;
+                if (q < cnt) out[2 * (c_begin + q) + (idx & 1)] = x[0];
+            } else if (idx == 2 * NQ && wave == 0) {
+                prow[J] = make_double2(x[0], 0.0);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ update (any width)
@@ -653,15 +747,34 @@ void dispatch_proj(int nc, dim3 grid, hipStream_t s, int64_t n, int c0, const c1
     }
 }
 
-#define AKS_NC_WIDE_CASES(M) \
-    M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40) M(41)
+// exact-width fused kernel up to FUSED_EXACT_MAX columns, column-split fused kernel beyond
+constexpr int FUSED_EXACT_MAX = 20;
 
 void dispatch_update_proj(int nc, dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
                           const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl) {
     switch (nc) {
 #define M(N) case N: launch_update_proj_nc<N>(grid, s, n, V, ldv, w, h, partial, ldp, ctrl); break;
         AKS_NC_CASES(M)
-        AKS_NC_WIDE_CASES(M)
+#undef M
+        default: break;
+    }
+}
+
+template <int NQ>
+void launch_update_proj_split(dim3 grid, hipStream_t s, int64_t n, int J, const c128 *V, int64_t ldv, c128 *w,
+                              const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl) {
+    hipLaunchKernelGGL(k_update_proj_split<NQ>, grid, dim3(BLOCK), 0, s, n, J, V, ldv, w, h, partial, ldp, ctrl);
+}
+
+#define AKS_NQ_CASES(M) \
+    M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) \
+    M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31) M(32)
+
+void dispatch_update_proj_split(int J, dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
+                                const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl) {
+    switch ((J + WAVES - 1) / WAVES) {
+#define M(N) case N: launch_update_proj_split<N>(grid, s, n, J, V, ldv, w, h, partial, ldp, ctrl); break;
+        AKS_NQ_CASES(M)
 #undef M
         default: break;
     }
@@ -823,17 +936,15 @@ int aks_gs_update_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_
     hipStream_t s = static_cast<hipStream_t>(stream);
     const c128 *V = reinterpret_cast<const c128 *>(d_V);
     c128 *w = reinterpret_cast<c128 *>(d_w);
-    if (J <= NC_FUSED_MAX) {
+    const int fused_exact_max = getenv("AKS_FUSED_EXACT_MAX") ? atoi(getenv("AKS_FUSED_EXACT_MAX")) : FUSED_EXACT_MAX;
+    if (J <= fused_exact_max && J <= NC_MAX)
         dispatch_update_proj(J, dim3(ws.lay.n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
                              ws.lay.ld_partial, ws.ctrl);
-        hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
-                           ws.lay.ld_partial, 0, ws.red2, J, nullptr, nullptr, 0.0, nullptr, ws.ctrl);
-    } else {
-        // wide panel: update, then the grouped projection (one extra panel read)
-        hipLaunchKernelGGL(k_update<false>, dim3(ws.lay.n_blocks), dim3(BLOCK), 0, s, n_rows, J, V, ldv, w,
-                           ws.red1, ws.partial, ws.lay.ld_partial, J, nullptr, nullptr, 0.0, ws.ctrl);
-        enqueue_projection(s, ws, n_rows, J, V, ldv, w, ws.red2, nullptr);
-    }
+    else
+        dispatch_update_proj_split(J, dim3(ws.lay.n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
+                                   ws.lay.ld_partial, ws.ctrl);
+    hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
+                       ws.lay.ld_partial, 0, ws.red2, J, nullptr, nullptr, 0.0, nullptr, ws.ctrl);
     AKS_CHECK_LAUNCH("aks_gs_update_project");
     return AKS_OK;
 }

@@ -39,7 +39,7 @@ def main():
     libs = sys.argv[1:3]
     n = sys.argv[3] if len(sys.argv) > 3 else "10000000"
     rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-    widths = "12,16,20" if int(n) >= 8_000_000 else "12,20,28,40"
+    widths = os.environ.get("AB_WIDTHS", "12,16,20" if int(n) >= 8_000_000 else "12,20,28,40")
     res = {lib: {} for lib in libs}
     for _ in range(rounds):
         for lib in libs:

@@ -553,7 +553,9 @@ def test_stress_grid_against_oracle(amd, nev, ncv, p, which):
     assert st["p"] == p and st["max_dim"] == ncv
     np.testing.assert_array_equal(h.restarts, ho.restarts)
     np.testing.assert_array_equal(h.matvecs, ho.matvecs)
-    np.testing.assert_allclose(np.diag(T), np.diag(To), rtol=1e-8, atol=1e-10)
+    # both solves stop at residual ~ tol (1e-8 / 1.5e-8): the last converged eigenvalues agree to a
+    # few tol, the well converged ones far better
+    np.testing.assert_allclose(np.diag(T), np.diag(To), rtol=1e-7, atol=1e-10)
     _, _, rel = oracle.eig_residuals(A, Q, T)
     _, _, rel_o = oracle.eig_residuals(A, Qo, To)
     assert rel.max() <= max(1.05 * rel_o.max(), 1e-12), (rel.max(), rel_o.max())
