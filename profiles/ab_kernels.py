@@ -43,15 +43,19 @@ def main():
     res = {lib: {} for lib in libs}
     for _ in range(rounds):
         for lib in libs:
-            r = subprocess.run([sys.executable, "-c", WORKER, n, widths], capture_output=True, text=True,
-                               env=dict(os.environ, AKS_LIB_PATH=os.path.abspath(lib)))
+            path, _, extra = lib.partition(":")        # "lib.so:VAR=value" adds an environment variable
+            env = dict(os.environ, AKS_LIB_PATH=os.path.abspath(path))
+            if extra:
+                k, _, v = extra.partition("=")
+                env[k] = v
+            r = subprocess.run([sys.executable, "-c", WORKER, n, widths], capture_output=True, text=True, env=env)
             if r.returncode != 0:
                 print(r.stderr[-2000:]); sys.exit(1)
             for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items():
                 res[lib].setdefault(k, []).append(v)
     keys = list(res[libs[0]])
     print(f"n={n}  median ms over {rounds} interleaved rounds")
-    print(f"{'kernel':28s} " + " ".join(f"{os.path.basename(l):>22s}" for l in libs))
+    print(f"{'kernel':28s} " + " ".join(f"{os.path.basename(l)[-22:]:>22s}" for l in libs))
     for k in keys:
         print(f"{k:28s} " + " ".join(f"{sorted(res[l][k])[len(res[l][k])//2]:22.4f}" for l in libs))
 
