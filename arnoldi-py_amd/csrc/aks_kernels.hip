@@ -995,12 +995,14 @@ int aks_dgks_gs(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks
 
 // ---- slab-binned form: host planner -------------------------------------------------------
 int64_t aks_pb_plan_count(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
-                          int32_t *slab_ptr_out) {
+                          int32_t *slab_ptr_out) try {
     if (!indptr || !indices || !slab_ptr_out) return fail(AKS_ERR_ARG, "null pointer");
     if (n_rows <= 0 || n_cols <= 0 || n_rows >= INT32_MAX || n_cols >= INT32_MAX)
         return fail(AKS_ERR_ARG, "matrix shape out of range");
     const int64_t n_slabs = (n_cols + (1 << PB_SLAB_BITS) - 1) >> PB_SLAB_BITS;
     const int64_t nnz = indptr[n_rows];
+    if (nnz < 0 || nnz > (int64_t)INT32_MAX - 2 * PB_CHUNK)   // 32-bit entry positions in the kernels
+        return fail(AKS_ERR_UNSUPPORTED, "too many non-zeros for the binned form");
     std::vector<int64_t> cnt(n_slabs, 0);
     for (int64_t k = 0; k < nnz; ++k) {
         const int32_t c = indices[k];
@@ -1015,12 +1017,16 @@ int64_t aks_pb_plan_count(const int32_t *indptr, const int32_t *indices, int64_t
     }
     slab_ptr_out[n_slabs] = (int32_t)acc;
     return chunks;
+} catch (const std::exception &e) {
+    return fail(AKS_ERR_ARG, e.what());      // e.g. std::bad_alloc: nothing may cross the C boundary
+} catch (...) {
+    return fail(AKS_ERR_ARG, "unexpected C++ exception");
 }
 
 int aks_pb_plan_fill(const int32_t *indptr, const int32_t *indices, const void *values, int32_t values_complex,
                      int64_t n_rows, int64_t n_cols, const int32_t *slab_ptr, void *val_out, uint16_t *lcol_out,
                      int32_t *dest_out, uint16_t *lrow_out, int32_t *rb_ptr_out, int32_t *chunk_begin_out,
-                     int32_t *chunk_slab_out) {
+                     int32_t *chunk_slab_out) try {
     if (!indptr || !indices || !values || !slab_ptr || !val_out || !lcol_out || !dest_out || !lrow_out ||
         !rb_ptr_out || !chunk_begin_out || !chunk_slab_out)
         return fail(AKS_ERR_ARG, "null pointer");
@@ -1094,6 +1100,10 @@ int aks_pb_plan_fill(const int32_t *indptr, const int32_t *indices, const void *
             ++c;
         }
     return AKS_OK;
+} catch (const std::exception &e) {
+    return fail(AKS_ERR_ARG, e.what());      // e.g. std::bad_alloc: nothing may cross the C boundary
+} catch (...) {
+    return fail(AKS_ERR_ARG, "unexpected C++ exception");
 }
 
 int aks_pb_spmv(const aks_pb_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate, const void *d_ws,
@@ -1185,7 +1195,7 @@ int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ld
     return launch_truncate<96>(s, n_rows, m, p, V, ldv, Q);
 }
 
-int aks_probe_create(int32_t capacity, void **probe_out) {
+int aks_probe_create(int32_t capacity, void **probe_out) try {
     if (capacity < 1 || probe_out == nullptr) return fail(AKS_ERR_ARG, "bad probe capacity / pointer");
     Probe *p = new (std::nothrow) Probe();
     if (p == nullptr) return fail(AKS_ERR_ARG, "out of host memory");
@@ -1202,6 +1212,10 @@ int aks_probe_create(int32_t capacity, void **probe_out) {
     }
     *probe_out = p;
     return AKS_OK;
+} catch (const std::exception &e) {
+    return fail(AKS_ERR_ARG, e.what());      // e.g. std::bad_alloc: nothing may cross the C boundary
+} catch (...) {
+    return fail(AKS_ERR_ARG, "unexpected C++ exception");
 }
 
 int aks_probe_destroy(void *probe) {
