@@ -18,8 +18,8 @@
 //   k_reduce        deterministic second stage of the block partial sums.
 //   k_finish        H column, beta, breakdown test, w /= beta.
 //                                                       (ortho.py:95,103,107; decomposition.py:61-66)
-//   k_truncate<PA>  V[:, :p] = V[:, :m] Qp in place (one lane owns a row), V[:, p] = V[:, m].
-//                                                       (krylov_schur.py:78,81)
+//   k_truncate_mfma<MT,NS>  V[:, :p] = V[:, :m] Qp in place on v_mfma_f64_16x16x4_f64 (one wave owns
+//                   64 rows), V[:, p] = V[:, m].        (krylov_schur.py:78,81)
 //
 // Reductions are two-stage (per-block partials, then one fixed-order sum): no float
 // atomics, so results are bitwise reproducible run to run.
@@ -531,54 +531,89 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *
 }
 
 // ------------------------------------------------------------------ restart compression
-// One lane owns a row: it accumulates the p outputs while streaming the row's m inputs, and only
-// then overwrites columns 0..p-1 -- in place without an n x p temporary (krylov_schur.py:78).
-template <int PA>
-__global__ __launch_bounds__(BLOCK) void k_truncate(int64_t n, int m, int p, c128 *__restrict__ V, int64_t ldv,
-                                                   const c128 *__restrict__ Qp) {
+// V[:, :p] = V[:, :m] Qp in place and V[:, p] = V[:, m] (krylov_schur.py:78,81) on the matrix cores
+// (v_mfma_f64_16x16x4_f64): the one place on this path where a real K-dimension -- the m basis
+// columns -- is summed.  Complex arithmetic as a real GEMM
+//     [Cr Ci] = [Vr Vi] . [[Qr Qi], [-Qi Qr]]        (n x 2m) . (2m x 2p)
+// computed transposed, D = A.B with  M = 16 real OUTPUT columns (8 complex), N = 16 rows of V,
+// K = 4 complex input columns per load: lane (g = l>>4, r = l&15) loads the 16-byte element
+// V[row r, column c0+g] once and feeds two MFMAs -- its real part against row 2(c0+g) of the real
+// Q block, its imaginary part against row 2(c0+g)+1 -- so no cross-lane shuffles are needed
+// (the K order inside an MFMA is free as long as A and B agree).  The D layout of the f64 MFMA
+// (row = (l>>4) + 4 reg, col = l&15) puts 16 consecutive rows of V on consecutive lanes, so the
+// stores are 256-byte contiguous runs like the loads.  One wave owns 64 rows (4 N-tiles) and all MT
+// M-tiles; it reads all m columns of its rows before it overwrites any, hence in place.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int MT, int NS>   // NS row sub-tiles of 16 per wave (4, or 2 when MT is large)
+__global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p, c128 *__restrict__ V, int64_t ldv,
+                                                        const c128 *__restrict__ Qp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    c128 *qs = reinterpret_cast<c128 *>(smem_raw);  // [m][PA], zero padded
-    for (int e = threadIdx.x; e < m * PA; e += BLOCK) {
-        const int k = e / PA, c = e - k * PA;
-        qs[e] = c < p ? Qp[(int64_t)k * p + c] : make_double2(0.0, 0.0);
+    c128 *qs = reinterpret_cast<c128 *>(smem_raw);      // [mpad][PP] complex, zero padded
+    constexpr int PP = MT * 8;
+    const int mpad = (m + 3) & ~3;
+    for (int e = threadIdx.x; e < mpad * PP; e += BLOCK) {
+        const int k = e / PP, c = e - k * PP;
+        qs[e] = (k < m && c < p) ? Qp[(int64_t)k * p + c] : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        double ar[PA], ai[PA];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int comp = r16 & 1;                            // this lane's real output column is Re (0) / Im (1)
+    constexpr int ROWS = 16 * NS;
+    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
+    for (int64_t t = (int64_t)blockIdx.x * WAVES + wave; t < n_tiles; t += (int64_t)gridDim.x * WAVES) {
+        const int64_t row0 = t * ROWS;
+        v4d acc[NS][MT];
 #pragma unroll
-        for (int c = 0; c < PA; ++c) ar[c] = ai[c] = 0.0;
-        int k = 0;
-        for (; k + 4 <= m; k += 4) {
-            c128 v[4];
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = V[i + (int64_t)(k + u) * ldv];
+            for (int mt = 0; mt < MT; ++mt) acc[s][mt] = (v4d){0.0, 0.0, 0.0, 0.0};
+        int64_t rows[NS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const c128 *qrow = qs + (k + u) * PA;
+        for (int s = 0; s < NS; ++s) rows[s] = min(row0 + s * 16 + r16, n - 1);
+        for (int c0 = 0; c0 < mpad; c0 += 4) {
+            const int c = min(c0 + g, m - 1);            // padded K slots re-read a valid column; their Q rows are 0
+            c128 v[NS];
 #pragma unroll
-                for (int c = 0; c < PA; ++c) {
-                    const c128 q = qrow[c];
-                    ar[c] = fma(v[u].x, q.x, fma(-v[u].y, q.y, ar[c]));
-                    ai[c] = fma(v[u].x, q.y, fma(v[u].y, q.x, ai[c]));
+            for (int s = 0; s < NS; ++s) v[s] = V[rows[s] + (int64_t)c * ldv];
+            const c128 *qrow = qs + (c0 + g) * PP;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const c128 q = qrow[mt * 8 + (r16 >> 1)];
+                const double a_re = comp ? q.y : q.x;    // row 2c   of [[Qr Qi], [-Qi Qr]]
+                const double a_im = comp ? q.x : -q.y;   // row 2c+1
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    acc[s][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_re, v[s].x, acc[s][mt], 0, 0, 0);
+                    acc[s][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_im, v[s].y, acc[s][mt], 0, 0, 0);
                 }
             }
         }
-        for (; k < m; ++k) {
-            const c128 v = V[i + (int64_t)k * ldv];
-            const c128 *qrow = qs + k * PA;
 #pragma unroll
-            for (int c = 0; c < PA; ++c) {
-                const c128 q = qrow[c];
-                ar[c] = fma(v.x, q.x, fma(-v.y, q.y, ar[c]));
-                ai[c] = fma(v.x, q.y, fma(v.y, q.x, ai[c]));
+        for (int s = 0; s < NS; ++s) {
+            const int64_t row = row0 + s * 16 + r16;
+            if (row < n) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int jj = mt * 16 + g + 4 * r;      // real output column held in register r
+                        const int j = jj >> 1;
+                        if (j < p) reinterpret_cast<double *>(V + row + (int64_t)j * ldv)[jj & 1] = acc[s][mt][r];
+                    }
+                }
             }
         }
-        const c128 last = V[i + (int64_t)m * ldv];
+        // V[:, p] = V[:, m] (krylov_schur.py:81).  Column m is never a destination of the stores
+        // above (they end at column p - 1 <= m - 1), so it can be read here.
+        if (g == 0) {
 #pragma unroll
-        for (int c = 0; c < PA; ++c)
-            if (c < p) V[i + (int64_t)c * ldv] = make_double2(ar[c], ai[c]);
-        V[i + (int64_t)p * ldv] = last;  // krylov_schur.py:81
+            for (int s = 0; s < NS; ++s) {
+                const int64_t row = row0 + s * 16 + r16;
+                if (row < n) V[row + (int64_t)p * ldv] = V[row + (int64_t)m * ldv];
+            }
+        }
     }
 }
 
@@ -796,19 +831,20 @@ void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c12
                        ws.lay.ld_partial, 0, red_out, J, nullptr, nullptr, 0.0, zero_slot, ws.ctrl);
 }
 
-template <int PA>
-int launch_truncate(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_t ldv, const c128 *Qp) {
-    const size_t smem = (size_t)m * PA * sizeof(c128);
+template <int MT>
+int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_t ldv, const c128 *Qp) {
+    constexpr int NS = MT <= 9 ? 4 : 2;      // keeps NS * MT * 8 accumulator registers below the spill point
+    const size_t smem = (size_t)((m + 3) & ~3) * MT * 8 * sizeof(c128);
     if (smem > 160 * 1024) return fail(AKS_ERR_UNSUPPORTED, "Qp does not fit the 160 KiB LDS");
     if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_truncate<PA>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_truncate_mfma<MT, NS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_truncate)");
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_truncate_mfma)");
     }
-    const int64_t want = (n + BLOCK - 1) / BLOCK;
-    const dim3 grid((unsigned)(want < 2048 ? want : 2048));
-    hipLaunchKernelGGL(k_truncate<PA>, grid, dim3(BLOCK), smem, s, n, m, p, V, ldv, Qp);
-    AKS_CHECK_LAUNCH("k_truncate");
+    const int64_t want = ((n + 16 * NS - 1) / (16 * NS) + WAVES - 1) / WAVES;
+    const dim3 grid((unsigned)(want < 4096 ? want : 4096));
+    hipLaunchKernelGGL((k_truncate_mfma<MT, NS>), grid, dim3(BLOCK), smem, s, n, m, p, V, ldv, Qp);
+    AKS_CHECK_LAUNCH("k_truncate_mfma");
     return AKS_OK;
 }
 
@@ -1186,13 +1222,13 @@ int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ld
     hipStream_t s = static_cast<hipStream_t>(stream);
     c128 *V = reinterpret_cast<c128 *>(d_V);
     const c128 *Q = reinterpret_cast<const c128 *>(d_Qp);
-    if (p <= 8) return launch_truncate<8>(s, n_rows, m, p, V, ldv, Q);
-    if (p <= 16) return launch_truncate<16>(s, n_rows, m, p, V, ldv, Q);
-    if (p <= 24) return launch_truncate<24>(s, n_rows, m, p, V, ldv, Q);
-    if (p <= 32) return launch_truncate<32>(s, n_rows, m, p, V, ldv, Q);
-    if (p <= 48) return launch_truncate<48>(s, n_rows, m, p, V, ldv, Q);
-    if (p <= 64) return launch_truncate<64>(s, n_rows, m, p, V, ldv, Q);
-    return launch_truncate<96>(s, n_rows, m, p, V, ldv, Q);
+    switch ((p + 7) / 8) {   // M-tiles of 16 real = 8 complex output columns
+#define M(N) case N: return launch_truncate_mfma<N>(s, n_rows, m, p, V, ldv, Q);
+        M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12)
+#undef M
+        default: break;
+    }
+    return fail(AKS_ERR_UNSUPPORTED, "p exceeds AKS_MAX_TRUNC");
 }
 
 int aks_probe_create(int32_t capacity, void **probe_out) try {

@@ -28,7 +28,7 @@ for J in widths:
     w = basis.col(J)
     out[f"project J={J}"] = timeit(lambda: dev.gs_project(basis, J, w, ws))
     out[f"update_project J={J}"] = timeit(lambda: dev.gs_update_project(basis, J, w, ws))
-for mm, pp in ((20, 10), (40, 15)):
+for mm, pp in ((20, 10), (40, 15), (41, 25), (80, 65), (100, 85)):
     if mm <= m:
         Q = torch.randn(mm, pp, dtype=torch.complex128, device="cuda")
         out[f"truncate m={mm} p={pp}"] = timeit(lambda: dev.truncate(basis, mm, pp, Q))
