@@ -23,6 +23,7 @@ run fetch --kernel-trace --pmc FETCH_SIZE &&
 run write --kernel-trace --pmc WRITE_SIZE &&
 run tcc --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum &&
 run ea --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum &&
-run req --kernel-trace --pmc TCC_REQ_sum TCC_READ_sum
+run req --kernel-trace --pmc TCC_REQ_sum TCC_READ_sum &&
+run mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE
 python3 "$R/profiles/summarize_pmc.py" "$OUT" > "$OUT/pmc_summary.json"
 cat "$OUT/pmc_summary.json"

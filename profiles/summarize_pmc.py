@@ -54,6 +54,11 @@ def main(root):
         if f is not None and w is not None:
             d["hbm_bytes_per_launch_raw"] = int((f + w) * 1024)
             d["hbm_bytes_per_launch_fetch_x2"] = int((2 * f + w) * 1024)
+        busy, act = d.get("SQ_VALU_MFMA_BUSY_CYCLES_per_launch"), d.get("GRBM_GUI_ACTIVE_per_launch")
+        if busy is not None and act:
+            # MfmaUtil as rocprofv3 defines it: busy cycles summed over SIMDs / (active cycles x SIMDs);
+            # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS note)
+            d["mfma_util_pct"] = round(100.0 * busy / ((act / 8.0) * 1024), 2)
         h, m = d.get("TCC_HIT_sum_per_launch"), d.get("TCC_MISS_sum_per_launch")
         if h is not None and m is not None and h + m > 0:
             d["l2_hit_rate"] = round(h / (h + m), 4)
