@@ -83,6 +83,7 @@ SIGNATURES = {
     "aks_gs_update_norm": (C.c_int, [_I64, _I32, _P, _I64, _P, _F64, _P, _I64, _I32, _P]),
     "aks_gs_finish": (C.c_int, [_I64, _I32, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
     "aks_dgks_gs": (C.c_int, [_I64, _I32, _P, _I64, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
+    "aks_pb_params": (C.c_int, [C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "aks_pb_plan_count": (_I64, [_P, _P, _I64, _I64, _P]),
     "aks_pb_plan_fill": (C.c_int, [_P, _P, _P, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "aks_pb_spmv": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),
@@ -166,6 +167,13 @@ class Probe:
                 self.handle = _P()
         except Exception:
             pass
+
+
+def pb_params():
+    """(slab_bits, rowblock_bits, chunk_nnz) of the loaded library's slab-binned SpMV form."""
+    a, b, c = _I32(0), _I32(0), _I32(0)
+    check(load().aks_pb_params(C.byref(a), C.byref(b), C.byref(c)), "aks_pb_params")
+    return a.value, b.value, c.value
 
 
 def workspace_layout(n_rows, max_dim):

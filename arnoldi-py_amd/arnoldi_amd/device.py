@@ -215,8 +215,9 @@ class BinnedCSR:
         indices = np.ascontiguousarray(M.indices, dtype=np.int32)
         cplx = int(M.data.dtype == C128)
         values = np.ascontiguousarray(M.data)
-        n_slabs = (n_cols + (1 << _hip.PB_SLAB_BITS) - 1) >> _hip.PB_SLAB_BITS
-        n_rb = (n_rows + (1 << _hip.PB_ROWBLOCK_BITS) - 1) >> _hip.PB_ROWBLOCK_BITS
+        slab_bits, rb_bits, _ = _hip.pb_params()
+        n_slabs = (n_cols + (1 << slab_bits) - 1) >> slab_bits
+        n_rb = (n_rows + (1 << rb_bits) - 1) >> rb_bits
         slab_ptr = np.empty(n_slabs + 1, np.int32)
         n_chunks = lib.aks_pb_plan_count(indptr.ctypes.data, indices.ctypes.data, n_rows, n_cols,
                                          slab_ptr.ctypes.data)

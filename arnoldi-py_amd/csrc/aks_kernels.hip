@@ -972,8 +972,12 @@ int aks_gs_update_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_
     hipStream_t s = static_cast<hipStream_t>(stream);
     const c128 *V = reinterpret_cast<const c128 *>(d_V);
     c128 *w = reinterpret_cast<c128 *>(d_w);
-    const int fused_exact_max = getenv("AKS_FUSED_EXACT_MAX") ? atoi(getenv("AKS_FUSED_EXACT_MAX")) : FUSED_EXACT_MAX;
-    if (J <= fused_exact_max && J <= NC_MAX)
+    // Measured at n = 10M (profiles/ab_kernels.py): the column-split kernel wins for 5 <= J <= 12 (more waves
+    // in flight) and for J > 20 (the exact-width kernel drops to one wave per SIMD); the exact-width kernel
+    // wins for 13 <= J <= 20.  AKS_FUSED_EXACT_MAX overrides the upper switch point for A/B runs.
+    static const int exact_max = getenv("AKS_FUSED_EXACT_MAX") ? atoi(getenv("AKS_FUSED_EXACT_MAX")) : FUSED_EXACT_MAX;
+    const bool exact = J <= exact_max && J <= NC_MAX && !(J >= 5 && J <= 12 && exact_max == FUSED_EXACT_MAX);
+    if (exact)
         dispatch_update_proj(J, dim3(ws.lay.n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
                              ws.lay.ld_partial, ws.ctrl);
     else
@@ -1030,6 +1034,14 @@ int aks_dgks_gs(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks
 }
 
 // ---- slab-binned form: host planner -------------------------------------------------------
+int aks_pb_params(int32_t *slab_bits, int32_t *rowblock_bits, int32_t *chunk_nnz) {
+    if (!slab_bits || !rowblock_bits || !chunk_nnz) return fail(AKS_ERR_ARG, "null pointer");
+    *slab_bits = PB_SLAB_BITS;
+    *rowblock_bits = PB_RB_BITS;
+    *chunk_nnz = PB_CHUNK;
+    return AKS_OK;
+}
+
 int64_t aks_pb_plan_count(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
                           int32_t *slab_ptr_out) try {
     if (!indptr || !indices || !slab_ptr_out) return fail(AKS_ERR_ARG, "null pointer");

@@ -113,9 +113,15 @@ int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indic
  *            into LDS accumulators, then writes y.
  * aks_pb_plan_* are pure host functions that build the arrays from a canonical CSR matrix
  * (int32 indices); the caller uploads them and fills aks_pb_matrix with device pointers.     */
-#define AKS_PB_SLAB_BITS 16      /* columns per slab = 65536                                  */
+#ifndef AKS_PB_SLAB_BITS         /* (overridable at build time for tuning experiments)        */
+#define AKS_PB_SLAB_BITS 16      /* columns per slab = 65536 (<= 16: lcol is uint16)          */
+#endif
+#ifndef AKS_PB_ROWBLOCK_BITS
 #define AKS_PB_ROWBLOCK_BITS 10  /* rows per phase-2 wave = 1024                              */
-#define AKS_PB_CHUNK_NNZ 2048    /* non-zeros per phase-1 workgroup                           */
+#endif
+#ifndef AKS_PB_CHUNK_NNZ
+#define AKS_PB_CHUNK_NNZ 2048    /* non-zeros per phase-1 workgroup (multiple of 256)         */
+#endif
 
 typedef struct aks_pb_matrix {
     int64_t n_rows, n_cols, nnz, n_chunks;
@@ -130,6 +136,9 @@ typedef struct aks_pb_matrix {
     const int32_t *d_chunk_slab;    /* n_chunks: slab the chunk lies in                       */
     aks_c128 *d_prod;               /* nnz complex128 scratch (the products)                  */
 } aks_pb_matrix;
+
+/* The three constants above as compiled into the library (the host needs them for array sizes). */
+int aks_pb_params(int32_t *slab_bits, int32_t *rowblock_bits, int32_t *chunk_nnz);
 
 /* Pass 1 (host): entries per slab -> slab_ptr_out[0 .. n_slabs] (n_slabs = ceil(n_cols / 65536)).
  * Returns the number of phase-1 chunks, or a negative error. */
