@@ -33,6 +33,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CONFIG_OF = {"random": 5, "laplace2d": 2, "laplace3d": 4}   # BASELINE.json configs[] (1-based)
 
 
 def parse_args():
@@ -40,7 +41,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=10_000_000,
+                    help="matrix dimension (use --rows under torch.distributed.run, whose own parser "
+                         "treats --n as an ambiguous abbreviation)")
     ap.add_argument("--per-row", type=int, default=5)
     ap.add_argument("--nev", type=int, default=5)
     ap.add_argument("--max-dim", type=int, default=20)
@@ -61,12 +64,14 @@ def grid_dims(workload, n):
     return (nx, nx + 1, nx + 2)
 
 
-def build_rows(args, r0, r1, n):
+def build_rows(args, r0, r1, n, dims):
     from arnoldi_amd import matrices
 
     if args.workload == "random":
         return matrices.random_csr(n, args.per_row, 1234, row_range=(r0, r1))
-    return matrices.laplace_rows(grid_dims(args.workload, n), r0, r1)
+    rows = matrices.laplace_rows(dims, r0, r1)
+    assert rows.shape == (r1 - r0, n)
+    return rows
 
 
 def ortho_algorithmic_bytes(n_local, J, second):
@@ -132,6 +137,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # AKS_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path with all ranks sharing the visible GPU(s)
+    # (collectives staged through host memory); the measured numbers then mean nothing.
+    backend = os.environ.get("AKS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
     import torch.distributed as dist
@@ -143,7 +153,10 @@ def main():
 
     comm = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         comm = Comm()
     elif os.environ.get("AKS_FORCE_COMM") == "1":
         # rehearsal of the multi-rank host path on one GPU: a one-rank RCCL group whose
@@ -153,13 +166,14 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         comm = Comm(force=True)
 
-    n = args.n
+    n, dims = args.n, None
     if args.workload != "random":
-        n = int(np.prod(grid_dims(args.workload, n)))
+        dims = grid_dims(args.workload, args.n)      # computed ONCE: n below is the grid's row count
+        n = int(np.prod(dims))
     offsets = row_offsets(n, world)
     r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
     t_setup = time.perf_counter()
-    rows = build_rows(args, r0, r1, n)
+    rows = build_rows(args, r0, r1, n, dims)
     op = CsrOperator(local_rows=rows, offsets=offsets, comm=comm)
     nnz_local = op.nnz
     del rows
@@ -207,7 +221,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if comm is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if comm.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -273,7 +287,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": (f"{args.workload} CSR n={n} nnz={nnz_local if world == 1 else 'sharded'} "
-                             f"(BASELINE config 5 shape), partial_schur k={nev} max_dim={m} p={p}, "
+                             f"(BASELINE config {CONFIG_OF[args.workload]} shape), "
+                             f"partial_schur k={nev} max_dim={m} p={p}, "
                              f"1 step = 1 Krylov-Schur restart ({m - p} Arnoldi steps + host Schur + truncation)"),
                 "n": n, "nnz_rank0": nnz_local, "nev": nev, "max_dim": m, "p": p,
                 "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
