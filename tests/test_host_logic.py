@@ -382,6 +382,11 @@ def check_dist_verdicts(verdicts):
     assert all(v == verdicts[0] or v["mark50"]["restarts"] == verdicts[0]["mark50"]["restarts"] for v in verdicts)
 
 
+def test_row_sharded_solve_four_ranks_gloo(tmp_path):
+    """world_size = 4: interior ranks exchange with two neighbours, empty messages to the others."""
+    check_dist_verdicts(run_dist_worker(tmp_path, 4, "gloo", "cpu"))
+
+
 def test_row_sharded_solve_two_ranks_gloo(tmp_path):
     """world_size = 2 over gloo on CPU tensors: partition, ghost exchange, all-reduces and the
     stage chaining of the multi-GPU driver, against single-process oracle solves."""
