@@ -836,10 +836,12 @@ int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_
     constexpr int NS = MT <= 9 ? 4 : 2;      // keeps NS * MT * 8 accumulator registers below the spill point
     const size_t smem = (size_t)((m + 3) & ~3) * MT * 8 * sizeof(c128);
     if (smem > 160 * 1024) return fail(AKS_ERR_UNSUPPORTED, "Qp does not fit the 160 KiB LDS");
-    if (smem > 48 * 1024) {
+    static size_t smem_allowed = 48 * 1024;   // per instantiation (one process drives one GPU): raise once
+    if (smem > smem_allowed) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_truncate_mfma<MT, NS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_truncate_mfma)");
+        smem_allowed = smem;
     }
     const int64_t want = ((n + 16 * NS - 1) / (16 * NS) + WAVES - 1) / WAVES;
     const dim3 grid((unsigned)(want < 4096 ? want : 4096));

@@ -118,10 +118,29 @@ def cpu_baseline(args, n_full):
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         blas_threads = len(os.sched_getaffinity(0))
+    # per-phase split of the CPU path at the sample size: one operator apply and one
+    # dgks_gs call at the mean panel width of a restart
+    rng = np.random.default_rng(0)
+    xs = (rng.standard_normal(ns) + 1j * rng.standard_normal(ns)).astype(np.complex128)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        oracle.csr_matvec(A, xs)
+    ms_matvec = (time.perf_counter() - t0) / 3 * 1e3
+    p_ = min(args.nev + 5, args.max_dim - 1)
+    Jm = (p_ + 1 + args.max_dim) // 2
+    Vp, _ = np.linalg.qr(rng.standard_normal((ns, Jm)) + 0j)
+    Vp = np.asfortranarray(Vp)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        oracle.dgks_gs(xs.copy(), Vp, np.zeros(Jm, np.complex128), 1e-8)
+    ms_dgks = (time.perf_counter() - t0) / 3 * 1e3
     return {
         "value": (1.0 / per_restart) * scale,
         "unit": "restarts/s",
         "cores": int(blas_threads),
+        "ms_per_matvec_at_sample_n": round(ms_matvec, 2),
+        "ms_per_dgks_gs_at_sample_n": round(ms_dgks, 2),
+        "dgks_panel_width": Jm,
         "kind": "port",
         "sample": (f"oracle.krylov_schur on {what}, A.astype(complex128), {len(ts) - 1} steady-state "
                    f"restarts timed ({per_restart:.3f} s each, {wall:.1f} s CPU wall in all); all work is "
