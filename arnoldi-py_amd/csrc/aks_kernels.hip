@@ -11,18 +11,24 @@
 //   k_proj<NC>      tall-skinny  V[:, c0:c0+NC]^H w  with one lane per row and NC
 //                   complex accumulators per lane (exact NC: no masked loads), plus
 //                   ||w||^2.                            (ortho.py:92-94, 102)
+//   k_pb_phase1/2   the same operator for matrices without column locality: products are
+//                   formed slab by slab (x slab L2-resident) and written in row-block order,
+//                   then summed per 1024-row block from LDS.
 //   k_update_proj<NC>  w -= V h fused with the re-projection V^H w and ||w||^2: the
 //                   row's NC panel entries stay in registers between the two uses,
 //                   so the panel is read once instead of twice.   (ortho.py:96-98,102)
-//   k_update        w -= V h (any width) + ||w||^2.    (ortho.py:96-98 / 104-105)
+//   k_update_proj_split<NQ>  the same for wide panels: the J columns are dealt to the 4
+//                   waves of a block, partial updates meet in LDS.
+//   k_update<true>  second DGKS pass  w -= V h + ||w||^2, predicated on the device.
+//                                                       (ortho.py:101, 104-105)
 //   k_reduce        deterministic second stage of the block partial sums.
 //   k_finish        H column, beta, breakdown test, w /= beta.
 //                                                       (ortho.py:95,103,107; decomposition.py:61-66)
 //   k_truncate_mfma<MT,NS>  V[:, :p] = V[:, :m] Qp in place on v_mfma_f64_16x16x4_f64 (one wave owns
 //                   64 rows), V[:, p] = V[:, m].        (krylov_schur.py:78,81)
 //
-// Reductions are two-stage (per-block partials, then one fixed-order sum): no float
-// atomics, so results are bitwise reproducible run to run.
+// Reductions are two-stage (per-block partials, then one fixed-order sum) and the only atomics
+// are LDS adds issued by a single wave in program order: results are bitwise reproducible.
 #include <hip/hip_runtime.h>
 
 #include <cmath>

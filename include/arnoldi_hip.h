@@ -197,8 +197,9 @@ int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d
                        int32_t max_dim, void *probe, void *stream);
 
 /* ---- restart compression: replaces krylov_schur.py:78 and :81 --------------
- * V[:, :p] = V[:, :m] @ Qp   (in place, row-block by row-block)   and
- * V[:, p]  = V[:, m].   d_Qp is m x p complex128, row-major (ld = p). */
+ * V[:, :p] = V[:, :m] @ Qp   (in place: a wave reads all m columns of its 64 rows before it
+ * overwrites any; f64 MFMA)   and   V[:, p] = V[:, m].   d_Qp is m x p complex128, row-major
+ * (ld = p).  Limits: p <= AKS_MAX_TRUNC and ceil(m/4)*4 * ceil(p/8)*8 * 16 B <= 160 KiB (Qp in LDS). */
 int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv,
                  const aks_c128 *d_Qp, void *stream);
 
