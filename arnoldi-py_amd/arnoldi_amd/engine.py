@@ -158,6 +158,10 @@ class ArnoldiContext:
         of H into the host array exactly as the reference's in-place writes would.
         Returns n_iter (== end unless a step broke down)."""
         b, ws, op = self.basis, self.ws, self.op
+        # The reference's arnoldi_decomposition keeps no state between calls: a breakdown in the
+        # last step of one expansion (n_iter == max_dim, accepted by the driver) must not turn the
+        # next expansion into a no-op.  Clear the control block's (broken, n_iter) words.
+        ws.buf[:8].zero_()
         native = (isinstance(op, CsrOperator) and (op.comm is None or not op.comm.active)
                   and not self.force_chained)
         if native:

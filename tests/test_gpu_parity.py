@@ -410,6 +410,28 @@ def _planted_like_golden(n):
     return A
 
 
+@pytest.mark.parametrize("n", [3, 5, 17, 63, 64, 65, 129, 257])
+def test_partial_schur_tiny_sizes(amd, n):
+    """Sizes around the 64-lane / 256-thread / 1024-row granularities: symmetric-spectrum dense
+    matrices with well separated eigenvalues, against the oracle on the same start vector."""
+    rng = np.random.default_rng(n)
+    Qr, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.concatenate([[10.0, 7.0], np.linspace(1.0, 2.0, n - 2)])[:n]
+    A = (Qr * lam) @ Qr.T
+    nev = 1 if n < 5 else 2
+    kw = dict(max_dim=min(n, 12) if n > 3 else 3, sort_function=oracle.arg_largest_magnitude, max_restarts=500)
+    np.random.seed(n)
+    Qo, To, ho = oracle.krylov_schur(A, nev, **kw)
+    np.random.seed(n)
+    Q, T, h = amd.partial_schur(A, nev, **kw)
+    np.testing.assert_array_equal(h.restarts, ho.restarts)
+    np.testing.assert_allclose(np.diag(T), np.diag(To), rtol=1e-8)
+    np.testing.assert_allclose(np.sort(np.diag(T).real)[::-1], lam[:nev], rtol=1e-7)
+    _, _, rel = oracle.eig_residuals(A, Q, T)
+    _, _, rel_o = oracle.eig_residuals(A, Qo, To)
+    assert rel.max() <= max(1.05 * rel_o.max(), 1e-12)
+
+
 def test_partial_schur_errors(amd):
     g = load_golden("g9_errors")
     from arnoldi_amd.matrices import random_csr
