@@ -33,7 +33,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CONFIG_OF = {"random": 5, "laplace2d": 2, "laplace3d": 4}   # BASELINE.json configs[] (1-based)
+CONFIG_OF = {"random": 5, "laplace2d": 2, "laplace3d": 4, "markov": 1}   # BASELINE.json configs[] (1-based)
 
 
 def parse_args():
@@ -47,7 +47,9 @@ def parse_args():
     ap.add_argument("--per-row", type=int, default=5)
     ap.add_argument("--nev", type=int, default=5)
     ap.add_argument("--max-dim", type=int, default=20)
-    ap.add_argument("--workload", choices=["random", "laplace2d", "laplace3d"], default="random")
+    ap.add_argument("--workload", choices=["random", "laplace2d", "laplace3d", "markov"], default="random",
+                    help="random = BASELINE config 5 (default); laplace2d / laplace3d = configs 2 / 4; "
+                         "markov = mark(M) of the reference's README scaled to ~n rows (sorted LR)")
     ap.add_argument("--cpu-sample-n", type=int, default=1_000_000)
     ap.add_argument("--cpu-restarts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,6 +59,8 @@ def parse_args():
 
 
 def grid_dims(workload, n):
+    if workload == "markov":                      # mark(M): n = M (M + 1) / 2
+        return (int(round((2 * n) ** 0.5)),)
     if workload == "laplace2d":
         nx = int(round(n ** 0.5))
         return (nx, nx + 1)
@@ -69,7 +73,10 @@ def build_rows(args, r0, r1, n, dims):
 
     if args.workload == "random":
         return matrices.random_csr(n, args.per_row, 1234, row_range=(r0, r1))
-    rows = matrices.laplace_rows(dims, r0, r1)
+    if args.workload == "markov":
+        rows = matrices.mark(dims[0])[r0:r1]      # every rank builds the chain and keeps its rows
+    else:
+        rows = matrices.laplace_rows(dims, r0, r1)
     assert rows.shape == (r1 - r0, n)
     return rows
 
@@ -93,6 +100,11 @@ def cpu_baseline(args, n_full):
     if args.workload == "random":
         A = matrices.random_csr(ns, args.per_row, 1234)
         what = f"random CSR n={ns} ({args.per_row}/row, same generator)"
+    elif args.workload == "markov":
+        mm = grid_dims("markov", ns)[0]
+        A = matrices.mark(mm)
+        ns = A.shape[0]
+        what = f"mark({mm})"
     else:
         dims = grid_dims(args.workload, ns)
         ns = int(np.prod(dims))
@@ -103,7 +115,8 @@ def cpu_baseline(args, n_full):
     trace = {}
     t0 = time.perf_counter()
     try:
-        oracle.krylov_schur(A, args.nev, max_dim=args.max_dim, max_restarts=args.cpu_restarts, trace=trace)
+        oracle.krylov_schur(A, args.nev, max_dim=args.max_dim, max_restarts=args.cpu_restarts, trace=trace,
+                            sort_function=oracle.arg_largest_real if args.workload == "markov" else None)
     except ValueError:
         pass
     wall = time.perf_counter() - t0
@@ -168,7 +181,7 @@ def main():
     from arnoldi_amd.dist import Comm, row_offsets
     from arnoldi_amd.engine import CsrOperator
     from arnoldi_amd.krylov_schur import KrylovSchurSolver
-    from arnoldi_amd.utils import arg_largest_magnitude
+    from arnoldi_amd.utils import arg_largest_magnitude, arg_largest_real
 
     comm = None
     if world > 1:
@@ -188,7 +201,7 @@ def main():
     n, dims = args.n, None
     if args.workload != "random":
         dims = grid_dims(args.workload, args.n)      # computed ONCE: n below is the grid's row count
-        n = int(np.prod(dims))
+        n = dims[0] * (dims[0] + 1) // 2 if args.workload == "markov" else int(np.prod(dims))
     offsets = row_offsets(n, world)
     r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
     t_setup = time.perf_counter()
@@ -200,7 +213,8 @@ def main():
     nev, m = args.nev, args.max_dim
     p = min(nev + 5, m - 1)
     np.random.seed(0)
-    solver = KrylovSchurSolver(op, nev, m, p, 1e-8, arg_largest_magnitude, comm=comm)
+    sort_key = arg_largest_real if args.workload == "markov" else arg_largest_magnitude
+    solver = KrylovSchurSolver(op, nev, m, p, 1e-8, sort_key, comm=comm)
     ctx = solver.ctx
     native = world == 1 and not args.chained and comm is None
     if not native:
