@@ -17,10 +17,14 @@ from .ks_oracle import (  # noqa: F401
     csr_matvec,
     dgks_gs,
     eig_residuals,
+    explicit_restarts_with_deflation,
     krylov_schur,
     laplace_1d,
     laplace_1d_eigen,
     mark_matrix,
+    mgs,
+    naive_explicit_restarts,
     ordered_schur,
     random_unit_vector,
+    ritz_from_v_and_h,
 )

@@ -291,3 +291,114 @@ def eig_residuals(A, Q, T):
     vecs = Q @ S
     res = np.linalg.norm(A @ vecs - vecs * vals, axis=0)
     return vals, vecs, res / np.abs(vals)
+
+
+# --------------------------------------------------------------------------
+# explicit restarts: Ritz extraction, MGS, the two solvers
+# --------------------------------------------------------------------------
+@dataclasses.dataclass
+class Ritz:
+    """src/arnoldi/decomposition.py:71-79 -- ``RitzDecomposition``'s three fields."""
+
+    values: np.ndarray
+    vectors: np.ndarray
+    approximate_residuals: np.ndarray
+
+    def compute_true_residuals(self, A):
+        """decomposition.py:134-146 -- column norms of ``A U - U diag(values)``."""
+        return np.linalg.norm(A @ self.vectors - self.values * self.vectors, axis=0)
+
+
+def ritz_from_v_and_h(V, H, n_ritz, *, max_dim=None, sort_function=None):
+    """src/arnoldi/decomposition.py:81-132 -- ``RitzDecomposition.from_v_and_h``:
+    eigenpairs of ``H[:m, :m]`` (LAPACK zgeev through numpy), the first ``n_ritz`` in the order
+    of ``sort_function``, Ritz vectors ``V[:, :m] S`` and ``|H[m, m-1] * S[m-1, :]|``."""
+    max_dim = max_dim or V.shape[1] - 1               # decomposition.py:108
+    assert H.shape[0] > max_dim                       # decomposition.py:110-113
+    assert H.shape[1] >= max_dim
+    assert V.shape[1] > max_dim
+    assert n_ritz <= max_dim
+    if sort_function is None:
+        sort_function = arg_largest_magnitude
+    w, S = np.linalg.eig(H[:max_dim, :max_dim])       # decomposition.py:121
+    pick = sort_function(w)[:n_ritz]                  # decomposition.py:122
+    S = S[:, pick]
+    return Ritz(w[pick], V[:, :max_dim] @ S, np.abs(H[max_dim, max_dim - 1] * S[-1]))
+
+
+def mgs(basis, w, tol):
+    """src/arnoldi/explicit_restarts.py:64-78 -- modified Gram-Schmidt of ``w`` against the columns
+    of ``basis`` one at a time, then normalisation; in place; asserts on a norm <= tol."""
+    for j in range(basis.shape[1]):
+        w -= np.vdot(basis[:, j], w) * basis[:, j]
+    beta = np.linalg.norm(w)
+    assert beta > tol, "MGS: Too small norm when orthornormalizing"
+    w /= beta
+    return w
+
+
+def naive_explicit_restarts(A, m=None, *, stopping_criterion=None, max_restarts=10):
+    """src/arnoldi/explicit_restarts.py:31-61 -- one eigenpair: m Arnoldi steps, restart from the
+    dominant Ritz vector.  Returns ``(ritz, converged, restarts_used)``."""
+    tol = np.sqrt(np.finfo(A.dtype).eps) if stopping_criterion is None else stopping_criterion
+    dtype = np.promote_types(A.dtype, np.complex64)   # explicit_restarts.py:37
+    n = A.shape[0]
+    k = 1
+    if m is None:
+        m = min(max(2 * k + 1, 20), n)
+    V = np.zeros((n, m + 1), dtype)
+    H = np.zeros((m + 1, m), dtype)
+    v0 = random_unit_vector(n).astype(dtype)          # explicit_restarts.py:48
+    ritz = None
+    for i in range(max_restarts):
+        V[:, 0] = v0
+        Va, Ha, _ = arnoldi_expand(A, V, H)           # default invariant tolerance
+        ritz = ritz_from_v_and_h(Va, Ha, k)
+        if ritz.approximate_residuals[0] < tol:       # explicit_restarts.py:53-56
+            res = ritz.compute_true_residuals(A)
+            if res[0] / max(np.abs(ritz.values[0]), tol) < tol:
+                return ritz, True, i
+        v0 = ritz.vectors[:, 0]                       # explicit_restarts.py:58-59
+    return ritz, False, max_restarts
+
+
+def explicit_restarts_with_deflation(A, nev, *, max_dim=None, stopping_criterion=None,
+                                     max_restarts=100, sort_function=None):
+    """src/arnoldi/explicit_restarts.py:81-168 -- eigenpairs one at a time; converged Schur vectors
+    stay locked in ``V[:, :k]`` (the expansion from ``start_dim = k`` orthogonalises against them)
+    and ``H[:k+1, k]`` is rebuilt from them.  Returns ``(eigenvalues, eigenvectors, History)``."""
+    tol = np.sqrt(np.finfo(A.dtype).eps) if stopping_criterion is None else stopping_criterion
+    if sort_function is None:
+        sort_function = arg_largest_magnitude
+    assert max_restarts > 0
+    n = A.shape[0]
+    assert A.shape[1] == n
+    if max_dim is None:
+        max_dim = min(max(2 * nev + 1, 20), n)
+    V = np.zeros((n, max_dim + 1), dtype=C128)
+    H = np.zeros((max_dim + 1, max_dim), dtype=C128)
+    hist = History.from_k(nev)
+    for k in range(nev):
+        v0 = random_unit_vector(n, C128)              # explicit_restarts.py:111-113
+        mgs(V[:, :k], v0, tol)
+        V[:, k] = v0
+        for restart in range(max_restarts):
+            Va, Ha, m = arnoldi_expand(A, V, H, tol, start_dim=k)
+            assert m > k
+            lucky = m != max_dim                      # explicit_restarts.py:123-126
+            booked = restart * (max_dim - k) + (m - k)
+            ritz = ritz_from_v_and_h(Va[:, k:], Ha[k:, k:], m - k, sort_function=sort_function)
+            V[:, k] = ritz.vectors[:, 0]              # explicit_restarts.py:140-141
+            mgs(V[:, :k], V[:, k], tol)
+            if lucky or ritz.approximate_residuals[0] / np.abs(ritz.values[0]) < tol:
+                Av = A @ V[:, k]                      # explicit_restarts.py:149-151
+                for i in range(k + 1):
+                    H[i, k] = np.vdot(V[:, i], Av)
+                H[k + 1:-1, k] = 0
+                hist.matvecs[k] = booked
+                hist.restarts[k] = restart + 1
+                break
+        else:
+            raise ValueError(f"Could not converge for value {k}")
+    vals, Y = np.linalg.eig(H[:nev, :nev])            # explicit_restarts.py:166-167
+    return vals, V[:, :nev] @ Y, hist

@@ -1,0 +1,123 @@
+/* Plain-C host for libarnoldi_hip.so: no Python, no torch -- the C ABI of include/arnoldi_hip.h is
+ * the whole interface.  Builds a 1-D Laplacian (tridiagonal, n = 5000) in CSR, runs an m = 12 step
+ * Arnoldi expansion on the device (aks_arnoldi_expand = the reference's arnoldi_decomposition,
+ * src/arnoldi/decomposition.py:13-68), copies V and H back and checks the Arnoldi invariants
+ *     V^H V = I      and      A V_m = V_{m+1} H
+ * on the host, then compresses the basis with aks_truncate and re-checks orthonormality.
+ *
+ *   hipcc -x c abi_smoke.c -I../../include -L<dir of the .so> -larnoldi_hip -o abi_smoke
+ * Exit code 0 = pass.  Used by tests/test_gpu_parity.py::test_c_abi_from_plain_c. */
+#include <complex.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include "arnoldi_hip.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 2; } } while (0)
+#define CHECK_AKS(x) do { int rc_ = (int)(x); if (rc_ < 0) { \
+    fprintf(stderr, "aks error %d (%s) at line %d\n", rc_, aks_last_error(), __LINE__); return 3; } } while (0)
+
+int main(void) {
+    const int64_t n = 5000;
+    const int32_t m = 12, p = 5;
+    const int64_t nnz = 3 * n - 2, ldv = (n + 63) / 64 * 64;
+
+    /* host CSR of tridiag(1, -2, 1) */
+    int32_t *indptr = malloc((n + 1) * sizeof *indptr), *indices = malloc(nnz * sizeof *indices);
+    double *values = malloc(nnz * sizeof *values);
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        indptr[i] = (int32_t)k;
+        if (i > 0) { indices[k] = (int32_t)(i - 1); values[k++] = 1.0; }
+        indices[k] = (int32_t)i; values[k++] = -2.0;
+        if (i < n - 1) { indices[k] = (int32_t)(i + 1); values[k++] = 1.0; }
+    }
+    indptr[n] = (int32_t)k;
+    int32_t *tiles = malloc((n + 2) * sizeof *tiles);
+    const int64_t n_tiles = aks_csr_plan_tiles(indptr, n, AKS_SPMV_TILE_NNZ, tiles, n + 2);
+    CHECK_AKS(n_tiles);
+
+    aks_ws_layout lay;
+    CHECK_AKS(aks_workspace_layout(n, m, &lay));
+
+    int32_t *d_indptr, *d_indices, *d_tiles;
+    double *d_values;
+    aks_c128 *d_V, *d_H, *d_Q;
+    void *d_ws;
+    CHECK_HIP(hipMalloc((void **)&d_indptr, (n + 1) * 4));
+    CHECK_HIP(hipMalloc((void **)&d_indices, nnz * 4));
+    CHECK_HIP(hipMalloc((void **)&d_values, nnz * 8));
+    CHECK_HIP(hipMalloc((void **)&d_tiles, (n_tiles + 1) * 4));
+    CHECK_HIP(hipMalloc((void **)&d_V, (size_t)(m + 1) * ldv * 16));
+    CHECK_HIP(hipMalloc((void **)&d_H, (size_t)(m + 1) * m * 16));
+    CHECK_HIP(hipMalloc((void **)&d_Q, (size_t)m * p * 16));
+    CHECK_HIP(hipMalloc(&d_ws, lay.total_bytes));
+    CHECK_HIP(hipMemcpy(d_indptr, indptr, (n + 1) * 4, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_indices, indices, nnz * 4, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_values, values, nnz * 8, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_tiles, tiles, (n_tiles + 1) * 4, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemset(d_V, 0, (size_t)(m + 1) * ldv * 16));
+    CHECK_HIP(hipMemset(d_H, 0, (size_t)(m + 1) * m * 16));
+
+    /* start vector: deterministic, complex, unit norm */
+    double complex *V = calloc((size_t)(m + 1) * ldv, sizeof *V);
+    double nrm = 0.0;
+    for (int64_t i = 0; i < n; ++i) { V[i] = sin(0.37 * (double)i + 1.0) + 0.5 * I * cos(0.11 * (double)i); nrm += creal(V[i] * conj(V[i])); }
+    for (int64_t i = 0; i < n; ++i) V[i] /= sqrt(nrm);
+    CHECK_HIP(hipMemcpy(d_V, V, (size_t)n * 16, hipMemcpyHostToDevice));
+
+    CHECK_AKS(aks_workspace_init(d_ws, lay.total_bytes, n, m, NULL));
+    CHECK_AKS(aks_arnoldi_expand(n, d_indptr, d_indices, d_values, 0, d_tiles, n_tiles, 0, NULL, d_V, ldv, d_H, m,
+                                 0, m, 1e-8, sqrt(0.5), d_ws, lay.total_bytes, m, NULL, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+
+    double complex *H = malloc((size_t)(m + 1) * m * sizeof *H);
+    aks_ctrl ctrl;
+    CHECK_HIP(hipMemcpy(V, d_V, (size_t)(m + 1) * ldv * 16, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(H, d_H, (size_t)(m + 1) * m * 16, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(&ctrl, d_ws, sizeof ctrl, hipMemcpyDeviceToHost));
+    if (ctrl.broken || ctrl.steps_done != m) { fprintf(stderr, "unexpected control block\n"); return 4; }
+
+    double worst_orth = 0.0, worst_rel = 0.0;
+    for (int a = 0; a <= m; ++a)
+        for (int b = 0; b <= m; ++b) {
+            double complex s = 0.0;
+            for (int64_t i = 0; i < n; ++i) s += conj(V[a * ldv + i]) * V[b * ldv + i];
+            const double d = cabs(s - (a == b ? 1.0 : 0.0));
+            if (d > worst_orth) worst_orth = d;
+        }
+    for (int j = 0; j < m; ++j)                       /* A v_j - sum_i V_i H[i][j] */
+        for (int64_t i = 0; i < n; ++i) {
+            double complex r = -2.0 * V[j * ldv + i];
+            if (i > 0) r += V[j * ldv + i - 1];
+            if (i < n - 1) r += V[j * ldv + i + 1];
+            for (int c = 0; c <= j + 1; ++c) r -= V[c * ldv + i] * H[c * m + j];
+            if (cabs(r) > worst_rel) worst_rel = cabs(r);
+        }
+
+    /* restart compression with a unitary Qp: first p columns of a Householder reflector */
+    double complex *Q = calloc((size_t)m * p, sizeof *Q);
+    for (int r = 0; r < m; ++r)
+        for (int c = 0; c < p; ++c) Q[r * p + c] = (r == c ? 1.0 : 0.0) - 2.0 / m;   /* I - 2 u u^T, u = 1/sqrt(m) */
+    CHECK_HIP(hipMemcpy(d_Q, Q, (size_t)m * p * 16, hipMemcpyHostToDevice));
+    CHECK_AKS(aks_truncate(n, m, p, d_V, ldv, d_Q, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(V, d_V, (size_t)(p + 1) * ldv * 16, hipMemcpyDeviceToHost));
+    double worst_orth2 = 0.0;
+    for (int a = 0; a <= p; ++a)
+        for (int b = 0; b <= p; ++b) {
+            double complex s = 0.0;
+            for (int64_t i = 0; i < n; ++i) s += conj(V[a * ldv + i]) * V[b * ldv + i];
+            const double d = cabs(s - (a == b ? 1.0 : 0.0));
+            if (d > worst_orth2) worst_orth2 = d;
+        }
+    printf("abi %d: |V^H V - I| = %.2e, |A V - V H| = %.2e, after truncate |V^H V - I| = %.2e, second passes %d\n",
+           aks_abi_version(), worst_orth, worst_rel, worst_orth2, ctrl.second_passes);
+    return (worst_orth < 1e-12 && worst_rel < 1e-12 && worst_orth2 < 1e-12) ? 0 : 1;
+}

@@ -17,7 +17,12 @@ REF = "/root/reference/src"
 sys.path.insert(0, REF)
 sys.dont_write_bytecode = True
 
-from arnoldi.decomposition import arnoldi_decomposition  # noqa: E402
+from arnoldi.decomposition import RitzDecomposition, arnoldi_decomposition  # noqa: E402
+from arnoldi.explicit_restarts import (  # noqa: E402
+    explicit_restarts_with_deflation,
+    mgs,
+    naive_explicit_restarts,
+)
 from arnoldi.krylov_schur import partial_schur  # noqa: E402
 from arnoldi.matrices import laplace, laplace_eigen, mark  # noqa: E402
 from arnoldi.ortho import dgks_gs  # noqa: E402
@@ -255,5 +260,87 @@ def main():
     save("g9_errors", not_converged=np.array(msg))
 
 
+def explicit_restart_fixtures():
+    """G10: the explicit-restart path: RitzDecomposition, mgs and the two
+    solvers of src/arnoldi/explicit_restarts.py on the cases of tests/test_explicit_restarts.py
+    plus two sparse ones.  ``python make_golden.py explicit`` regenerates only this file."""
+    g = {}
+    rng = np.random.default_rng(11)
+
+    # (a) Ritz extraction from a real Arnoldi factorisation of mark(10), m = 8
+    A = mark(10)
+    n, m = A.shape[0], 8
+    V = np.zeros((n, m + 1), C128)
+    H = np.zeros((m + 1, m), C128)
+    np.random.seed(3)
+    V[:, 0] = rand_normalized_vector(n, C128)
+    Va, Ha, n_iter = arnoldi_decomposition(A, V, H)
+    assert n_iter == m
+    g["ritz_V"], g["ritz_H"] = np.array(Va), np.array(Ha)
+    for tag, nr, fn in (("lm3", 3, None), ("lr8", 8, arg_largest_real)):
+        r = RitzDecomposition.from_v_and_h(Va, Ha, nr, sort_function=fn)
+        g[f"ritz_{tag}_values"] = r.values
+        g[f"ritz_{tag}_vectors"] = r.vectors
+        g[f"ritz_{tag}_approx"] = r.approximate_residuals
+        g[f"ritz_{tag}_true"] = r.compute_true_residuals(A)
+
+    # (b) mgs against 0, 1 and 6 orthonormal columns
+    nn = 300
+    Bq, _ = np.linalg.qr(rng.standard_normal((nn, 6)) + 1j * rng.standard_normal((nn, 6)))
+    g["mgs_basis"] = np.asfortranarray(Bq.astype(C128))
+    w0 = (rng.standard_normal(nn) + 1j * rng.standard_normal(nn)).astype(C128)
+    g["mgs_w_in"] = w0
+    for k in (0, 1, 6):
+        w = w0.copy()
+        mgs(g["mgs_basis"][:, :k], w, 1e-8)
+        g[f"mgs_w_out_{k}"] = w
+
+    # (c) naive explicit restarts: Saad table 6.2 (mark(10), m = 10) and the convergence test
+    for restarts in (1, 2, 3, 4, 5):
+        np.random.seed(0)
+        ritz, ok, used = naive_explicit_restarts(A, 10, max_restarts=restarts)
+        g[f"naive_r{restarts}_value"] = ritz.values
+        g[f"naive_r{restarts}_true"] = ritz.compute_true_residuals(A)
+        g[f"naive_r{restarts}_flags"] = np.array([int(ok), used])
+    np.random.seed(0)
+    ritz, ok, used = naive_explicit_restarts(A, 20, max_restarts=200, stopping_criterion=1e-6)
+    g["naive_conv_value"], g["naive_conv_true"] = ritz.values, ritz.compute_true_residuals(A)
+    g["naive_conv_flags"] = np.array([int(ok), used])
+    g["naive_conv_vector"] = ritz.vectors[:, 0]
+
+    # (d) deflation solver: Saad table 6.3 (mark(10), m = 10, k = 3, LR), the rotated diagonal with a
+    # double eigenvalue (happy breakdown inside), mark(30) LR and a 2-D Laplacian LM
+    def record(tag, M, nev, seed, **kw):
+        np.random.seed(seed)
+        vals, vecs, hist = explicit_restarts_with_deflation(M, nev, **kw)
+        g[f"{tag}_vals"], g[f"{tag}_vecs"] = vals, vecs
+        g[f"{tag}_matvecs"], g[f"{tag}_restarts"] = hist.matvecs, hist.restarts
+        g[f"{tag}_residuals"] = np.linalg.norm(M @ vecs - vals * vecs, axis=0)
+
+    record("defl_mark10", A, 3, 0, max_dim=10, stopping_criterion=1e-8, sort_function=arg_largest_real)
+    D = np.diag([7.0, 7, 5, 4, 3, 2, 1])
+    Qr, _ = np.linalg.qr(rng.standard_normal((7, 7)))
+    Ad = Qr.T @ D @ Qr
+    g["defl_diag_A"] = Ad
+    record("defl_diag", Ad, 3, 0)
+    record("defl_mark30", mark(30), 4, 1, max_dim=30, stopping_criterion=1e-8, sort_function=arg_largest_real)
+    L = laplace2d(12, 13)
+    record("defl_lap", L, 3, 2, max_dim=30, stopping_criterion=1e-6, max_restarts=400)
+
+    # (e) the error of test_fail_convergence
+    np.random.seed(0)
+    try:
+        explicit_restarts_with_deflation(A, 3, max_dim=5, stopping_criterion=1e-16, max_restarts=10)
+        msg = ""
+    except ValueError as e:
+        msg = str(e)
+    g["defl_fail_message"] = np.array(msg)
+    save("g10_explicit_restarts", **g)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["explicit"]:
+        explicit_restart_fixtures()
+    else:
+        main()
+        explicit_restart_fixtures()

@@ -612,3 +612,17 @@ def test_stress_grid_against_oracle(amd, nev, ncv, p, which):
     _, _, rel_o = oracle.eig_residuals(A, Qo, To)
     assert rel.max() <= max(1.05 * rel_o.max(), 1e-12), (rel.max(), rel_o.max())
     np.testing.assert_allclose(Q.conj().T @ Q, np.eye(nev), atol=1e-11)
+
+
+def test_c_abi_from_plain_c():
+    """tests/c_abi/abi_smoke.c -- a C program with hipMalloc'd buffers and no Python in the process --
+    drives aks_arnoldi_expand + aks_truncate through include/arnoldi_hip.h and checks the Arnoldi
+    invariants on the host (what a cgo/JNI/ctypes binding of the reference would rely on)."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(__file__), "c_abi", "abi_smoke")
+    assert os.path.exists(exe), "tests/c_abi/abi_smoke missing: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "|A V - V H|" in r.stdout

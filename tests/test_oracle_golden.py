@@ -178,3 +178,87 @@ def test_not_converged_message():
     with pytest.raises(ValueError) as e:
         oracle.krylov_schur(A, 5, max_dim=20, max_restarts=3)
     assert str(e.value) == str(g["not_converged"]) == "Has not converged !"
+
+
+# ---------------------------------------------------------------- explicit restarts (G10)
+def _laplace2d(nx, ny):
+    Lx, Ly = sp.csr_matrix(oracle.laplace_1d(nx)), sp.csr_matrix(oracle.laplace_1d(ny))
+    return (sp.kron(sp.eye(ny), Lx) + sp.kron(Ly, sp.eye(nx))).tocsr()
+
+
+def _same_up_to_phase(u, v, atol):
+    """Eigenvector columns are defined up to a unit factor only when LAPACK versions differ; here the
+    oracle and the reference share LAPACK, so compare directly and fall back to the phase-free test
+    for the message."""
+    np.testing.assert_allclose(u, v, rtol=0, atol=atol)
+
+
+def test_ritz_from_v_and_h():
+    g = load_golden("g10_explicit_restarts")
+    A = oracle.mark_matrix(10)
+    for tag, nr, fn in (("lm3", 3, None), ("lr8", 8, oracle.arg_largest_real)):
+        r = oracle.ritz_from_v_and_h(g["ritz_V"], g["ritz_H"], nr, sort_function=fn)
+        np.testing.assert_allclose(r.values, g[f"ritz_{tag}_values"], **TIGHT)
+        _same_up_to_phase(r.vectors, g[f"ritz_{tag}_vectors"], 1e-12)
+        np.testing.assert_allclose(r.approximate_residuals, g[f"ritz_{tag}_approx"], **TIGHT)
+        np.testing.assert_allclose(r.compute_true_residuals(A), g[f"ritz_{tag}_true"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("k", [0, 1, 6])
+def test_mgs(k):
+    g = load_golden("g10_explicit_restarts")
+    w = g["mgs_w_in"].copy()
+    out = oracle.mgs(g["mgs_basis"][:, :k], w, 1e-8)
+    assert out is w
+    np.testing.assert_array_equal(w, g[f"mgs_w_out_{k}"])     # same NumPy arithmetic: bit for bit
+    with pytest.raises(AssertionError, match="Too small norm"):
+        oracle.mgs(g["mgs_basis"][:, :2], g["mgs_basis"][:, 0].copy(), 1e-8)
+
+
+def test_naive_explicit_restarts():
+    g = load_golden("g10_explicit_restarts")
+    A = oracle.mark_matrix(10)
+    for restarts, digits in [(1, 0), (2, 1), (3, 3), (4, 5), (5, 6)]:     # tests/test_explicit_restarts.py:45-60
+        np.random.seed(0)
+        ritz, ok, used = oracle.naive_explicit_restarts(A, 10, max_restarts=restarts)
+        np.testing.assert_allclose(ritz.values, g[f"naive_r{restarts}_value"], rtol=1e-12)
+        np.testing.assert_allclose(ritz.compute_true_residuals(A), g[f"naive_r{restarts}_true"], rtol=1e-6)
+        assert [int(ok), used] == list(g[f"naive_r{restarts}_flags"])
+        assert ritz.compute_true_residuals(A) <= 2 * 10.0 ** (-digits)
+    np.random.seed(0)
+    ritz, ok, used = oracle.naive_explicit_restarts(A, 20, max_restarts=200, stopping_criterion=1e-6)
+    assert [int(ok), used] == list(g["naive_conv_flags"]) and ok
+    np.testing.assert_allclose(ritz.values, g["naive_conv_value"], rtol=1e-12)
+    np.testing.assert_allclose(ritz.vectors[:, 0], g["naive_conv_vector"], rtol=0, atol=1e-12)
+    assert ritz.compute_true_residuals(A) <= 1e-6
+
+
+@pytest.mark.parametrize("tag", ["defl_mark10", "defl_diag", "defl_mark30", "defl_lap"])
+def test_explicit_restarts_with_deflation(tag):
+    g = load_golden("g10_explicit_restarts")
+    M, nev, seed, kw = {
+        "defl_mark10": (oracle.mark_matrix(10), 3, 0,
+                        dict(max_dim=10, stopping_criterion=1e-8, sort_function=oracle.arg_largest_real)),
+        "defl_diag": (g["defl_diag_A"], 3, 0, {}),
+        "defl_mark30": (oracle.mark_matrix(30), 4, 1,
+                        dict(max_dim=30, stopping_criterion=1e-8, sort_function=oracle.arg_largest_real)),
+        "defl_lap": (_laplace2d(12, 13), 3, 2, dict(max_dim=30, stopping_criterion=1e-6, max_restarts=400)),
+    }[tag]
+    np.random.seed(seed)
+    vals, vecs, hist = oracle.explicit_restarts_with_deflation(M, nev, **kw)
+    np.testing.assert_array_equal(hist.matvecs, g[f"{tag}_matvecs"])
+    np.testing.assert_array_equal(hist.restarts, g[f"{tag}_restarts"])
+    np.testing.assert_allclose(vals, g[f"{tag}_vals"], rtol=1e-11, atol=1e-13)
+    res = np.linalg.norm(M @ vecs - vals * vecs, axis=0)
+    np.testing.assert_allclose(res, g[f"{tag}_residuals"], rtol=1e-3, atol=1e-14)
+    if tag != "defl_diag":      # the double eigenvalue's vectors span a plane: compared through residuals only
+        _same_up_to_phase(vecs, g[f"{tag}_vecs"], 1e-10)
+
+
+def test_explicit_restarts_fail_message():
+    g = load_golden("g10_explicit_restarts")
+    np.random.seed(0)
+    with pytest.raises(ValueError, match="Could not converge for value 0") as e:
+        oracle.explicit_restarts_with_deflation(oracle.mark_matrix(10), 3, max_dim=5, stopping_criterion=1e-16,
+                                                max_restarts=10)
+    assert str(e.value) == str(g["defl_fail_message"])
