@@ -90,6 +90,8 @@ SIGNATURES = {
     "aks_arnoldi_expand": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, C.POINTER(PbMatrix), _P, _I64,
                                      _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P]),
     "aks_truncate": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P]),
+    "aks_combine": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P, _I64, _P]),
+    "aks_scale": (C.c_int, [_I64, _P, _F64, _F64, _P]),
     "aks_gather_c128": (C.c_int, [_I64, _P, _P, _P, _P]),
     "aks_probe_create": (C.c_int, [_I32, C.POINTER(_P)]),
     "aks_probe_destroy": (C.c_int, [_P]),

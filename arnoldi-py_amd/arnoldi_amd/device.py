@@ -367,3 +367,53 @@ def truncate(basis, m, p, Qp_dev):
 def gather_c128(count, idx, src, dst):
     rc = _hip.load().aks_gather_c128(count, _ptr(idx), _ptr(src), _ptr(dst), _stream())
     _hip.check(rc, "aks_gather_c128")
+
+
+def combine(n_rows, m, V, ldv, S_dev, out, ldo):
+    """out[:, :q] = V[:, :m] @ S on the device (S_dev: (m, q) complex128 tensor), out of place."""
+    q = int(S_dev.shape[1])
+    rc = _hip.load().aks_combine(n_rows, m, q, _ptr(V), ldv, _ptr(S_dev), _ptr(out), ldo, _stream())
+    _hip.check(rc, "aks_combine")
+
+
+def scale(n_rows, w, alpha):
+    alpha = complex(alpha)
+    rc = _hip.load().aks_scale(n_rows, _ptr(w), alpha.real, alpha.imag, _stream())
+    _hip.check(rc, "aks_scale")
+
+
+class DeviceColumns:
+    """``n_cols`` complex128 vectors of ``n_rows`` entries in HBM, column-major with the basis'
+    padded leading dimension (Ritz vectors, eigenvectors, scratch columns)."""
+
+    def __init__(self, n_rows, n_cols, device=None):
+        device = _require_gpu(device)
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.ldv = (self.n_rows + 63) // 64 * 64
+        self.V = torch.zeros((self.n_cols, self.ldv), dtype=torch.complex128, device=device)
+        self.device = device
+
+    def col(self, j):
+        return self.V[j]
+
+    def set_cols(self, j0, host_cols):
+        a = np.ascontiguousarray(np.asarray(host_cols, dtype=C128).T)
+        self.V[j0: j0 + a.shape[0], : self.n_rows].copy_(torch.from_numpy(a))
+
+    def get_cols(self, j0=0, j1=None):
+        j1 = self.n_cols if j1 is None else j1
+        return self.V[j0:j1, : self.n_rows].cpu().numpy().T
+
+
+def combine_columns(cols, j0, m, S, out=None):
+    """``cols[:, j0:j0+m] @ S`` on the device (``aks_combine``) -> DeviceColumns with S.shape[1]
+    columns.  ``cols`` is a ``KrylovBasis`` or a ``DeviceColumns``; S is a host (m, q) array."""
+    S = np.ascontiguousarray(np.asarray(S, dtype=C128).reshape(m, -1))
+    q = S.shape[1]
+    if out is None:
+        out = DeviceColumns(cols.n_rows, q, cols.device)
+    for c0 in range(0, q, 64):                        # column chunks keep S within the kernel's LDS budget
+        Sd = torch.from_numpy(np.ascontiguousarray(S[:, c0: c0 + 64])).to(cols.device)
+        combine(cols.n_rows, m, cols.V.data_ptr() + 16 * cols.ldv * j0, cols.ldv, Sd,
+                out.V.data_ptr() + 16 * out.ldv * c0, out.ldv)
+    return out

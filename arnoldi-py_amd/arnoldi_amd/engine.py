@@ -126,6 +126,18 @@ class HostOperator:
         y[: self.n].copy_(torch.from_numpy(np.ascontiguousarray(hy)))
 
 
+class NullOperator:
+    """Sizes only: for contexts that orthogonalise / combine columns but never apply A."""
+
+    def __init__(self, n):
+        self.n = self.n_local = int(n)
+        self.r0, self.r1, self.comm = 0, int(n), None
+        self.shape = (self.n, self.n)
+
+    def apply(self, x, y, ws=None):
+        raise TypeError("this context has no operator")
+
+
 def as_operator(A, comm=None, device=None):
     if isinstance(A, (CsrOperator, HostOperator)):
         return A
@@ -292,6 +304,108 @@ class ArnoldiContext:
             out[i] = red2[2]                                      # red2[1].re = ||r||^2
         res = np.sqrt(out.cpu().numpy())
         return vals, res, res / np.abs(vals)
+
+    # -- building blocks of the explicit-restart solvers ---------------------
+    # All of them work on columns of the resident basis; nothing of length n moves to the host.
+    def _clear_ctrl(self):
+        """Stage kernels are no-ops once the control block says ``broken`` (a happy breakdown in the
+        last expansion): clear (broken, n_iter) before using them outside an expansion."""
+        self.ws.buf[:8].zero_()
+
+    def _multi(self):
+        return self.comm is not None and self.comm.active
+
+    def mgs(self, k, j, tol):
+        """``mgs(V[:, :k], V[:, j], tol)`` of src/arnoldi/explicit_restarts.py:64-78: modified
+        Gram-Schmidt of column ``j`` against columns ``0..k-1`` one at a time (each a J = 1 projection
+        + fused update of the DGKS stage kernels), then normalisation.  Returns beta."""
+        b, ws, lib = self.basis, self.ws, _hip.load()
+        self._clear_ctrl()
+        w = b.V.data_ptr() + 16 * b.ldv * j
+        args = (dev._ptr(ws.buf), ws.nbytes, ws.max_dim, dev._stream())
+        multi = self._multi()
+        for i in range(max(k, 1)):
+            vi = b.V.data_ptr() + 16 * b.ldv * i if k else w       # k == 0: only ||w||^2 is wanted
+            _hip.check(lib.aks_gs_project(b.n_rows, 1, vi, b.ldv, w, *args), "aks_gs_project")
+            if multi:
+                self.comm.allreduce_sum_(ws.red(1, 2))
+            if k:
+                _hip.check(lib.aks_gs_update_project(b.n_rows, 1, vi, b.ldv, w, *args), "aks_gs_update_project")
+        slot = ws.red(2, 2) if k else ws.red(1, 2)                   # [<v, w>, ||w||^2] after the last step
+        if multi and k:
+            self.comm.allreduce_sum_(slot)
+        beta = float(np.sqrt(slot[2].item()))
+        assert beta > tol, "MGS: Too small norm when orthornormalizing"      # explicit_restarts.py:74-75
+        dev.scale(b.n_rows, w, 1.0 / beta)
+        return beta
+
+    def ritz_vector_into_first(self, k, m, s):
+        """``V[:, k] = V[:, k:m] @ s`` in place (the restart vector of both explicit-restart solvers,
+        explicit_restarts.py:59 and :140): ``aks_truncate`` with p = 1 on the sub-basis that starts at
+        column k.  (Its second effect, ``V[:, k+1] = V[:, m]``, lands in a column the next expansion
+        recomputes.)"""
+        b = self.basis
+        Sd = torch.from_numpy(np.ascontiguousarray(np.asarray(s, dtype=C128).reshape(m - k, 1))).to(b.device)
+        rc = _hip.load().aks_truncate(b.n_rows, m - k, 1, b.V.data_ptr() + 16 * b.ldv * k, b.ldv,
+                                      dev._ptr(Sd), dev._stream())
+        _hip.check(rc, "aks_truncate")
+
+    def _scratch_col(self):
+        if getattr(self, "_scratch", None) is None:
+            self._scratch = dev.DeviceColumns(self.basis.n_rows, 1, self.basis.device)
+        return self._scratch.col(0)
+
+    def rayleigh_column(self, k):
+        """``[vdot(V[:, i], A @ V[:, k]) for i <= k]`` (explicit_restarts.py:149-150): one operator
+        application into a scratch column and one (k+1)-column projection."""
+        b, ws = self.basis, self.ws
+        self._clear_ctrl()
+        y = self._scratch_col()
+        self.op.apply(b.col(k), y, ws)
+        dev.gs_project(b, k + 1, y, ws)
+        red = ws.red(1, k + 2)
+        if self._multi():
+            self.comm.allreduce_sum_(red)
+        return red[: 2 * (k + 1)].cpu().numpy().view(C128).copy()
+
+    def residual_norms(self, block, values, j0=0):
+        """``||A u_i - values[i] u_i||`` for the device columns ``u_i = block.col(j0 + i)`` (``block`` is
+        the basis or a ``DeviceColumns``) -- RitzDecomposition.compute_true_residuals,
+        decomposition.py:134-146: operator application into a scratch column, then
+        ``aks_gs_update_project`` with J = 1 and coefficient values[i], whose norm output is
+        ``||A u_i - values[i] u_i||^2``."""
+        b, ws, lib = self.basis, self.ws, _hip.load()
+        self._clear_ctrl()
+        values = np.atleast_1d(np.asarray(values, dtype=C128))
+        lam = torch.from_numpy(values).to(b.device).view(torch.float64)
+        y = self._scratch_col()
+        red1, red2 = ws.red(1, 1), ws.red(2, 2)
+        out = torch.zeros(len(values), dtype=torch.float64, device=b.device)
+        for i in range(len(values)):
+            u = block.col(j0 + i)
+            self.op.apply(u, y, ws)
+            red1.copy_(lam[2 * i: 2 * i + 2])
+            _hip.check(lib.aks_gs_update_project(b.n_rows, 1, dev._ptr(u), block.ldv, dev._ptr(y), dev._ptr(ws.buf),
+                                                 ws.nbytes, ws.max_dim, dev._stream()), "aks_gs_update_project")
+            if self._multi():
+                self.comm.allreduce_sum_(red2)
+            out[i] = red2[2]
+        return np.sqrt(out.cpu().numpy())
+
+    def combine(self, j0, m, S, out=None):
+        """``V[:, j0:j0+m] @ S`` into a new (or the given) ``DeviceColumns`` block, out of place."""
+        return dev.combine_columns(self.basis, j0, m, S, out)
+
+    def gather_block(self, block):
+        """Host copy of a ``DeviceColumns`` block with all rows (every rank), Fortran order."""
+        loc = block.get_cols()
+        if self.comm is None or self.comm.size == 1:
+            return np.asfortranarray(loc)
+        import torch.distributed as dist
+
+        parts = [None] * self.comm.size
+        dist.all_gather_object(parts, np.ascontiguousarray(loc), group=self.comm.group)
+        return np.asfortranarray(np.concatenate(parts, axis=0))
 
 
 def default_comm():

@@ -551,9 +551,11 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *
 // M-tiles; it reads all m columns of its rows before it overwrites any, hence in place.
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// The same kernel also forms Ritz vectors out of place (aks_combine: O != V, no column copy).
 template <int MT, int NS>   // NS row sub-tiles of 16 per wave (4, or 2 when MT is large)
-__global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p, c128 *__restrict__ V, int64_t ldv,
-                                                        const c128 *__restrict__ Qp) {
+__global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p, c128 *V, int64_t ldv,
+                                                        const c128 *__restrict__ Qp, c128 *O, int64_t ldo,
+                                                        int copy_last) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     c128 *qs = reinterpret_cast<c128 *>(smem_raw);      // [mpad][PP] complex, zero padded
     constexpr int PP = MT * 8;
@@ -606,21 +608,27 @@ __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p
                     for (int r = 0; r < 4; ++r) {
                         const int jj = mt * 16 + g + 4 * r;      // real output column held in register r
                         const int j = jj >> 1;
-                        if (j < p) reinterpret_cast<double *>(V + row + (int64_t)j * ldv)[jj & 1] = acc[s][mt][r];
+                        if (j < p) reinterpret_cast<double *>(O + row + (int64_t)j * ldo)[jj & 1] = acc[s][mt][r];
                     }
                 }
             }
         }
         // V[:, p] = V[:, m] (krylov_schur.py:81).  Column m is never a destination of the stores
         // above (they end at column p - 1 <= m - 1), so it can be read here.
-        if (g == 0) {
+        if (copy_last && g == 0) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int64_t row = row0 + s * 16 + r16;
-                if (row < n) V[row + (int64_t)p * ldv] = V[row + (int64_t)m * ldv];
+                if (row < n) O[row + (int64_t)p * ldo] = V[row + (int64_t)m * ldv];
             }
         }
     }
+}
+
+// w *= alpha (the normalisation at the end of the explicit-restart solvers' mgs, explicit_restarts.py:77)
+__global__ __launch_bounds__(BLOCK) void k_scale(int64_t n, c128 *__restrict__ w, c128 alpha) {
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) w[i] = cmul(alpha, w[i]);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_gather(int64_t count, const int32_t *__restrict__ idx,
@@ -838,7 +846,8 @@ void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c12
 }
 
 template <int MT>
-int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_t ldv, const c128 *Qp) {
+int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_t ldv, const c128 *Qp, c128 *O,
+                         int64_t ldo, int copy_last) {
     constexpr int NS = MT <= 9 ? 4 : 2;      // keeps NS * MT * 8 accumulator registers below the spill point
     const size_t smem = (size_t)((m + 3) & ~3) * MT * 8 * sizeof(c128);
     if (smem > 160 * 1024) return fail(AKS_ERR_UNSUPPORTED, "Qp does not fit the 160 KiB LDS");
@@ -851,7 +860,7 @@ int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_
     }
     const int64_t want = ((n + 16 * NS - 1) / (16 * NS) + WAVES - 1) / WAVES;
     const dim3 grid((unsigned)(want < 4096 ? want : 4096));
-    hipLaunchKernelGGL((k_truncate_mfma<MT, NS>), grid, dim3(BLOCK), smem, s, n, m, p, V, ldv, Qp);
+    hipLaunchKernelGGL((k_truncate_mfma<MT, NS>), grid, dim3(BLOCK), smem, s, n, m, p, V, ldv, Qp, O, ldo, copy_last);
     AKS_CHECK_LAUNCH("k_truncate_mfma");
     return AKS_OK;
 }
@@ -1243,12 +1252,47 @@ int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ld
     c128 *V = reinterpret_cast<c128 *>(d_V);
     const c128 *Q = reinterpret_cast<const c128 *>(d_Qp);
     switch ((p + 7) / 8) {   // M-tiles of 16 real = 8 complex output columns
-#define M(N) case N: return launch_truncate_mfma<N>(s, n_rows, m, p, V, ldv, Q);
+#define M(N) case N: return launch_truncate_mfma<N>(s, n_rows, m, p, V, ldv, Q, V, ldv, 1);
         M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12)
 #undef M
         default: break;
     }
     return fail(AKS_ERR_UNSUPPORTED, "p exceeds AKS_MAX_TRUNC");
+}
+
+int aks_combine(int64_t n_rows, int32_t m, int32_t q, const aks_c128 *d_V, int64_t ldv, const aks_c128 *d_S,
+                aks_c128 *d_out, int64_t ldo, void *stream) {
+    if (n_rows <= 0 || d_V == nullptr || d_S == nullptr || d_out == nullptr) return fail(AKS_ERR_ARG, "bad argument");
+    if (m < 1 || m > AKS_MAX_DIM) return fail(AKS_ERR_UNSUPPORTED, "m outside [1, AKS_MAX_DIM]");
+    if (q < 1) return fail(AKS_ERR_ARG, "need q >= 1");
+    if (q > AKS_MAX_TRUNC) return fail(AKS_ERR_UNSUPPORTED, "q exceeds AKS_MAX_TRUNC");
+    if (ldv < n_rows || ldo < n_rows) return fail(AKS_ERR_ARG, "leading dimension < n_rows");
+    {   // out of place only (a wave may overwrite rows another wave has not read yet unless O == V exactly)
+        const char *v0 = reinterpret_cast<const char *>(d_V), *v1 = v0 + ((int64_t)(m - 1) * ldv + n_rows) * 16;
+        const char *o0 = reinterpret_cast<const char *>(d_out), *o1 = o0 + ((int64_t)(q - 1) * ldo + n_rows) * 16;
+        if (o0 < v1 && v0 < o1) return fail(AKS_ERR_ARG, "out overlaps V (use aks_truncate for the in-place form)");
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    c128 *V = const_cast<c128 *>(reinterpret_cast<const c128 *>(d_V));   // only read when copy_last == 0
+    const c128 *S = reinterpret_cast<const c128 *>(d_S);
+    c128 *O = reinterpret_cast<c128 *>(d_out);
+    switch ((q + 7) / 8) {
+#define M(N) case N: return launch_truncate_mfma<N>(s, n_rows, m, q, V, ldv, S, O, ldo, 0);
+        M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12)
+#undef M
+        default: break;
+    }
+    return fail(AKS_ERR_UNSUPPORTED, "q exceeds AKS_MAX_TRUNC");
+}
+
+int aks_scale(int64_t n_rows, aks_c128 *d_w, double alpha_re, double alpha_im, void *stream) {
+    if (n_rows <= 0 || d_w == nullptr) return fail(AKS_ERR_ARG, "bad argument");
+    const int64_t want = (n_rows + BLOCK - 1) / BLOCK;
+    const dim3 grid((unsigned)(want < 4096 ? want : 4096));
+    hipLaunchKernelGGL(k_scale, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), n_rows,
+                       reinterpret_cast<c128 *>(d_w), make_double2(alpha_re, alpha_im));
+    AKS_CHECK_LAUNCH("k_scale");
+    return AKS_OK;
 }
 
 int aks_probe_create(int32_t capacity, void **probe_out) try {

@@ -203,6 +203,18 @@ int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d
 int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv,
                  const aks_c128 *d_Qp, void *stream);
 
+/* ---- Ritz vectors: replaces  ritz_vectors = V_m @ S  (decomposition.py:125) and
+ * eivecs = V[:, :nev] @ Y  (explicit_restarts.py:167) --------------------------------
+ * out[:, :q] = V[:, :m] @ S, out of place (out must not overlap V; the in-place restart form is
+ * aks_truncate).  d_S is m x q complex128, row-major (ld = q); q <= AKS_MAX_TRUNC and the LDS limit of
+ * aks_truncate apply.  Same f64-MFMA kernel as aks_truncate. */
+int aks_combine(int64_t n_rows, int32_t m, int32_t q, const aks_c128 *d_V, int64_t ldv,
+                const aks_c128 *d_S, aks_c128 *d_out, int64_t ldo, void *stream);
+
+/* w *= alpha: the normalisation that ends the explicit-restart solvers' mgs (explicit_restarts.py:74-77;
+ * the projections before it are aks_gs_project / aks_gs_update_project with J = 1, one column at a time). */
+int aks_scale(int64_t n_rows, aks_c128 *d_w, double alpha_re, double alpha_im, void *stream);
+
 /* ---- device-time probes (measurement only; bench.py's roofline figures) --------
  * A probe owns `capacity` hipEvent pairs.  When one is handed to
  * aks_arnoldi_expand, every SpMV launch is bracketed by a pair with tag

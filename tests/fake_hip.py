@@ -193,6 +193,21 @@ class FakeHip:
         Vv[p, :n] = last
         return 0
 
+    def aks_combine(self, n, m, q, V, ldv, S, out, ldo, stream):
+        self.calls.append("combine")
+        Vv = _view(V, C128, ldv * (m - 1) + n)
+        cols = np.stack([Vv[c * ldv: c * ldv + n] for c in range(m)])          # (m, n)
+        Sm = _view(S, C128, m * q).reshape(m, q)
+        Ov = _view(out, C128, ldo * (q - 1) + n)
+        new = Sm.T @ cols
+        for c in range(q):
+            Ov[c * ldo: c * ldo + n] = new[c]
+        return 0
+
+    def aks_scale(self, n, w, a_re, a_im, stream):
+        _view(w, C128, n)[:] *= complex(a_re, a_im)
+        return 0
+
     def aks_gather_c128(self, count, idx, src, dst, stream):
         if count == 0:
             return 0

@@ -440,3 +440,32 @@ def test_scatter_ratio_separates_stencils_from_random_graphs():
     assert ratio(matrices.laplace2d(300, 301)) < 0.2
     assert ratio(matrices.laplace3d(40, 41, 42)) < 0.3
     assert ratio(matrices.random_csr(200_000, 5, 1)) > 0.9
+
+
+# ---------------------------------------------------------------- explicit restarts (host logic)
+def test_explicit_restart_building_blocks(fake):
+    import explicit_cases as ec
+
+    ec.check_ritz_decomposition()
+    ec.check_ritz_wide(n=500, m=100, q=100)
+    ec.check_mgs()
+    assert "combine" in fake.calls
+
+
+def test_naive_explicit_restarts_host_logic(fake):
+    import explicit_cases as ec
+
+    ec.check_naive()
+
+
+@pytest.mark.parametrize("tag", ["defl_mark10", "defl_diag", "defl_mark30", "defl_lap"])
+def test_explicit_restarts_with_deflation_host_logic(fake, tag):
+    import explicit_cases as ec
+
+    ec.check_deflation(tag)
+
+
+def test_explicit_restarts_reference_tests_host_logic(fake):
+    import explicit_cases as ec
+
+    ec.check_deflation_reference_tests()
