@@ -370,6 +370,16 @@ def run_dist_worker(tmp_path, nproc, backend, device, timeout=600):
 
 def check_dist_verdicts(verdicts):
     for v in verdicts:
+        ex = v.pop("explicit")
+        for name in ("mark30", "planted"):
+            c = ex[name]
+            assert c["hist_equal"] and c["eig_err"] < 1e-9, (name, c)
+            assert c["res_max"] <= max(2 * c["res_oracle_max"], 1e-11), (name, c)
+            assert c["device_residual_err"] < 1e-11, (name, c)
+        assert ex["mark30"]["shape"] == [465, 4] and ex["planted"]["shape"] == [6000, 3]
+        c = ex["naive"]
+        assert c["flags_equal"] and c["value_err"] < 1e-10 and c["vector_shape"] == [55, 1], c
+        assert abs(c["true_residual"] - c["true_residual_oracle"]) <= 1e-3 * c["true_residual_oracle"] + 1e-12, c
         assert set(v) == {"mark50", "laplace2d", "random_planted", "local_rows", "block_diag", "complex"}
         for name, c in v.items():
             assert c["restarts_equal"] and c["matvec_hist_equal"], (name, c)
