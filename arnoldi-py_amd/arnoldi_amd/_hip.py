@@ -89,6 +89,8 @@ SIGNATURES = {
     "aks_pb_spmv": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),
     "aks_arnoldi_expand": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, C.POINTER(PbMatrix), _P, _I64,
                                      _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P]),
+    "aks_arnoldi_expand_from_w": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, C.POINTER(PbMatrix), _P, _I64,
+                                            _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P]),
     "aks_truncate": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P]),
     "aks_combine": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P, _I64, _P]),
     "aks_scale": (C.c_int, [_I64, _P, _F64, _F64, _P]),

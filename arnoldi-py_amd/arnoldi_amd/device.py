@@ -417,3 +417,24 @@ def combine_columns(cols, j0, m, S, out=None):
         combine(cols.n_rows, m, cols.V.data_ptr() + 16 * cols.ldv * j0, cols.ldv, Sd,
                 out.V.data_ptr() + 16 * out.ldv * c0, out.ldv)
     return out
+
+
+def fetch_H_and_ctrl(basis, ws):
+    """Queue the copy of the device H and the 64-byte control block to pinned host memory on the current
+    stream and return a function that waits for exactly that copy (an event, not the whole stream) and
+    gives ``(H_host, ctrl)``.  Kernels queued after this call keep running while the host works on H."""
+    if not basis.V.is_cuda:                                   # CPU tensors (tests/fake_hip.py)
+        return lambda: (basis.download_H(), ws.read_ctrl())
+    if getattr(basis, "_H_pinned", None) is None:
+        basis._H_pinned = torch.empty(basis.H.shape, dtype=basis.H.dtype, pin_memory=True)
+        basis._ctrl_pinned = torch.empty(64, dtype=torch.uint8, pin_memory=True)
+    basis._H_pinned.copy_(basis.H, non_blocking=True)
+    basis._ctrl_pinned.copy_(ws.buf[:64], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+
+    def wait():
+        ev.synchronize()
+        return basis._H_pinned.numpy(), _hip.Ctrl.from_buffer_copy(basis._ctrl_pinned.numpy().tobytes())
+
+    return wait

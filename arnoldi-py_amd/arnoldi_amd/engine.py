@@ -163,24 +163,43 @@ class ArnoldiContext:
         self.force_chained = False  # run the Python-chained stage path even on one GPU (tests, bench)
         self.use_graph = os.environ.get("AKS_GRAPH", "0") == "1"   # hipGraph replay of re-expansions (opt-in)
         self._graphs = {}
+        # look-ahead operator application (see expand): off with AKS_LOOKAHEAD=0
+        self.allow_lookahead = os.environ.get("AKS_LOOKAHEAD", "1") != "0"
+        self._look = None           # scratch column holding A V[:, end] of the last expansion
+        self._look_valid = False
+        self.lookahead_applies = 0  # operator applications issued ahead of time (the last one of a solve is unused)
 
     # -- seam 1 ------------------------------------------------------------------
-    def expand(self, H, start, end, tol, eta=dev.ETA_DGKS):
+    def expand(self, H, start, end, tol, eta=dev.ETA_DGKS, *, lookahead=False, consume_lookahead=False):
         """Run Arnoldi steps j = start..end-1 on the device, then mirror the new columns
         of H into the host array exactly as the reference's in-place writes would.
-        Returns n_iter (== end unless a step broke down)."""
+        Returns n_iter (== end unless a step broke down).
+
+        ``lookahead``: after the last step, also queue ``A V[:, end]`` into a scratch column.  H and the
+        control block are copied back *before* it in stream order, so the host gets them while that SpMV
+        (and its ghost exchange) still runs: the Krylov-Schur driver's host Schur step then overlaps
+        device work instead of leaving the GPU idle.  ``consume_lookahead``: the caller guarantees that
+        ``V[:, start]`` now holds the vector the look-ahead was applied to (Krylov-Schur:
+        ``V[:, p] = V[:, m]``), so the first step starts from the stored product.  Results are identical
+        with and without (same kernels, same operands)."""
         b, ws, op = self.basis, self.ws, self.op
         # The reference's arnoldi_decomposition keeps no state between calls: a breakdown in the
         # last step of one expansion (n_iter == max_dim, accepted by the driver) must not turn the
         # next expansion into a no-op.  Clear the control block's (broken, n_iter) words.
         ws.buf[:8].zero_()
+        w_ready = bool(consume_lookahead and self._look_valid and end > start)
+        self._look_valid = False
+        if w_ready:
+            b.V[start + 1].copy_(self._look.V[0])       # device-to-device, stream-ordered
         native = (isinstance(op, CsrOperator) and (op.comm is None or not op.comm.active)
                   and not self.force_chained)
         if native:
             d = op.diag
 
             def enqueue():
-                rc = _hip.load().aks_arnoldi_expand(
+                lib = _hip.load()
+                fn = lib.aks_arnoldi_expand_from_w if w_ready else lib.aks_arnoldi_expand
+                rc = fn(
                     b.n_rows, dev._ptr(d.indptr), dev._ptr(d.indices), dev._ptr(d.values), d.values_complex,
                     dev._ptr(d.tiles), d.n_tiles, d.lanes_per_row,
                     C.byref(d.binned.desc) if d.use_binned else None, dev._ptr(b.V), b.ldv, dev._ptr(b.H),
@@ -193,7 +212,7 @@ class ArnoldiContext:
             # captured once into a hipGraph and replayed: one host call per restart instead of
             # ~10 launches per Arnoldi step (opt-in: AKS_GRAPH=1; pays off when the host is slow
             # relative to the kernels).  Not used while a probe records per-kernel events.
-            key = (start, end, float(tol), float(eta))
+            key = (start, end, float(tol), float(eta), w_ready)
             if self.use_graph and self.probe is None and start > 0:
                 g = self._graphs.get(key)
                 if g is None:
@@ -220,7 +239,9 @@ class ArnoldiContext:
                     J = j + 1
                     x = vbase + stride * j if raw else b.col(j)
                     w = vbase + stride * J if raw else b.col(J)
-                    if self.spmv_events is not None:   # bench.py: device time of the sharded SpMV
+                    if w_ready and j == start:
+                        pass                           # w = A V[:, start] was applied ahead of time
+                    elif self.spmv_events is not None:   # bench.py: device time of the sharded SpMV
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
                         op.apply(x, w, ws)
@@ -238,8 +259,16 @@ class ArnoldiContext:
                     dev.gs_update_norm(b, J, w, ws, eta)
                     self.comm.allreduce_sum_(ws.red(3, 1))
                     dev.gs_finish(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
-        Hd = b.download_H()
-        ctrl = ws.read_ctrl()
+        fetch = dev.fetch_H_and_ctrl(b, ws)                 # queued before the look-ahead, waited for after it
+        if lookahead and self.allow_lookahead and isinstance(op, CsrOperator) and end > start:
+            if self._look is None:
+                self._look = dev.DeviceColumns(b.n_rows, 1, b.device)
+            op.apply(b.col(end), self._look.col(0), ws)     # a no-op on the device if a step broke down
+            self.lookahead_applies += 1
+            self._look_valid = True
+        Hd, ctrl = fetch()
+        if ctrl.broken:
+            self._look_valid = False
         n_iter = int(ctrl.n_iter) if ctrl.broken else end
         self.matvecs += n_iter - start
         for j in range(start, n_iter):

@@ -41,7 +41,7 @@ class KrylovSchurSolver:
 
     def start(self):
         """Initial m-step expansion (krylov_schur.py:51-54)."""
-        self.m = self.ctx.expand(self.H, 0, self.max_dim, self.tol)
+        self.m = self.ctx.expand(self.H, 0, self.max_dim, self.tol, lookahead=True)
         return self.m
 
     def contract(self, restart):
@@ -76,8 +76,10 @@ class KrylovSchurSolver:
         return bool(np.all(estimate[:nev] < self.tol))               # krylov_schur.py:99
 
     def expand(self):
-        """Re-expansion from p to max_dim (krylov_schur.py:103-106)."""
-        self.m = self.ctx.expand(self.H, self.p, self.max_dim, self.tol)
+        """Re-expansion from p to max_dim (krylov_schur.py:103-106).  Its first product
+        ``A V[:, p]`` (= ``A V[:, m]`` of the previous cycle, ``contract`` copies that column) was
+        queued at the end of the previous expansion and ran while the host did the Schur step."""
+        self.m = self.ctx.expand(self.H, self.p, self.max_dim, self.tol, lookahead=True, consume_lookahead=True)
         return self.m
 
     def true_residuals(self):
@@ -150,6 +152,7 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
         ctx = solver.ctx
         stats.update(restarts=solver.restarts_run, matvecs=ctx.matvecs,
                      second_passes=int(ctx.last_ctrl.second_passes), solver=solver,
+                     lookahead_applies=ctx.lookahead_applies,
                      tol=float(tol), max_dim=int(max_dim), p=int(p))
     if not converged:
         raise ValueError("Has not converged !")                      # krylov_schur.py:108-109

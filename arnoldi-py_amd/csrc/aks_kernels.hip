@@ -1210,11 +1210,11 @@ int aks_pb_spmv(const aks_pb_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int3
     return AKS_OK;
 }
 
-int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const void *d_values,
+static int expand_impl(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const void *d_values,
                        int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row,
                        const aks_pb_matrix *pb, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
                        int32_t start_dim, int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
-                       int32_t max_dim, void *probe, void *stream) {
+                       int32_t max_dim, void *probe, void *stream, bool first_w_ready) {
     if (start_dim < 0 || end_dim > max_dim || start_dim > end_dim)
         return fail(AKS_ERR_ARG, "need 0 <= start_dim <= end_dim <= max_dim");
     if (d_V == nullptr || d_H == nullptr) return fail(AKS_ERR_ARG, "null pointer");
@@ -1226,19 +1226,41 @@ int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d
     for (int32_t j = start_dim; j < end_dim; ++j) {
         aks_c128 *x = d_V + (int64_t)j * ldv;
         aks_c128 *w = d_V + (int64_t)(j + 1) * ldv;
-        hipEvent_t done = pr ? pr->begin(AKS_PROBE_SPMV, s) : nullptr;
-        int rc = pb != nullptr
+        hipEvent_t done = nullptr;
+        int rc = AKS_OK;
+        if (!(first_w_ready && j == start_dim)) {
+            done = pr ? pr->begin(AKS_PROBE_SPMV, s) : nullptr;
+            rc = pb != nullptr
                      ? aks_pb_spmv(pb, x, w, 0, d_ws, stream)
                      : aks_csr_spmv(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
                                     lanes_per_row, x, w, 0, d_ws, stream);
-        if (done) (void)hipEventRecord(done, s);
-        if (rc != AKS_OK) return rc;
+            if (done) (void)hipEventRecord(done, s);
+            if (rc != AKS_OK) return rc;
+        }
         done = pr ? pr->begin(AKS_PROBE_ORTHO, s) : nullptr;
         rc = aks_dgks_gs(n_rows, j + 1, d_V, ldv, w, d_H + j, ldh, tol, eta, 1, d_ws, ws_bytes, max_dim, stream);
         if (done) (void)hipEventRecord(done, s);
         if (rc != AKS_OK) return rc;
     }
     return AKS_OK;
+}
+
+int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const void *d_values,
+                       int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row,
+                       const aks_pb_matrix *pb, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
+                       int32_t start_dim, int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
+                       int32_t max_dim, void *probe, void *stream) {
+    return expand_impl(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles, lanes_per_row, pb,
+                       d_V, ldv, d_H, ldh, start_dim, end_dim, tol, eta, d_ws, ws_bytes, max_dim, probe, stream, false);
+}
+
+int aks_arnoldi_expand_from_w(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
+                              const void *d_values, int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles,
+                              int32_t lanes_per_row, const aks_pb_matrix *pb, aks_c128 *d_V, int64_t ldv,
+                              aks_c128 *d_H, int64_t ldh, int32_t start_dim, int32_t end_dim, double tol, double eta,
+                              void *d_ws, int64_t ws_bytes, int32_t max_dim, void *probe, void *stream) {
+    return expand_impl(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles, lanes_per_row, pb,
+                       d_V, ldv, d_H, ldh, start_dim, end_dim, tol, eta, d_ws, ws_bytes, max_dim, probe, stream, true);
 }
 
 int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv, const aks_c128 *d_Qp,

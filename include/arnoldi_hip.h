@@ -196,6 +196,16 @@ int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d
                        int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
                        int32_t max_dim, void *probe, void *stream);
 
+/* The same, for a caller that applied the operator to V[:, start_dim] ahead of time (e.g. while the
+ * host was busy with the restart's Schur step): V[:, start_dim+1] must already hold A V[:, start_dim];
+ * the first step then starts at the orthogonalisation.  Identical results to aks_arnoldi_expand. */
+int aks_arnoldi_expand_from_w(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
+                              const void *d_values, int32_t values_complex, const int32_t *d_tiles,
+                              int64_t n_tiles, int32_t lanes_per_row, const aks_pb_matrix *pb,
+                              aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh, int32_t start_dim,
+                              int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
+                              int32_t max_dim, void *probe, void *stream);
+
 /* ---- restart compression: replaces krylov_schur.py:78 and :81 --------------
  * V[:, :p] = V[:, :m] @ Qp   (in place: a wave reads all m columns of its 64 rows before it
  * overwrites any; f64 MFMA)   and   V[:, p] = V[:, m].   d_Qp is m x p complex128, row-major

@@ -169,13 +169,18 @@ class FakeHip:
         self.aks_gs_update_norm(n, J, V, ldv, w, eta, ws, ws_bytes, max_dim, stream)
         return self.aks_gs_finish(n, J, w, Hcol, ldh, tol, eta, normalize, ws, ws_bytes, max_dim, stream)
 
+    def aks_arnoldi_expand_from_w(self, *args):
+        return self.aks_arnoldi_expand(*args, first_w_ready=True)
+
     def aks_arnoldi_expand(self, n, indptr, indices, values, cplx, tiles, n_tiles, lpr, pb, V, ldv, H, ldh,
-                           start, end, tol, eta, ws, ws_bytes, max_dim, probe, stream):
-        self.calls.append("expand")
+                           start, end, tol, eta, ws, ws_bytes, max_dim, probe, stream, first_w_ready=False):
+        self.calls.append("expand_from_w" if first_w_ready else "expand")
         for j in range(start, end):
             x = _addr(V) + 16 * ldv * j
             w = _addr(V) + 16 * ldv * (j + 1)
-            if pb is not None:
+            if first_w_ready and j == start:
+                pass
+            elif pb is not None:
                 self.aks_pb_spmv(pb, x, w, 0, ws, stream)
             else:
                 self.aks_csr_spmv(n, indptr, indices, values, cplx, tiles, n_tiles, lpr, x, w, 0, ws, stream)

@@ -626,3 +626,23 @@ def test_c_abi_from_plain_c():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "|A V - V H|" in r.stdout
+
+
+def test_lookahead_is_bitwise_neutral(amd, monkeypatch):
+    """AKS_LOOKAHEAD=1 (default: A V[:, m] queued behind the copy of H, consumed by
+    aks_arnoldi_expand_from_w) and =0 run the same kernels on the same operands: identical bits."""
+    from arnoldi_amd import matrices
+
+    A = matrices.random_csr(300_000, 5, 1234, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5))
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("AKS_LOOKAHEAD", flag)
+        np.random.seed(0)
+        st = {}
+        Q, T, h = amd.partial_schur(A, 5, max_dim=20, stats=st)
+        res[flag] = (Q, T, h.restarts.copy(), st["lookahead_applies"], st["matvecs"])
+    assert res["1"][3] == int(res["1"][2].max()) and res["0"][3] == 0     # one per expansion, none when off
+    np.testing.assert_array_equal(res["1"][0], res["0"][0])
+    np.testing.assert_array_equal(res["1"][1], res["0"][1])
+    np.testing.assert_array_equal(res["1"][2], res["0"][2])
+    assert res["1"][4] == res["0"][4]

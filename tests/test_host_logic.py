@@ -479,3 +479,29 @@ def test_explicit_restarts_reference_tests_host_logic(fake):
     import explicit_cases as ec
 
     ec.check_deflation_reference_tests()
+
+
+def test_lookahead_application_is_used_and_changes_nothing(fake, monkeypatch):
+    """The Krylov-Schur driver queues A V[:, m] behind the copy of H (engine.ArnoldiContext.expand) and
+    starts the next expansion from it (aks_arnoldi_expand_from_w): same iterates as without."""
+    import arnoldi_amd
+    from arnoldi_amd import matrices
+    from arnoldi_amd.utils import arg_largest_real
+
+    A = matrices.mark(20)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("AKS_LOOKAHEAD", flag)
+        fake.calls.clear()
+        np.random.seed(3)
+        st = {}
+        Q, T, h = arnoldi_amd.partial_schur(A, 3, max_dim=12, stopping_criterion=1e-9, sort_function=arg_largest_real,
+                                            stats=st)
+        out[flag] = (Q, T, h.restarts.copy(), st["matvecs"], st["lookahead_applies"], list(fake.calls))
+    on, off = out["1"], out["0"]
+    assert "expand_from_w" in on[5] and "expand_from_w" not in off[5]
+    assert on[4] == int(on[2].max()) and off[4] == 0     # one per expansion; none when switched off
+    np.testing.assert_array_equal(on[0], off[0])
+    np.testing.assert_array_equal(on[1], off[1])
+    np.testing.assert_array_equal(on[2], off[2])
+    assert on[3] == off[3]                      # Arnoldi steps consumed, not speculative applications
