@@ -33,7 +33,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CONFIG_OF = {"random": 5, "laplace2d": 2, "laplace3d": 4, "markov": 1}   # BASELINE.json configs[] (1-based)
+CONFIG_OF = {"random": 5, "laplace2d": 2, "laplace3d": 4, "markov": 1, "banded": 3}   # BASELINE.json configs[] (1-based)
 
 
 def parse_args():
@@ -47,9 +47,12 @@ def parse_args():
     ap.add_argument("--per-row", type=int, default=5)
     ap.add_argument("--nev", type=int, default=5)
     ap.add_argument("--max-dim", type=int, default=20)
-    ap.add_argument("--workload", choices=["random", "laplace2d", "laplace3d", "markov"], default="random",
+    ap.add_argument("--workload", choices=["random", "laplace2d", "laplace3d", "markov", "banded"],
+                    default="random",
                     help="random = BASELINE config 5 (default); laplace2d / laplace3d = configs 2 / 4; "
-                         "markov = mark(M) of the reference's README scaled to ~n rows (sorted LR)")
+                         "markov = mark(M) of the reference's README scaled to ~n rows (sorted LR); "
+                         "banded = stand-in for config 3 (af_shell10 is not available offline): use "
+                         "--n 1500000 --per-row 35 --nev 20 --max-dim 41")
     ap.add_argument("--cpu-sample-n", type=int, default=1_000_000)
     ap.add_argument("--cpu-restarts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -73,6 +76,8 @@ def build_rows(args, r0, r1, n, dims):
 
     if args.workload == "random":
         return matrices.random_csr(n, args.per_row, 1234, row_range=(r0, r1))
+    if args.workload == "banded":
+        return matrices.banded_csr(n, args.per_row, 1234)[r0:r1]
     if args.workload == "markov":
         rows = matrices.mark(dims[0])[r0:r1]      # every rank builds the chain and keeps its rows
     else:
@@ -100,6 +105,9 @@ def cpu_baseline(args, n_full):
     if args.workload == "random":
         A = matrices.random_csr(ns, args.per_row, 1234)
         what = f"random CSR n={ns} ({args.per_row}/row, same generator)"
+    elif args.workload == "banded":
+        A = matrices.banded_csr(ns, args.per_row, 1234)
+        what = f"banded CSR n={ns} ({args.per_row}/row, same generator)"
     elif args.workload == "markov":
         mm = grid_dims("markov", ns)[0]
         A = matrices.mark(mm)
@@ -199,7 +207,7 @@ def main():
         comm = Comm(force=True)
 
     n, dims = args.n, None
-    if args.workload != "random":
+    if args.workload not in ("random", "banded"):
         dims = grid_dims(args.workload, args.n)      # computed ONCE: n below is the grid's row count
         n = dims[0] * (dims[0] + 1) // 2 if args.workload == "markov" else int(np.prod(dims))
     offsets = row_offsets(n, world)
