@@ -75,6 +75,25 @@ class KrylovSchurSolver:
         self.estimate = estimate[:nev]
         return bool(np.all(estimate[:nev] < self.tol))               # krylov_schur.py:99
 
+    def contract_invariant(self, restart):
+        """Happy breakdown (the expansion stopped at ``m < max_dim`` because ``A V_m = V_m H_m`` holds
+        to the invariance tolerance): the eigenvalues of ``H[:m, :m]`` are eigenvalues of A.  Rotate the
+        wanted ``nev`` Schur vectors to the front and stop -- the reference has this as a TODO
+        (krylov_schur.py:57-59); only reached with ``on_breakdown="deflate"``."""
+        H, m, nev = self.H, self.m, self.nev
+        if m < nev:
+            raise ValueError(f"Happy breakdown: invariant subspace of dimension {m} < nev = {nev}")
+        T, Q = scipy.linalg.schur(H[:m, :m], output="complex")
+        T, Q = reorder_schur(T, Q, self.sort_function(np.diag(T)))
+        self.ctx.truncate(Q[:, :nev], m, nev)
+        H[:nev, :nev] = T[:nev, :nev]
+        H[nev:, :nev] = 0
+        self.history.matvecs[:] = restart * (self.max_dim - nev) + (m - nev)
+        self.history.restarts[:] = restart + 1
+        self.restarts_run = restart + 1
+        self.estimate = np.zeros(nev)
+        return True
+
     def expand(self):
         """Re-expansion from p to max_dim (krylov_schur.py:103-106).  Its first product
         ``A V[:, p]`` (= ``A V[:, m]`` of the previous cycle, ``contract`` copies that column) was
@@ -98,7 +117,7 @@ class KrylovSchurSolver:
 
 def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts=100,
                   sort_function=None, p=None, v0=None, comm=None, device=None, gather=True,
-                  stats=None):
+                  stats=None, on_breakdown="raise"):
     """Compute ``nev`` Schur vectors ``Q`` and the ``nev x nev`` upper-triangular ``T``
     with ``A Q ~= Q T`` by the Krylov-Schur algorithm.
 
@@ -112,6 +131,9 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
     device  torch device of this rank's GPU (default: current device).
     gather  multi-GPU only: return the full ``Q`` on every rank (True) or just this
             rank's rows (False).
+    on_breakdown  "raise" (default, the reference's behaviour) or "deflate": when the Arnoldi expansion
+            stops early because the Krylov space is A-invariant, return the ``nev`` wanted Schur
+            vectors of that space instead of raising.
     stats   optional dict that receives ``restarts``, ``matvecs`` (true operator
             applications), ``second_passes`` and the solver object.
 
@@ -133,6 +155,7 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
     if p is None:
         p = min(nev + 5, max_dim - 1)               # size of the basis kept at a restart
     assert nev <= p < max_dim
+    assert on_breakdown in ("raise", "deflate")
 
     if comm is None:
         comm = default_comm()
@@ -142,7 +165,10 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
     solver.start()
     for restart in range(max_restarts):
         if solver.m != max_dim:
-            raise ValueError("Happy breakdown not supported yet")   # krylov_schur.py:57-59
+            if on_breakdown != "deflate":
+                raise ValueError("Happy breakdown not supported yet")   # krylov_schur.py:57-59
+            converged = solver.contract_invariant(restart)
+            break
         converged = solver.contract(restart)
         if converged:
             break

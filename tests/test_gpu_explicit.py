@@ -185,3 +185,7 @@ def test_deflation_full_size_planted(amd):
     assert np.all(res / np.abs(vals) < 1e-6), res
     assert vecs.shape == (n, 3)
     np.testing.assert_allclose(np.linalg.norm(vecs, axis=0), 1.0, rtol=1e-8)
+
+
+def test_happy_breakdown_deflate(amd):
+    ec.check_happy_breakdown_deflate()

@@ -633,7 +633,9 @@ def test_lookahead_is_bitwise_neutral(amd, monkeypatch):
     aks_arnoldi_expand_from_w) and =0 run the same kernels on the same operands: identical bits."""
     from arnoldi_amd import matrices
 
-    A = matrices.random_csr(300_000, 5, 1234, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5))
+    from arnoldi_amd.engine import CsrOperator
+
+    A = CsrOperator(matrices.random_csr(300_000, 5, 1234, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5)))  # one SpMV form
     res = {}
     for flag in ("1", "0"):
         monkeypatch.setenv("AKS_LOOKAHEAD", flag)

@@ -505,3 +505,9 @@ def test_lookahead_application_is_used_and_changes_nothing(fake, monkeypatch):
     np.testing.assert_array_equal(on[1], off[1])
     np.testing.assert_array_equal(on[2], off[2])
     assert on[3] == off[3]                      # Arnoldi steps consumed, not speculative applications
+
+
+def test_happy_breakdown_deflate_host_logic(fake):
+    import explicit_cases as ec
+
+    ec.check_happy_breakdown_deflate()
