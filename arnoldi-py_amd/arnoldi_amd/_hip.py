@@ -48,7 +48,9 @@ class Ctrl(C.Structure):
         ("second_passes", C.c_int32),
         ("beta_in", C.c_double),
         ("beta", C.c_double),
-        ("reserved", C.c_double * 4),
+        ("real_mode", C.c_int32),
+        ("reserved_i", C.c_int32),
+        ("reserved", C.c_double * 3),
     ]
 
 
@@ -58,6 +60,7 @@ _I32, _I64, _F64 = C.c_int32, C.c_int64, C.c_double
 PB_SLAB_BITS = 16       # AKS_PB_SLAB_BITS
 PB_ROWBLOCK_BITS = 10   # AKS_PB_ROWBLOCK_BITS
 PB_CHUNK_NNZ = 2048     # AKS_PB_CHUNK_NNZ
+EXPAND_FROM_W, EXPAND_REAL_PACKED = 1, 2   # AKS_EXPAND_* flags of aks_arnoldi_expand_ex
 
 
 class PbMatrix(C.Structure):
@@ -91,6 +94,12 @@ SIGNATURES = {
                                      _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P]),
     "aks_arnoldi_expand_from_w": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, C.POINTER(PbMatrix), _P, _I64,
                                             _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P]),
+    "aks_arnoldi_expand_ex": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, C.POINTER(PbMatrix), _P, _I64,
+                                        _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P, _I32]),
+    "aks_workspace_set_real": (C.c_int, [_P, _I32, _P]),
+    "aks_csr_spmv_real": (C.c_int, [_I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _P]),
+    "aks_pb_spmv_real": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),
+    "aks_gather_f64": (C.c_int, [_I64, _P, _P, _P, _P]),
     "aks_truncate": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P]),
     "aks_combine": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P, _I64, _P]),
     "aks_scale": (C.c_int, [_I64, _P, _F64, _F64, _P]),

@@ -124,10 +124,11 @@ class DeviceCSR:
         self.binned = None        # BinnedCSR once built
         self.use_binned = False   # which form spmv() / aks_arnoldi_expand use
 
-    def algorithmic_bytes(self):
-        """12 nnz + 36 n + 4 (f64 values) or 20 nnz + 36 n + 4 (c128 values)."""
+    def algorithmic_bytes(self, real=False):
+        """12 nnz + 36 n + 4 (f64 values) or 20 nnz + 36 n + 4 (c128 values); with real
+        vectors x and y are 8 bytes per row: 12 nnz + 20 n + 4."""
         per_nnz = 20 if self.values_complex else 12
-        return per_nnz * self.nnz + 36 * self.n_rows + 4
+        return per_nnz * self.nnz + (20 if real else 36) * self.n_rows + 4
 
     # -- choice of SpMV form ------------------------------------------------------------------
     def scatter_ratio(self, sample_windows=64):
@@ -152,10 +153,11 @@ class DeviceCSR:
             self.binned = BinnedCSR(self._host, self.device)
         return self.binned
 
-    def autotune(self, min_nnz=2_000_000, reps=3, force=None):
+    def autotune(self, min_nnz=2_000_000, reps=3, force=None, real=False):
         """Pick the CSR-stream or the slab-binned SpMV by timing both on this device.
         Only matrices that are large and scattered enough to miss L2 are candidates.
-        ``force`` = "csr" | "binned" skips the measurement.  Frees the host copy."""
+        ``force`` = "csr" | "binned" skips the measurement.  Frees the host copy.
+        ``real``: time the real-vector kernels (real-packed mode)."""
         choice = force
         if choice is None:
             candidate = self.nnz >= min_nnz and self.n_cols * 16 > (4 << 20) and self.scatter_ratio() > 0.5
@@ -168,11 +170,11 @@ class DeviceCSR:
             times = {}
             for form in ("csr", "binned"):
                 self.use_binned = form == "binned"
-                self.spmv(x, y)
+                self.spmv(x, y, real=real)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
-                    self.spmv(x, y)
+                    self.spmv(x, y, real=real)
                 e1.record()
                 torch.cuda.synchronize()
                 times[form] = e0.elapsed_time(e1) / reps
@@ -186,11 +188,26 @@ class DeviceCSR:
         self._host = None
         return choice
 
-    def spmv(self, x, y, accumulate=False, ws=None):
-        """y (=|+=) A x on the current stream; x, y are complex128 device tensors."""
+    def spmv(self, x, y, accumulate=False, ws=None, real=False):
+        """y (=|+=) A x on the current stream; x, y are complex128 device tensors -- or, with ``real``,
+        real vectors (float64 tensors, or real-packed complex128 columns: two rows per slot)."""
         for t, need in ((x, self.n_cols), (y, self.n_rows)):   # raw addresses (hot loop) skip the checks
             if not isinstance(t, int):
-                assert t.dtype == torch.complex128 and t.numel() >= need and t.is_contiguous()
+                have = t.numel() * (2 if (real and t.dtype == torch.complex128) else 1)
+                assert t.dtype == torch.complex128 or (real and t.dtype == torch.float64)
+                assert have >= need and t.is_contiguous()
+        wsp = _ptr(ws.buf) if ws is not None else C.c_void_p(0)
+        if real:
+            assert not self.values_complex, "real vectors need real matrix values"
+            if self.use_binned:
+                rc = _hip.load().aks_pb_spmv_real(C.byref(self.binned.desc), _ptr(x), _ptr(y), int(accumulate),
+                                                  wsp, _stream())
+            else:
+                rc = _hip.load().aks_csr_spmv_real(
+                    self.n_rows, _ptr(self.indptr), _ptr(self.indices), _ptr(self.values), _ptr(self.tiles),
+                    self.n_tiles, self.lanes_per_row, _ptr(x), _ptr(y), int(accumulate), wsp, _stream())
+            _hip.check(rc, "aks_*_spmv_real")
+            return
         if self.use_binned:
             rc = _hip.load().aks_pb_spmv(C.byref(self.binned.desc), _ptr(x), _ptr(y), int(accumulate),
                                          _ptr(ws.buf) if ws is not None else C.c_void_p(0), _stream())
@@ -259,9 +276,10 @@ class BinnedCSR:
 class Workspace:
     """Device scratch for the reductions + the control block (``aks_ws_layout``)."""
 
-    def __init__(self, n_rows, max_dim, device=None):
+    def __init__(self, n_rows, max_dim, device=None, real=False):
         device = _require_gpu(device)
         self.n_rows, self.max_dim = int(n_rows), int(max_dim)
+        self.real = bool(real)      # real-packed panels: reductions drop the imaginary parts
         self.layout = _hip.workspace_layout(self.n_rows, self.max_dim)
         self.nbytes = int(self.layout.total_bytes)
         self._raw = torch.empty(self.nbytes + 256, dtype=torch.uint8, device=device)
@@ -274,6 +292,8 @@ class Workspace:
     def reset(self):
         rc = _hip.load().aks_workspace_init(_ptr(self.buf), self.nbytes, self.n_rows, self.max_dim, _stream())
         _hip.check(rc, "aks_workspace_init")
+        if self.real:
+            _hip.check(_hip.load().aks_workspace_set_real(_ptr(self.buf), 1, _stream()), "aks_workspace_set_real")
 
     def _slot(self, off, n_c128):
         return self.buf[off: off + 16 * n_c128].view(torch.float64)
@@ -300,9 +320,14 @@ class KrylovBasis:
     Mirrors the work arrays of src/arnoldi/krylov_schur.py:42-43.  ``V[j]`` is column j.
     """
 
-    def __init__(self, n_rows, max_dim, device=None):
+    def __init__(self, n_rows, max_dim, device=None, real=False):
+        """``real``: real-packed basis -- ``n_rows`` real rows are stored two per complex slot, so the
+        panel the kernels see has ``self.n_rows = ceil(n_rows / 2)`` rows (``self.n_real`` keeps the
+        vector length).  Host vectors go in and come out as float64."""
         device = _require_gpu(device)
-        self.n_rows, self.max_dim = int(n_rows), int(max_dim)
+        self.real = bool(real)
+        self.n_real = int(n_rows)
+        self.n_rows, self.max_dim = ((int(n_rows) + 1) // 2 if real else int(n_rows)), int(max_dim)
         self.ldv = (self.n_rows + 63) // 64 * 64
         self.V = torch.zeros((self.max_dim + 1, self.ldv), dtype=torch.complex128, device=device)
         self.H = torch.zeros((self.max_dim + 1, self.max_dim), dtype=torch.complex128, device=device)
@@ -311,18 +336,31 @@ class KrylovBasis:
     def col(self, j):
         return self.V[j]
 
+    def _pack(self, host_cols_T):
+        """(k, n) host rows -> (k, n_rows) complex128 (real-packed: pairs of reals, zero tail)."""
+        if not self.real:
+            return np.ascontiguousarray(host_cols_T, dtype=C128)
+        a = np.asarray(host_cols_T)
+        assert not np.iscomplexobj(a) or not a.imag.any(), "real-packed basis takes real vectors"
+        buf = np.zeros((a.shape[0], 2 * self.n_rows), np.float64)
+        buf[:, : self.n_real] = a.real
+        return buf.view(C128)
+
     def set_col(self, j, host_vec):
-        v = torch.from_numpy(np.ascontiguousarray(host_vec, dtype=C128))
+        v = torch.from_numpy(self._pack(np.asarray(host_vec).reshape(1, -1))[0])
         self.V[j, : self.n_rows].copy_(v)
 
     def get_cols(self, j0, j1):
-        """Host copy, shape (n, j1-j0), Fortran order (like the reference's V views)."""
+        """Host copy, shape (n, j1-j0), Fortran order (like the reference's V views); float64 for a
+        real-packed basis."""
         out = self.V[j0:j1, : self.n_rows].cpu().numpy()  # (cols, n) C-order == (n, cols) F-order
+        if self.real:
+            out = np.ascontiguousarray(out).view(np.float64)[:, : self.n_real]
         return out.T
 
     def set_cols(self, j0, host_cols):
-        a = np.ascontiguousarray(np.asarray(host_cols, dtype=C128).T)
-        self.V[j0: j0 + a.shape[0], : self.n_rows].copy_(torch.from_numpy(a))
+        a = self._pack(np.asarray(host_cols).T)
+        self.V[j0: j0 + a.shape[0], : self.n_rows].copy_(torch.from_numpy(np.ascontiguousarray(a)))
 
     def download_H(self):
         return self.H.cpu().numpy()
@@ -367,6 +405,11 @@ def truncate(basis, m, p, Qp_dev):
 def gather_c128(count, idx, src, dst):
     rc = _hip.load().aks_gather_c128(count, _ptr(idx), _ptr(src), _ptr(dst), _stream())
     _hip.check(rc, "aks_gather_c128")
+
+
+def gather_f64(count, idx, src, dst):
+    rc = _hip.load().aks_gather_f64(count, _ptr(idx), _ptr(src), _ptr(dst), _stream())
+    _hip.check(rc, "aks_gather_f64")
 
 
 def combine(n_rows, m, V, ldv, S_dev, out, ldo):

@@ -146,11 +146,11 @@ class Comm:
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(h)
 
-    def alltoallv_start(self, send, send_counts, recv, recv_counts):
-        """Start  recv <- all-to-all(send)  on float64 views (2 doubles per complex).
-        Returns a handle for ``alltoallv_finish``."""
-        ss = [2 * int(c) for c in send_counts]
-        rs = [2 * int(c) for c in recv_counts]
+    def alltoallv_start(self, send, send_counts, recv, recv_counts, words=2):
+        """Start  recv <- all-to-all(send)  on float64 views (``words`` doubles per vector entry: 2 for
+        complex128, 1 for real vectors).  Returns a handle for ``alltoallv_finish``."""
+        ss = [words * int(c) for c in send_counts]
+        rs = [words * int(c) for c in recv_counts]
         if self.backend == "nccl" or not send.is_cuda:
             return dist.all_to_all_single(recv, send, rs, ss, group=self.group, async_op=True)
         hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)

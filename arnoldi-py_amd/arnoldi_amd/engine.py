@@ -31,13 +31,16 @@ C128 = np.complex128
 class CsrOperator:
     """CSR operator resident in HBM, row-sharded over ``comm`` (or whole on one GPU)."""
 
-    def __init__(self, A=None, *, local_rows=None, offsets=None, comm=None, device=None, spmv_form=None):
+    def __init__(self, A=None, *, local_rows=None, offsets=None, comm=None, device=None, spmv_form=None,
+                 real=False):
         """``spmv_form``: None/"auto" (time the CSR-stream and the slab-binned kernels on large
         scattered matrices and keep the faster), "csr" or "binned".  Environment override:
-        AKS_SPMV_FORM."""
+        AKS_SPMV_FORM.  ``real``: the operator works on real vectors (real-packed Krylov basis):
+        real-vector SpMV kernels, float64 ghost exchange."""
         form = os.environ.get("AKS_SPMV_FORM", spmv_form or "auto")
         force = None if form == "auto" else form
         self.comm = comm
+        self.real = bool(real)
         world = comm.size if comm is not None else 1
         rank = comm.rank if comm is not None else 0
         if local_rows is not None:
@@ -54,18 +57,20 @@ class CsrOperator:
         self.r0, self.r1 = int(self.offsets[rank]), int(self.offsets[rank + 1])
         self.n_local = self.r1 - self.r0
         self.dtype = rows.dtype
+        if self.real and np.iscomplexobj(rows.data):
+            raise ValueError("real arithmetic needs a real matrix")
         if world == 1:
             self.diag = dev.DeviceCSR(rows, device)
-            self.spmv_form = self.diag.autotune(force=force)
+            self.spmv_form = self.diag.autotune(force=force, real=self.real)
             self.off = None
             self.n_ghost = 0
             return
         plan = split_local_rows(rows, self.offsets, rank)
         self.diag = dev.DeviceCSR(plan.diag, device)
         self.off = dev.DeviceCSR(plan.off, device) if plan.off is not None else None
-        self.spmv_form = self.diag.autotune(force=force)
+        self.spmv_form = self.diag.autotune(force=force, real=self.real)
         if self.off is not None:
-            self.off.autotune(force=force)
+            self.off.autotune(force=force, real=self.real)
         self.n_ghost = plan.n_ghost
         self.recv_counts = [int(c) for c in plan.recv_counts]
         asked = comm.exchange_requests(plan.ghost_cols, plan.recv_counts)
@@ -75,8 +80,9 @@ class CsrOperator:
         d = self.diag.device
         self.send_idx = torch.from_numpy(send_idx).to(d)
         self.n_send = int(send_idx.size)
-        self.sendbuf = torch.zeros(max(self.n_send, 1), dtype=torch.complex128, device=d)
-        self.ghostbuf = torch.zeros(max(self.n_ghost, 1), dtype=torch.complex128, device=d)
+        vec_dtype = torch.float64 if self.real else torch.complex128
+        self.sendbuf = torch.zeros(max(self.n_send, 1), dtype=vec_dtype, device=d)
+        self.ghostbuf = torch.zeros(max(self.n_ghost, 1), dtype=vec_dtype, device=d)
         self.any_exchange = bool(sum(comm.allgather_int64([self.n_send + self.n_ghost])[r][0]
                                      for r in range(world)))
 
@@ -89,22 +95,25 @@ class CsrOperator:
         return self.diag.nnz + (self.off.nnz if self.off is not None else 0)
 
     def algorithmic_bytes(self):
-        return self.diag.algorithmic_bytes() + (self.off.algorithmic_bytes() if self.off is not None else 0)
+        return (self.diag.algorithmic_bytes(self.real)
+                + (self.off.algorithmic_bytes(self.real) if self.off is not None else 0))
 
     def apply(self, x, y, ws=None):
-        """y = A x for this shard's rows; x, y are columns of V (local rows)."""
+        """y = A x for this shard's rows; x, y are columns of V (local rows; real-packed if ``real``)."""
+        real = self.real
         if self.comm is None or self.comm.size == 1 or not self.any_exchange:
-            self.diag.spmv(x, y, False, ws)
+            self.diag.spmv(x, y, False, ws, real)
             return
+        w = 1 if real else 2                     # float64 words per vector entry
         if self.n_send:
-            dev.gather_c128(self.n_send, self.send_idx, x, self.sendbuf)
+            (dev.gather_f64 if real else dev.gather_c128)(self.n_send, self.send_idx, x, self.sendbuf)
         handle = self.comm.alltoallv_start(
-            self.sendbuf.view(torch.float64)[: 2 * self.n_send], self.send_counts,
-            self.ghostbuf.view(torch.float64)[: 2 * self.n_ghost], self.recv_counts)
-        self.diag.spmv(x, y, False, ws)          # overlaps the exchange
+            self.sendbuf.view(torch.float64)[: w * self.n_send], self.send_counts,
+            self.ghostbuf.view(torch.float64)[: w * self.n_ghost], self.recv_counts, words=w)
+        self.diag.spmv(x, y, False, ws, real)    # overlaps the exchange
         self.comm.alltoallv_finish(handle)
         if self.off is not None:
-            self.off.spmv(self.ghostbuf, y, True, ws)
+            self.off.spmv(self.ghostbuf, y, True, ws, real)
 
 
 class HostOperator:
@@ -138,11 +147,19 @@ class NullOperator:
         raise TypeError("this context has no operator")
 
 
-def as_operator(A, comm=None, device=None):
-    if isinstance(A, (CsrOperator, HostOperator)):
+def as_operator(A, comm=None, device=None, real=False):
+    if isinstance(A, CsrOperator):
+        if A.real != bool(real):
+            raise ValueError("the CsrOperator was built for %s vectors" % ("real" if A.real else "complex"))
+        return A
+    if isinstance(A, HostOperator):
+        if real:
+            raise TypeError("real arithmetic needs a CSR operator")
         return A
     if dev.canonical_csr(A) is not None:
-        return CsrOperator(A, comm=comm, device=device)
+        return CsrOperator(A, comm=comm, device=device, real=real)
+    if real:
+        raise TypeError("real arithmetic needs a sparse/dense matrix, not an opaque operator")
     if comm is not None and comm.size > 1:
         raise TypeError("row-sharded solves need a sparse/dense matrix, not an opaque operator")
     return HostOperator(A, device)
@@ -155,8 +172,11 @@ class ArnoldiContext:
         self.op = op
         self.comm = op.comm
         self.max_dim = int(max_dim)
-        self.basis = dev.KrylovBasis(op.n_local, max_dim, device)
-        self.ws = dev.Workspace(op.n_local, max_dim, device)
+        # real-packed mode follows the operator: a real basis is stored two rows per complex slot and every
+        # panel kernel runs on basis.n_rows = ceil(n_local / 2) rows (include/arnoldi_hip.h, "real-packed")
+        self.real = bool(getattr(op, "real", False))
+        self.basis = dev.KrylovBasis(op.n_local, max_dim, device, real=self.real)
+        self.ws = dev.Workspace(self.basis.n_rows, max_dim, device, real=self.real)
         self.matvecs = 0
         self.probe = None   # optional _hip.Probe (bench.py): device time of SpMV / ortho launches
         self.spmv_events = None  # optional list (bench.py, Python-chained path): torch event pairs
@@ -196,16 +216,16 @@ class ArnoldiContext:
         if native:
             d = op.diag
 
+            flags = (_hip.EXPAND_FROM_W if w_ready else 0) | (_hip.EXPAND_REAL_PACKED if self.real else 0)
+
             def enqueue():
-                lib = _hip.load()
-                fn = lib.aks_arnoldi_expand_from_w if w_ready else lib.aks_arnoldi_expand
-                rc = fn(
-                    b.n_rows, dev._ptr(d.indptr), dev._ptr(d.indices), dev._ptr(d.values), d.values_complex,
+                rc = _hip.load().aks_arnoldi_expand_ex(
+                    op.n_local, dev._ptr(d.indptr), dev._ptr(d.indices), dev._ptr(d.values), d.values_complex,
                     dev._ptr(d.tiles), d.n_tiles, d.lanes_per_row,
                     C.byref(d.binned.desc) if d.use_binned else None, dev._ptr(b.V), b.ldv, dev._ptr(b.H),
                     self.max_dim, start, end, tol, eta, dev._ptr(ws.buf), ws.nbytes, ws.max_dim,
-                    self.probe.handle if self.probe is not None else C.c_void_p(0), dev._stream())
-                _hip.check(rc, "aks_arnoldi_expand")
+                    self.probe.handle if self.probe is not None else C.c_void_p(0), dev._stream(), flags)
+                _hip.check(rc, "aks_arnoldi_expand_ex")
 
             # The re-expansion (start = p) is the same launch sequence with the same arguments at
             # every restart (DGKS decisions and breakdown are taken on the device), so it can be
@@ -271,6 +291,8 @@ class ArnoldiContext:
             self._look_valid = False
         n_iter = int(ctrl.n_iter) if ctrl.broken else end
         self.matvecs += n_iter - start
+        if not np.iscomplexobj(H):
+            Hd = Hd.real                                  # real-packed mode: a real Hessenberg matrix
         for j in range(start, n_iter):
             rows = j + 1 if (ctrl.broken and j == n_iter - 1) else j + 2
             H[:rows, j] = Hd[:rows, j]

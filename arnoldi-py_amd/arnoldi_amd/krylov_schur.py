@@ -117,7 +117,7 @@ class KrylovSchurSolver:
 
 def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts=100,
                   sort_function=None, p=None, v0=None, comm=None, device=None, gather=True,
-                  stats=None, on_breakdown="raise"):
+                  stats=None, on_breakdown="raise", arithmetic="complex"):
     """Compute ``nev`` Schur vectors ``Q`` and the ``nev x nev`` upper-triangular ``T``
     with ``A Q ~= Q T`` by the Krylov-Schur algorithm.
 
@@ -134,6 +134,10 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
     on_breakdown  "raise" (default, the reference's behaviour) or "deflate": when the Arnoldi expansion
             stops early because the Krylov space is A-invariant, return the ``nev`` wanted Schur
             vectors of that space instead of raising.
+    arithmetic  "complex" (default: the reference's complex128 iteration, identical restart history) or
+            "real": for a real matrix and a real start vector, iterate in real arithmetic on a
+            real-packed basis (krylov_schur_real.py) -- half the memory traffic; same ``(Q, T)`` contract,
+            restart counts may differ from the reference's.
     stats   optional dict that receives ``restarts``, ``matvecs`` (true operator
             applications), ``second_passes`` and the solver object.
 
@@ -156,10 +160,20 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
         p = min(nev + 5, max_dim - 1)               # size of the basis kept at a restart
     assert nev <= p < max_dim
     assert on_breakdown in ("raise", "deflate")
+    assert arithmetic in ("complex", "real")
 
     if comm is None:
         comm = default_comm()
-    solver = KrylovSchurSolver(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)
+    if arithmetic == "real":
+        from .krylov_schur_real import RealKrylovSchurSolver
+
+        if np.issubdtype(np.dtype(A.dtype), np.complexfloating):
+            raise ValueError("arithmetic='real' needs a real matrix")
+        if on_breakdown != "raise":
+            raise ValueError("on_breakdown='deflate' is only implemented for arithmetic='complex'")
+        solver = RealKrylovSchurSolver(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)
+    else:
+        solver = KrylovSchurSolver(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)
 
     converged = False
     solver.start()
@@ -178,7 +192,7 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
         ctx = solver.ctx
         stats.update(restarts=solver.restarts_run, matvecs=ctx.matvecs,
                      second_passes=int(ctx.last_ctrl.second_passes), solver=solver,
-                     lookahead_applies=ctx.lookahead_applies,
+                     lookahead_applies=ctx.lookahead_applies, arithmetic=arithmetic,
                      tol=float(tol), max_dim=int(max_dim), p=int(p))
     if not converged:
         raise ValueError("Has not converged !")                      # krylov_schur.py:108-109

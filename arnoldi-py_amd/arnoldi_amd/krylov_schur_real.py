@@ -1,0 +1,171 @@
+"""Krylov-Schur in real arithmetic for real matrices -- the reference's "real arithmetic (real Schur,
+``dtrexc``)" TODO (README.md:112-119, utils.py:64-65), opt-in through
+``partial_schur(..., arithmetic="real")``.
+
+For a real matrix and a real start vector the Krylov basis is real.  The device keeps it *real-packed*
+(two rows per complex128 slot, include/arnoldi_hip.h) and runs the very same panel kernels on half the
+rows: half the HBM traffic of Gram-Schmidt and of the restart compression, 8-byte gathers and products
+in the SpMV, half the ghost-exchange volume between GPUs.  The host works with the real Schur form
+(``dgees`` + ``dtrexc``): 1x1 and 2x2 diagonal blocks; the restart size moves by one when it would cut
+a conjugate pair.  The result is converted to the reference's contract at the end
+(``scipy.linalg.rsf2csf``): unitary ``Q``, complex upper-triangular ``T`` with ``A Q = Q T``.
+
+This is a different (mathematically equivalent) iteration from the complex one: where the complex
+driver keeps exactly ``p`` Schur vectors -- possibly one member of a conjugate pair -- this one keeps the
+pair.  Restart counts can therefore differ from the reference's; eigenpairs and residuals agree to the
+stopping tolerance (tests/test_gpu_real.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+from scipy.linalg.lapack import dtrexc
+
+from .engine import ArnoldiContext, as_operator
+from .history import History
+from .utils import rand_normalized_vector
+
+
+def real_blocks(T):
+    """``[(start, size)]`` of the 1x1 / 2x2 diagonal blocks of a real quasi-triangular matrix."""
+    m = T.shape[0]
+    out, i = [], 0
+    while i < m:
+        size = 2 if (i + 1 < m and T[i + 1, i] != 0.0) else 1
+        out.append((i, size))
+        i += size
+    return out
+
+
+def block_eigenvalues(T, blocks=None):
+    """Eigenvalues of a real quasi-triangular matrix, one per diagonal position (a 2x2 block gives
+    ``a + ib`` at its first row and ``a - ib`` at its second)."""
+    ev = np.zeros(T.shape[0], dtype=np.complex128)
+    for s, size in (real_blocks(T) if blocks is None else blocks):
+        if size == 1:
+            ev[s] = T[s, s]
+        else:
+            lam = np.linalg.eigvals(T[s: s + 2, s: s + 2])
+            lam = lam[np.argsort(-lam.imag)]
+            if np.iscomplexobj(lam) and lam[0].imag != 0:
+                ev[s], ev[s + 1] = lam[0], lam[1]
+            else:                       # a block that is numerically two real eigenvalues
+                ev[s], ev[s + 1] = lam[0], lam[1]
+    return ev
+
+
+def reorder_real_schur(T, Z, sort_function):
+    """Reorder the diagonal blocks of the real Schur form ``(T, Z)`` with ``dtrexc`` so that they
+    follow ``sort_function`` (a full permutation of the eigenvalues, best first, as in
+    utils.arg_largest_*); a 2x2 block takes the better rank of its two members and moves as a unit."""
+    m = T.shape[0]
+    blocks = real_blocks(T)
+    ev = block_eigenvalues(T, blocks)
+    rank = np.empty(m, dtype=np.int64)
+    rank[np.asarray(sort_function(ev))] = np.arange(m)
+    keys = [int(rank[s: s + size].min()) for s, size in blocks]
+    sizes = [size for _, size in blocks]
+    wanted = sorted(range(len(blocks)), key=lambda b: keys[b])
+    current = list(range(len(blocks)))
+    T = np.asfortranarray(T)
+    Z = np.asfortranarray(Z)
+    for target, bid in enumerate(wanted):
+        src = current.index(bid)
+        if src == target:
+            continue
+        ifst = 1 + sum(sizes[b] for b in current[:src])
+        ilst = 1 + sum(sizes[b] for b in current[:target])
+        T, Z, info = dtrexc(T, Z, ifst, ilst)
+        if info < 0:
+            raise np.linalg.LinAlgError(f"dtrexc: illegal argument {-info}")
+        # info == 1: two blocks too close to swap (T is still a valid Schur form, partially reordered)
+        current.pop(src)
+        current.insert(target, bid)
+    return T, Z
+
+
+class RealKrylovSchurSolver:
+    """Same ``start`` / ``contract`` / ``expand`` / ``result`` protocol as ``KrylovSchurSolver``."""
+
+    def __init__(self, A, nev, max_dim, p, tol, sort_function, *, v0=None, comm=None, device=None):
+        n = A.shape[0]
+        self.n, self.nev, self.max_dim, self.p = n, nev, max_dim, p
+        self.tol, self.sort_function = tol, sort_function
+        self.op = as_operator(A, comm=comm, device=device, real=True)
+        self.ctx = ArnoldiContext(self.op, max_dim, device)
+        if v0 is None:
+            start = rand_normalized_vector(n)              # the reference's draw (its imaginary part is 0)
+        else:
+            start = np.asarray(v0)
+            if np.iscomplexobj(start):
+                if start.imag.any():
+                    raise ValueError("real arithmetic needs a real start vector")
+                start = start.real
+        assert start.shape == (n,)
+        self.ctx.set_start_vector(np.ascontiguousarray(start, dtype=np.float64))
+        self.H = np.zeros((max_dim + 1, max_dim), dtype=np.float64)
+        self.history = History.from_k(nev)
+        self.m = 0
+        self.p_now = p
+        self.nev_now = nev
+        self.restarts_run = 0
+
+    def start(self):
+        self.m = self.ctx.expand(self.H, 0, self.max_dim, self.tol, lookahead=True)
+        return self.m
+
+    def contract(self, restart):
+        H, m, nev = self.H, self.m, self.nev
+        T, Z = scipy.linalg.schur(H[:m, :m], output="real")
+        T, Z = reorder_real_schur(T, Z, self.sort_function)
+
+        def cut(k):                       # never cut a 2x2 block: move the boundary up (or down at the end)
+            if 0 < k < m and T[k, k - 1] != 0.0:
+                return k + 1 if k + 1 < m else k - 1
+            return k
+
+        nev_now = min(cut(nev), m - 1)
+        p = cut(self.p)
+        if p < nev_now:
+            p = nev_now
+        assert 1 <= p < m
+        self.ctx.truncate(Z[:, :p], m, p)                 # V[:, :p] = V[:, :m] Z_p ; V[:, p] = V[:, m]
+        last = H[m, m - 1]
+        coupling = last * Z[m - 1, :p]
+        H[:] = 0.0
+        H[:p, :p] = T[:p, :p]
+        H[p, :p] = coupling
+
+        ev = block_eigenvalues(T)
+        tail = np.abs(Z[m - 1, :])
+        for s, size in real_blocks(T):
+            if size == 2:                                 # both members of a pair share the block's residual
+                tail[s] = tail[s + 1] = np.hypot(Z[m - 1, s], Z[m - 1, s + 1])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            estimate = np.abs(last) * tail / np.abs(ev)
+        under = estimate[:nev] <= self.tol
+        self.history.matvecs[under] = self.ctx.matvecs
+        self.history.restarts[under] = restart + 1
+        self.restarts_run = restart + 1
+        self.estimate = estimate[:nev_now]
+        self.p_now, self.nev_now = p, nev_now
+        return bool(np.all(estimate[:nev_now] < self.tol))
+
+    def expand(self):
+        self.m = self.ctx.expand(self.H, self.p_now, self.max_dim, self.tol, lookahead=True,
+                                 consume_lookahead=True)
+        return self.m
+
+    def result(self, gather=True):
+        """``(Q, T, history)`` in the reference's form: the real partial Schur pair (``nev`` columns, one
+        more if that completes a conjugate pair) is rotated to complex upper-triangular form on the host
+        (an O(n nev^2) product) and cut back to ``nev`` columns."""
+        k = self.nev_now
+        comm = self.ctx.comm
+        if comm is not None and comm.size > 1 and not gather:
+            Qr = np.asfortranarray(self.ctx.local_columns(0, k))
+        else:
+            Qr = self.ctx.gather_columns(0, k)
+        Tc, U = scipy.linalg.rsf2csf(self.H[:k, :k].copy(), np.eye(k))
+        Q = Qr @ U
+        return np.asfortranarray(Q[:, : self.nev]), np.array(Tc[: self.nev, : self.nev]), self.history

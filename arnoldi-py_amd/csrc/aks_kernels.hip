@@ -403,7 +403,9 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const c128 *__restrict__ parti
     }
     sr = block_sum(sr, sc);
     si = block_sum(si, sc);
-    if (threadIdx.x == 0) out[c] = make_double2(sr, si);
+    // real-packed mode (aks_workspace_set_real): the panel holds REAL vectors, two rows per complex slot;
+    // Re(V^H w) is the real dot product and the coefficients used downstream must be real
+    if (threadIdx.x == 0) out[c] = make_double2(sr, ctrl->real_mode ? 0.0 : si);
 }
 
 // ------------------------------------------------------------------ finish
@@ -533,6 +535,64 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *
             }
             y[r0] = make_double2(sr, si);
         }
+    }
+}
+
+// Real vectors (real-packed mode): x, y are float64 arrays, values float64.  Same tiling as k_spmv;
+// gathers are 8 bytes, one LDS plane.
+template <bool ACC>
+__global__ __launch_bounds__(BLOCK) void k_spmv_real(int64_t n_tiles, const int32_t *__restrict__ indptr,
+                                                    const int32_t *__restrict__ indices,
+                                                    const double *__restrict__ vals,
+                                                    const int32_t *__restrict__ tiles, int lpr,
+                                                    const double *__restrict__ x, double *__restrict__ y,
+                                                    const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl != nullptr && ctrl->broken) return;
+    __shared__ double pr[WAVES][TILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * WAVES + wave;
+    if (t >= n_tiles) return;
+    const int r0 = tiles[t], r1 = tiles[t + 1];
+    const int k0 = indptr[r0], k1 = indptr[r1];
+    const int nnz = k1 - k0;
+    if (nnz <= TILE) {
+        if (nnz > 0) {
+            int col[NPT];
+            double a[NPT], xv[NPT];
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) {
+                const int k = min(k0 + q * 64 + lane, k1 - 1);
+                col[q] = indices[k];
+                a[q] = vals[k];
+            }
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) xv[q] = x[col[q]];
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) {
+                const int s = q * 64 + lane;
+                if (s < nnz) pr[wave][s] = a[q] * xv[q];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int rows_per_pass = 64 / lpr;
+        const int sub = lane % lpr;
+        for (int rb = r0; rb < r1; rb += rows_per_pass) {
+            const int r = rb + lane / lpr;
+            double sr = 0.0;
+            if (r < r1) {
+                const int a0 = indptr[r] - k0, a1 = indptr[r + 1] - k0;
+                for (int s = a0 + sub; s < a1; s += lpr) sr += pr[wave][s];
+            }
+            for (int off = lpr >> 1; off > 0; off >>= 1) sr += __shfl_xor(sr, off, 64);
+            if (r < r1 && sub == 0) y[r] = ACC ? y[r] + sr : sr;
+        }
+    } else {
+        double sr = 0.0;
+        for (int k = k0 + lane; k < k1; k += 64) sr = fma(vals[k], x[indices[k]], sr);
+        sr = wave_sum(sr);
+        if (lane == 0) y[r0] = ACC ? y[r0] + sr : sr;
     }
 }
 
@@ -736,6 +796,89 @@ __global__ __launch_bounds__(BLOCK) void k_pb_phase2(int64_t n_rows, int n_rowbl
             y[row] = make_double2(sr, si);
         }
     }
+}
+
+// The two phases for real vectors (x, y, products float64).
+__global__ __launch_bounds__(BLOCK) void k_pb_phase1_real(int64_t n_chunks, int64_t chunks_per_xcd,
+                                                         const int32_t *__restrict__ chunk_begin,
+                                                         const int32_t *__restrict__ chunk_slab,
+                                                         const int32_t *__restrict__ slab_ptr,
+                                                         const double *__restrict__ val,
+                                                         const uint16_t *__restrict__ lcol,
+                                                         const int32_t *__restrict__ dest,
+                                                         const double *__restrict__ x, double *__restrict__ prod,
+                                                         const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl != nullptr && ctrl->broken) return;
+    const int64_t c = (int64_t)(blockIdx.x & 7) * chunks_per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= chunks_per_xcd || c >= n_chunks) return;
+    const int slab = chunk_slab[c];
+    const int b = chunk_begin[c];
+    const int e = min(b + PB_CHUNK, slab_ptr[slab + 1]);
+    const double *xs = x + ((int64_t)slab << PB_SLAB_BITS);
+    int lc[PB_PER_THREAD], d[PB_PER_THREAD];
+    double a[PB_PER_THREAD], xv[PB_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < PB_PER_THREAD; ++q) {
+        const int k = min(b + q * BLOCK + (int)threadIdx.x, e - 1);
+        lc[q] = lcol[k];
+        a[q] = val[k];
+        d[q] = dest[k];
+    }
+#pragma unroll
+    for (int q = 0; q < PB_PER_THREAD; ++q) xv[q] = xs[lc[q]];
+#pragma unroll
+    for (int q = 0; q < PB_PER_THREAD; ++q)
+        if (b + q * BLOCK + (int)threadIdx.x < e) prod[d[q]] = a[q] * xv[q];
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(BLOCK) void k_pb_phase2_real(int64_t n_rows, int n_rowblocks,
+                                                         const int32_t *__restrict__ rb_ptr,
+                                                         const uint16_t *__restrict__ lrow,
+                                                         const double *__restrict__ prod, double *__restrict__ y,
+                                                         const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl != nullptr && ctrl->broken) return;
+    __shared__ double acc_re[WAVES][PB_RB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rb = blockIdx.x * WAVES + wave;
+    if (rb >= n_rowblocks) return;
+    double *are = acc_re[wave];
+#pragma unroll
+    for (int q = 0; q < PB_RB / 64; ++q) are[q * 64 + lane] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int k0 = rb_ptr[rb], k1 = rb_ptr[rb + 1];
+    constexpr int U = 8;
+    for (int base = k0; base < k1; base += 64 * U) {
+        double p[U];
+        int r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = min(base + u * 64 + lane, k1 - 1);
+            p[u] = prod[k];
+            r[u] = lrow[k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (base + u * 64 + lane < k1) unsafeAtomicAdd(&are[r[u]], p[u]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int64_t row0 = (int64_t)rb << PB_RB_BITS;
+#pragma unroll 4
+    for (int q = 0; q < PB_RB / 64; ++q) {
+        const int i = q * 64 + lane;
+        const int64_t row = row0 + i;
+        if (row < n_rows) y[row] = ACC ? y[row] + are[i] : are[i];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gather_f64(int64_t count, const int32_t *__restrict__ idx,
+                                                     const double *__restrict__ src, double *__restrict__ dst) {
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) dst[i] = src[idx[i]];
 }
 
 // ------------------------------------------------------------------ host-side plumbing
@@ -963,6 +1106,26 @@ int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indic
             hipLaunchKernelGGL((k_spmv<double, false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
     }
     AKS_CHECK_LAUNCH("k_spmv");
+    return AKS_OK;
+}
+
+int aks_csr_spmv_real(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const double *d_values,
+                      const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row, const double *d_x,
+                      double *d_y, int32_t accumulate, const void *d_ws, void *stream) {
+    if (n_rows <= 0 || n_tiles <= 0) return fail(AKS_ERR_ARG, "empty matrix");
+    if (!d_indptr || !d_indices || !d_values || !d_tiles || !d_x || !d_y) return fail(AKS_ERR_ARG, "null pointer");
+    if (d_x == d_y) return fail(AKS_ERR_ARG, "x and y must not alias");
+    int lpr = lanes_per_row;
+    if (lpr <= 0) lpr = 1;
+    if (lpr > 64 || (lpr & (lpr - 1)) != 0) return fail(AKS_ERR_ARG, "lanes_per_row must be a power of two <= 64");
+    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((n_tiles + WAVES - 1) / WAVES));
+    if (accumulate)
+        hipLaunchKernelGGL((k_spmv_real<true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, d_values, d_tiles, lpr, d_x, d_y, ctrl);
+    else
+        hipLaunchKernelGGL((k_spmv_real<false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, d_values, d_tiles, lpr, d_x, d_y, ctrl);
+    AKS_CHECK_LAUNCH("k_spmv_real");
     return AKS_OK;
 }
 
@@ -1210,17 +1373,63 @@ int aks_pb_spmv(const aks_pb_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int3
     return AKS_OK;
 }
 
-static int expand_impl(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const void *d_values,
-                       int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row,
-                       const aks_pb_matrix *pb, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
-                       int32_t start_dim, int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
-                       int32_t max_dim, void *probe, void *stream, bool first_w_ready) {
+int aks_pb_spmv_real(const aks_pb_matrix *A, const double *d_x, double *d_y, int32_t accumulate, const void *d_ws,
+                     void *stream) {
+    if (A == nullptr || d_x == nullptr || d_y == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    if (A->values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
+    if (A->n_rows <= 0 || A->n_cols <= 0 || A->nnz < 0 || A->n_chunks < 0) return fail(AKS_ERR_ARG, "bad sizes");
+    if (A->n_slabs != (int32_t)((A->n_cols + (1 << PB_SLAB_BITS) - 1) >> PB_SLAB_BITS) ||
+        A->n_rowblocks != (int32_t)((A->n_rows + PB_RB - 1) >> PB_RB_BITS))
+        return fail(AKS_ERR_ARG, "n_slabs / n_rowblocks do not match the shape");
+    if (!A->d_rb_ptr || (A->nnz > 0 && (!A->d_val || !A->d_lcol || !A->d_dest || !A->d_lrow || !A->d_slab_ptr ||
+                                        !A->d_chunk_begin || !A->d_chunk_slab || !A->d_prod)))
+        return fail(AKS_ERR_ARG, "null array in aks_pb_matrix");
+    if (d_x == d_y) return fail(AKS_ERR_ARG, "x and y must not alias");
+    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double *prod = reinterpret_cast<double *>(A->d_prod);        // the first 8 nnz bytes of the c128 scratch
+    if (A->n_chunks > 0) {
+        const int64_t cpx = (A->n_chunks + 7) / 8;
+        hipLaunchKernelGGL(k_pb_phase1_real, dim3((unsigned)(cpx * 8)), dim3(BLOCK), 0, s, A->n_chunks, cpx,
+                           A->d_chunk_begin, A->d_chunk_slab, A->d_slab_ptr, static_cast<const double *>(A->d_val),
+                           A->d_lcol, A->d_dest, d_x, prod, ctrl);
+    }
+    const dim3 grid2((unsigned)((A->n_rowblocks + WAVES - 1) / WAVES));
+    if (accumulate)
+        hipLaunchKernelGGL(k_pb_phase2_real<true>, grid2, dim3(BLOCK), 0, s, A->n_rows, A->n_rowblocks, A->d_rb_ptr,
+                           A->d_lrow, prod, d_y, ctrl);
+    else
+        hipLaunchKernelGGL(k_pb_phase2_real<false>, grid2, dim3(BLOCK), 0, s, A->n_rows, A->n_rowblocks, A->d_rb_ptr,
+                           A->d_lrow, prod, d_y, ctrl);
+    AKS_CHECK_LAUNCH("aks_pb_spmv_real");
+    return AKS_OK;
+}
+
+int aks_workspace_set_real(void *d_ws, int32_t real_packed, void *stream) {
+    if (d_ws == nullptr) return fail(AKS_ERR_ARG, "workspace pointer is null");
+    aks_ctrl *ctrl = static_cast<aks_ctrl *>(d_ws);
+    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&ctrl->real_mode), real_packed ? 1 : 0, 1,
+                                     static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetD32Async(real_mode)");
+    return AKS_OK;
+}
+
+int aks_arnoldi_expand_ex(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const void *d_values,
+                          int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row,
+                          const aks_pb_matrix *pb, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
+                          int32_t start_dim, int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
+                          int32_t max_dim, void *probe, void *stream, int32_t flags) {
+    const bool first_w_ready = (flags & AKS_EXPAND_FROM_W) != 0, real = (flags & AKS_EXPAND_REAL_PACKED) != 0;
     if (start_dim < 0 || end_dim > max_dim || start_dim > end_dim)
         return fail(AKS_ERR_ARG, "need 0 <= start_dim <= end_dim <= max_dim");
     if (d_V == nullptr || d_H == nullptr) return fail(AKS_ERR_ARG, "null pointer");
     if (ldh < max_dim) return fail(AKS_ERR_ARG, "ldh < max_dim");
     if (pb != nullptr && (pb->n_rows != n_rows || pb->n_cols != n_rows))
         return fail(AKS_ERR_ARG, "binned matrix shape does not match n_rows");
+    if (real && values_complex) return fail(AKS_ERR_ARG, "real-packed mode needs real matrix values");
+    // real-packed: a column holds n_rows float64 = ceil(n_rows / 2) complex slots (an odd tail slot keeps Im = 0)
+    const int64_t n_panel = real ? (n_rows + 1) / 2 : n_rows;
+    if (ldv < n_panel) return fail(AKS_ERR_ARG, "ldv too small");
     Probe *pr = static_cast<Probe *>(probe);
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (int32_t j = start_dim; j < end_dim; ++j) {
@@ -1230,15 +1439,23 @@ static int expand_impl(int64_t n_rows, const int32_t *d_indptr, const int32_t *d
         int rc = AKS_OK;
         if (!(first_w_ready && j == start_dim)) {
             done = pr ? pr->begin(AKS_PROBE_SPMV, s) : nullptr;
-            rc = pb != nullptr
-                     ? aks_pb_spmv(pb, x, w, 0, d_ws, stream)
-                     : aks_csr_spmv(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
-                                    lanes_per_row, x, w, 0, d_ws, stream);
+            if (real)
+                rc = pb != nullptr
+                         ? aks_pb_spmv_real(pb, reinterpret_cast<const double *>(x), reinterpret_cast<double *>(w), 0,
+                                            d_ws, stream)
+                         : aks_csr_spmv_real(n_rows, d_indptr, d_indices, static_cast<const double *>(d_values),
+                                             d_tiles, n_tiles, lanes_per_row, reinterpret_cast<const double *>(x),
+                                             reinterpret_cast<double *>(w), 0, d_ws, stream);
+            else
+                rc = pb != nullptr
+                         ? aks_pb_spmv(pb, x, w, 0, d_ws, stream)
+                         : aks_csr_spmv(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
+                                        lanes_per_row, x, w, 0, d_ws, stream);
             if (done) (void)hipEventRecord(done, s);
             if (rc != AKS_OK) return rc;
         }
         done = pr ? pr->begin(AKS_PROBE_ORTHO, s) : nullptr;
-        rc = aks_dgks_gs(n_rows, j + 1, d_V, ldv, w, d_H + j, ldh, tol, eta, 1, d_ws, ws_bytes, max_dim, stream);
+        rc = aks_dgks_gs(n_panel, j + 1, d_V, ldv, w, d_H + j, ldh, tol, eta, 1, d_ws, ws_bytes, max_dim, stream);
         if (done) (void)hipEventRecord(done, s);
         if (rc != AKS_OK) return rc;
     }
@@ -1250,8 +1467,9 @@ int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d
                        const aks_pb_matrix *pb, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
                        int32_t start_dim, int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
                        int32_t max_dim, void *probe, void *stream) {
-    return expand_impl(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles, lanes_per_row, pb,
-                       d_V, ldv, d_H, ldh, start_dim, end_dim, tol, eta, d_ws, ws_bytes, max_dim, probe, stream, false);
+    return aks_arnoldi_expand_ex(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
+                                 lanes_per_row, pb, d_V, ldv, d_H, ldh, start_dim, end_dim, tol, eta, d_ws, ws_bytes,
+                                 max_dim, probe, stream, 0);
 }
 
 int aks_arnoldi_expand_from_w(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
@@ -1259,8 +1477,9 @@ int aks_arnoldi_expand_from_w(int64_t n_rows, const int32_t *d_indptr, const int
                               int32_t lanes_per_row, const aks_pb_matrix *pb, aks_c128 *d_V, int64_t ldv,
                               aks_c128 *d_H, int64_t ldh, int32_t start_dim, int32_t end_dim, double tol, double eta,
                               void *d_ws, int64_t ws_bytes, int32_t max_dim, void *probe, void *stream) {
-    return expand_impl(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles, lanes_per_row, pb,
-                       d_V, ldv, d_H, ldh, start_dim, end_dim, tol, eta, d_ws, ws_bytes, max_dim, probe, stream, true);
+    return aks_arnoldi_expand_ex(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
+                                 lanes_per_row, pb, d_V, ldv, d_H, ldh, start_dim, end_dim, tol, eta, d_ws, ws_bytes,
+                                 max_dim, probe, stream, AKS_EXPAND_FROM_W);
 }
 
 int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv, const aks_c128 *d_Qp,
@@ -1387,6 +1606,17 @@ int aks_gather_c128(int64_t count, const int32_t *d_idx, const aks_c128 *d_src, 
     hipLaunchKernelGGL(k_gather, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), count, d_idx,
                        reinterpret_cast<const c128 *>(d_src), reinterpret_cast<c128 *>(d_dst));
     AKS_CHECK_LAUNCH("k_gather");
+    return AKS_OK;
+}
+
+int aks_gather_f64(int64_t count, const int32_t *d_idx, const double *d_src, double *d_dst, void *stream) {
+    if (count == 0) return AKS_OK;
+    if (count < 0 || !d_idx || !d_src || !d_dst) return fail(AKS_ERR_ARG, "bad argument");
+    const int64_t want = (count + BLOCK - 1) / BLOCK;
+    const dim3 grid((unsigned)(want < 4096 ? want : 4096));
+    hipLaunchKernelGGL(k_gather_f64, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), count, d_idx, d_src,
+                       d_dst);
+    AKS_CHECK_LAUNCH("k_gather_f64");
     return AKS_OK;
 }
 

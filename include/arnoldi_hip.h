@@ -57,7 +57,9 @@ typedef struct aks_ctrl {
     int32_t second_passes; /* how many of them ran the DGKS second pass (ortho.py:101)   */
     double beta_in;        /* ||w|| before orthogonalisation, last step (ortho.py:92)    */
     double beta;           /* ||w|| after orthogonalisation, last step (ortho.py:98/105) */
-    double reserved[4];
+    int32_t real_mode;     /* 1: real-packed panel (aks_workspace_set_real); read by the reductions */
+    int32_t reserved_i;
+    double reserved[3];
 } aks_ctrl;
 
 /* Byte offsets of the workspace regions (all 256-byte aligned). */
@@ -205,6 +207,38 @@ int aks_arnoldi_expand_from_w(int64_t n_rows, const int32_t *d_indptr, const int
                               aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh, int32_t start_dim,
                               int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
                               int32_t max_dim, void *probe, void *stream);
+
+/* ---- real-packed mode (the reference's "real arithmetic" TODO, README.md:112-119) ----------------
+ * For a real matrix and a real start vector the whole Krylov basis is real.  A real column of n_rows
+ * float64 IS a complex128 column of ceil(n_rows/2) slots (rows 2i, 2i+1 in slot i; an odd tail keeps
+ * Im = 0), and on such panels
+ *     Re(V^H w) = V^T w,    w -= V h (h real),    ||w||,    V <- V Q (Q real)
+ * are exactly the real operations -- so every panel kernel above is reused on HALF the rows (half the
+ * HBM traffic); only the operator needs real-vector forms.  aks_workspace_set_real(ws, 1) makes the
+ * reductions drop the imaginary parts of the projections (they are not part of the real dot product).
+ * Callers pass n_panel = ceil(n_rows / 2) as n_rows to the aks_gs_*, aks_truncate, aks_combine and
+ * aks_scale entry points and real coefficients (Im = 0) in Qp / S. */
+int aks_workspace_set_real(void *d_ws, int32_t real_packed, void *stream);
+int aks_csr_spmv_real(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
+                      const double *d_values, const int32_t *d_tiles, int64_t n_tiles,
+                      int32_t lanes_per_row, const double *d_x, double *d_y, int32_t accumulate,
+                      const void *d_ws, void *stream);
+/* Binned form; A->d_prod (nnz complex128) is used as nnz float64. */
+int aks_pb_spmv_real(const aks_pb_matrix *A, const double *d_x, double *d_y, int32_t accumulate,
+                     const void *d_ws, void *stream);
+int aks_gather_f64(int64_t count, const int32_t *d_idx, const double *d_src, double *d_dst, void *stream);
+
+/* General form of the expansion: flags = AKS_EXPAND_FROM_W (as aks_arnoldi_expand_from_w) and / or
+ * AKS_EXPAND_REAL_PACKED (n_rows = matrix dimension; V columns are real-packed, ldv counts complex
+ * slots >= ceil(n_rows/2); the workspace is laid out for ceil(n_rows/2) rows and set to real mode). */
+#define AKS_EXPAND_FROM_W 1
+#define AKS_EXPAND_REAL_PACKED 2
+int aks_arnoldi_expand_ex(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
+                          const void *d_values, int32_t values_complex, const int32_t *d_tiles,
+                          int64_t n_tiles, int32_t lanes_per_row, const aks_pb_matrix *pb, aks_c128 *d_V,
+                          int64_t ldv, aks_c128 *d_H, int64_t ldh, int32_t start_dim, int32_t end_dim,
+                          double tol, double eta, void *d_ws, int64_t ws_bytes, int32_t max_dim,
+                          void *probe, void *stream, int32_t flags);
 
 /* ---- restart compression: replaces krylov_schur.py:78 and :81 --------------
  * V[:, :p] = V[:, :m] @ Qp   (in place: a wave reads all m columns of its 64 rows before it

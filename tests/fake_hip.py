@@ -56,6 +56,61 @@ class FakeHip:
         _view(ws, np.uint8, lay.partial_off)[:] = 0
         return 0
 
+    def aks_workspace_set_real(self, ws, flag, stream):
+        _view(_addr(ws) + 32, np.int32, 1)[0] = 1 if flag else 0
+        return 0
+
+    @staticmethod
+    def _is_real_mode(ws):
+        """aks_ctrl.real_mode: real-packed panels, the reductions drop the imaginary parts."""
+        return bool(_view(_addr(ws) + 32, np.int32, 1)[0])
+
+    def aks_csr_spmv_real(self, n_rows, indptr, indices, values, tiles, n_tiles, lpr, x, y, acc, ws, stream):
+        self.calls.append("spmv_real")
+        if _addr(ws) and _view(ws, np.int32, 1)[0]:
+            return 0
+        ip = _view(indptr, np.int32, n_rows + 1)
+        nnz = int(ip[-1])
+        ix = _view(indices, np.int32, nnz)
+        vals = _view(values, np.float64, nnz)
+        n_cols = int(ix.max()) + 1 if nnz else 1
+        A = sp.csr_matrix((vals, ix, ip), shape=(n_rows, n_cols))
+        r = A @ _view(x, np.float64, n_cols)
+        yv = _view(y, np.float64, n_rows)
+        yv[:] = yv + r if acc else r
+        return 0
+
+    def aks_pb_spmv_real(self, A, x, y, acc, ws, stream):
+        self.calls.append("pb_spmv_real")
+        if _addr(ws) and _view(ws, np.int32, 1)[0]:
+            return 0
+        d = A._obj if hasattr(A, "_obj") else A.contents
+        nnz, n_rows, n_cols = int(d.nnz), int(d.n_rows), int(d.n_cols)
+        assert not d.values_complex
+        yv = _view(y, np.float64, n_rows)
+        out = np.zeros(n_rows)
+        if nnz:
+            val = _view(d.d_val, np.float64, nnz)
+            lcol = _view(d.d_lcol, np.uint16, nnz).astype(np.int64)
+            dest = _view(d.d_dest, np.int32, nnz)
+            lrow = _view(d.d_lrow, np.uint16, nnz).astype(np.int64)
+            slab_ptr = _view(d.d_slab_ptr, np.int32, d.n_slabs + 1)
+            rb_ptr = _view(d.d_rb_ptr, np.int32, d.n_rowblocks + 1)
+            slab_of = np.repeat(np.arange(d.n_slabs, dtype=np.int64), np.diff(slab_ptr))
+            prod = _view(d.d_prod, np.float64, nnz)                              # first half of the c128 scratch
+            prod[dest] = val * _view(x, np.float64, n_cols)[(slab_of << 16) + lcol]
+            rb_of = np.repeat(np.arange(d.n_rowblocks, dtype=np.int64), np.diff(rb_ptr))
+            np.add.at(out, (rb_of << 10) + lrow, prod)
+        yv[:] = yv + out if acc else out
+        return 0
+
+    def aks_gather_f64(self, count, idx, src, dst, stream):
+        if count == 0:
+            return 0
+        ix = _view(idx, np.int32, count)
+        _view(dst, np.float64, count)[:] = _view(src, np.float64, int(ix.max()) + 1)[ix]
+        return 0
+
     # ---- SpMV ----------------------------------------------------------------------
     def aks_csr_spmv(self, n_rows, indptr, indices, values, cplx, tiles, n_tiles, lpr, x, y, acc, ws, stream):
         self.calls.append("spmv")
@@ -115,6 +170,8 @@ class FakeHip:
             return 0
         P, wv = self._panel(V, ldv, J, n), _view(w, C128, n)
         r1[:J] = P.conj() @ wv
+        if self._is_real_mode(ws):
+            r1[:J] = r1[:J].real
         r1[J] = np.vdot(wv, wv).real
         r3[0] = 0
         return 0
@@ -126,6 +183,8 @@ class FakeHip:
         P, wv = self._panel(V, ldv, J, n), _view(w, C128, n)
         wv -= r1[:J] @ P
         r2[:J] = P.conj() @ wv
+        if self._is_real_mode(ws):
+            r2[:J] = r2[:J].real
         r2[J] = np.vdot(wv, wv).real
         return 0
 
@@ -170,21 +229,32 @@ class FakeHip:
         return self.aks_gs_finish(n, J, w, Hcol, ldh, tol, eta, normalize, ws, ws_bytes, max_dim, stream)
 
     def aks_arnoldi_expand_from_w(self, *args):
-        return self.aks_arnoldi_expand(*args, first_w_ready=True)
+        return self.aks_arnoldi_expand_ex(*args, 1)
 
-    def aks_arnoldi_expand(self, n, indptr, indices, values, cplx, tiles, n_tiles, lpr, pb, V, ldv, H, ldh,
-                           start, end, tol, eta, ws, ws_bytes, max_dim, probe, stream, first_w_ready=False):
-        self.calls.append("expand_from_w" if first_w_ready else "expand")
+    def aks_arnoldi_expand(self, *args):
+        return self.aks_arnoldi_expand_ex(*args, 0)
+
+    def aks_arnoldi_expand_ex(self, n, indptr, indices, values, cplx, tiles, n_tiles, lpr, pb, V, ldv, H, ldh,
+                              start, end, tol, eta, ws, ws_bytes, max_dim, probe, stream, flags):
+        first_w_ready, real = bool(flags & 1), bool(flags & 2)
+        self.calls.append(("expand_from_w" if first_w_ready else "expand") + ("_real" if real else ""))
+        n_panel = (n + 1) // 2 if real else n
+        assert not real or self._is_real_mode(ws)
         for j in range(start, end):
             x = _addr(V) + 16 * ldv * j
             w = _addr(V) + 16 * ldv * (j + 1)
             if first_w_ready and j == start:
                 pass
+            elif real and pb is not None:
+                self.aks_pb_spmv_real(pb, x, w, 0, ws, stream)
+            elif real:
+                self.aks_csr_spmv_real(n, indptr, indices, values, tiles, n_tiles, lpr, x, w, 0, ws, stream)
             elif pb is not None:
                 self.aks_pb_spmv(pb, x, w, 0, ws, stream)
             else:
                 self.aks_csr_spmv(n, indptr, indices, values, cplx, tiles, n_tiles, lpr, x, w, 0, ws, stream)
-            self.aks_dgks_gs(n, j + 1, V, ldv, w, _addr(H) + 16 * j, ldh, tol, eta, 1, ws, ws_bytes, max_dim, stream)
+            self.aks_dgks_gs(n_panel, j + 1, V, ldv, w, _addr(H) + 16 * j, ldh, tol, eta, 1, ws, ws_bytes, max_dim,
+                             stream)
         return 0
 
     # ---- restart compression ---------------------------------------------------------------

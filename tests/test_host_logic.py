@@ -511,3 +511,26 @@ def test_happy_breakdown_deflate_host_logic(fake):
     import explicit_cases as ec
 
     ec.check_happy_breakdown_deflate()
+
+
+# ---------------------------------------------------------------- real-arithmetic mode (host logic)
+def test_reorder_real_schur():
+    import real_cases as rc
+
+    rc.check_reorder_real_schur()
+
+
+@pytest.mark.parametrize("name", ["mark30_lr", "mark50_readme", "planted_odd_n", "laplace2d", "conjugate_pairs",
+                                  "pair_cut_at_nev3", "pair_cut_at_nev5", "dense_array"])
+def test_real_arithmetic_host_logic(fake, name):
+    import real_cases as rc
+
+    A, nev, seed, kw = rc.cases()[name]
+    rc.check_case(A, nev, seed, **kw)
+    assert any(c.endswith("_real") for c in fake.calls)
+
+
+def test_real_arithmetic_errors(fake):
+    import real_cases as rc
+
+    rc.check_errors()
