@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--cpu-sample-n", type=int, default=1_000_000)
     ap.add_argument("--cpu-restarts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-real-leg", action="store_true",
+                    help="skip the extra measurement of partial_schur(arithmetic='real') on the same matrix")
     ap.add_argument("--chained", action="store_true",
                     help="force the Python-chained stage path on one GPU (the multi-GPU code path)")
     return ap.parse_args()
@@ -216,7 +218,6 @@ def main():
     rows = build_rows(args, r0, r1, n, dims)
     op = CsrOperator(local_rows=rows, offsets=offsets, comm=comm)
     nnz_local = op.nnz
-    del rows
 
     nev, m = args.nev, args.max_dim
     p = min(nev + 5, m - 1)
@@ -368,6 +369,53 @@ def main():
             out["restart_roofline"]["achieved_GBs"] / (HBM_PEAK_GBS * world), 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, n)
+
+    # ---- extra leg: the same workload in real arithmetic (opt-in mode of the product; `value` above stays
+    # the drop-in complex128 path).  Every rank takes part (collectives inside).
+    real_leg = None
+    if not args.no_real_leg:
+        from arnoldi_amd.krylov_schur_real import RealKrylovSchurSolver
+
+        del solver, ctx, op
+        torch.cuda.empty_cache()
+        op_r = CsrOperator(local_rows=rows, offsets=offsets, comm=comm, real=True)
+        np.random.seed(0)
+        rs = RealKrylovSchurSolver(op_r, nev, m, p, 1e-8, sort_key, comm=comm)
+        if not native:
+            rs.ctx.force_chained = True
+        assert rs.start() == m
+        for i in range(args.warmup):
+            rs.contract(i)
+            rs.expand()
+        pr = None
+        if native:
+            pr = _hip.Probe(capacity=2 * m * args.steps + 8)
+            rs.ctx.probe = pr
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            rs.contract(args.warmup + i)
+            rs.expand()
+        sync()
+        el = time.perf_counter() - t0
+        if comm is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if comm.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        real_leg = {"value": round(args.steps / el, 4), "unit": "restarts/s", "ms_per_step": round(el / args.steps * 1e3, 3),
+                    "dtype": "float64 (real-packed basis, real Schur form on the host)", "spmv_form": op_r.spmv_form,
+                    "note": "partial_schur(arithmetic='real'): same (Q, T) contract; restart size moves by one "
+                            "when it would cut a conjugate pair"}
+        if pr is not None:
+            ns, ms_s = pr.read(_hip.PROBE_SPMV)
+            no, ms_o = pr.read(_hip.PROBE_ORTHO)
+            b = op_r.algorithmic_bytes()
+            real_leg.update(spmv_avg_ms=round(ms_s / max(ns, 1), 4), spmv_algorithmic_bytes=b,
+                            spmv_achieved_GBs=round(b / (ms_s / max(ns, 1) * 1e-3) / 1e9, 1) if ns else None,
+                            ortho_avg_ms_per_step=round(ms_o / max(no, 1), 4))
+    if rank == 0:
+        if real_leg is not None:
+            out["real_arithmetic"] = real_leg
         print(json.dumps(out), flush=True)
 
     if comm is not None:

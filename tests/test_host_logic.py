@@ -370,6 +370,11 @@ def run_dist_worker(tmp_path, nproc, backend, device, timeout=600):
 
 def check_dist_verdicts(verdicts):
     for v in verdicts:
+        rl = v.pop("real")
+        for name, c in rl.items():
+            assert c["eig_err"] < 10 * c["tol"] * 4.5 and c["orth_err"] < 1e-11, (name, c)
+            assert c["rel"] <= max(1.05 * c["rel_oracle"], 10 * c["tol"]), (name, c)
+            assert abs(c["restarts"] - c["restarts_oracle"]) <= max(3, 0.3 * c["restarts_oracle"]), (name, c)
         ex = v.pop("explicit")
         for name in ("mark30", "planted"):
             c = ex[name]
