@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-leg", action="store_true",
                     help="skip the extra measurement of partial_schur(arithmetic='real') on the same matrix")
+    ap.add_argument("--real-leg", action="store_true",
+                    help="run that extra measurement with several GPUs too (default: one GPU only, so that "
+                         "nothing after the main measurement can cost a multi-GPU run its JSON line)")
     ap.add_argument("--chained", action="store_true",
                     help="force the Python-chained stage path on one GPU (the multi-GPU code path)")
     return ap.parse_args()
@@ -373,7 +376,7 @@ def main():
     # ---- extra leg: the same workload in real arithmetic (opt-in mode of the product; `value` above stays
     # the drop-in complex128 path).  Every rank takes part (collectives inside).
     real_leg = None
-    if not args.no_real_leg:
+    if not args.no_real_leg and (world == 1 or args.real_leg):
         from arnoldi_amd.krylov_schur_real import RealKrylovSchurSolver
 
         del solver, ctx, op
