@@ -331,6 +331,8 @@ class ArnoldiContext:
         points: ``aks_truncate`` forms ``vecs = Q S`` on a scratch copy, the operator gives
         ``A v_k`` and ``aks_gs_update_project`` with J = 1 and coefficient ``l_k`` yields
         ``||A v_k - l_k v_k||^2`` (its re-projection output is ignored)."""
+        if self.real:
+            raise NotImplementedError("device-side residuals need the complex basis (eigenvectors are complex)")
         k = T.shape[0]
         vals, S = np.linalg.eig(T)
         b = self.basis
@@ -425,6 +427,8 @@ class ArnoldiContext:
         decomposition.py:134-146: operator application into a scratch column, then
         ``aks_gs_update_project`` with J = 1 and coefficient values[i], whose norm output is
         ``||A u_i - values[i] u_i||^2``."""
+        if self.real:
+            raise NotImplementedError("device-side residuals need the complex basis (eigenvectors are complex)")
         b, ws, lib = self.basis, self.ws, _hip.load()
         self._clear_ctrl()
         values = np.atleast_1d(np.asarray(values, dtype=C128))

@@ -407,6 +407,7 @@ def main():
             el = float(t.item())
         real_leg = {"value": round(args.steps / el, 4), "unit": "restarts/s", "ms_per_step": round(el / args.steps * 1e3, 3),
                     "dtype": "float64 (real-packed basis, real Schur form on the host)", "spmv_form": op_r.spmv_form,
+                    "spmv_autotune_ms": getattr(op_r.diag, "tune_ms", None),
                     "note": "partial_schur(arithmetic='real'): same (Q, T) contract; restart size moves by one "
                             "when it would cut a conjugate pair"}
         if pr is not None:
