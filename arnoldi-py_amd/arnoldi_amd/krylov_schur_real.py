@@ -46,11 +46,7 @@ def block_eigenvalues(T, blocks=None):
             ev[s] = T[s, s]
         else:
             lam = np.linalg.eigvals(T[s: s + 2, s: s + 2])
-            lam = lam[np.argsort(-lam.imag)]
-            if np.iscomplexobj(lam) and lam[0].imag != 0:
-                ev[s], ev[s + 1] = lam[0], lam[1]
-            else:                       # a block that is numerically two real eigenvalues
-                ev[s], ev[s + 1] = lam[0], lam[1]
+            ev[s], ev[s + 1] = lam[np.argsort(-lam.imag)]      # (two real values if the block is not a pair)
     return ev
 
 
