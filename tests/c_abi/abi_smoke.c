@@ -3,7 +3,8 @@
  * Arnoldi expansion on the device (aks_arnoldi_expand = the reference's arnoldi_decomposition,
  * src/arnoldi/decomposition.py:13-68), copies V and H back and checks the Arnoldi invariants
  *     V^H V = I      and      A V_m = V_{m+1} H
- * on the host, then compresses the basis with aks_truncate and re-checks orthonormality.
+ * on the host, then compresses the basis with aks_truncate and re-checks orthonormality, and repeats the
+ * factorisation in real-packed mode (aks_workspace_set_real + aks_arnoldi_expand_ex).
  *
  *   hipcc -x c abi_smoke.c -I../../include -L<dir of the .so> -larnoldi_hip -o abi_smoke
  * Exit code 0 = pass.  Used by tests/test_gpu_parity.py::test_c_abi_from_plain_c. */
@@ -119,5 +120,50 @@ int main(void) {
         }
     printf("abi %d: |V^H V - I| = %.2e, |A V - V H| = %.2e, after truncate |V^H V - I| = %.2e, second passes %d\n",
            aks_abi_version(), worst_orth, worst_rel, worst_orth2, ctrl.second_passes);
-    return (worst_orth < 1e-12 && worst_rel < 1e-12 && worst_orth2 < 1e-12) ? 0 : 1;
+    if (!(worst_orth < 1e-12 && worst_rel < 1e-12 && worst_orth2 < 1e-12)) return 1;
+
+    /* ---- the same factorisation in real-packed mode: a column is n float64 = ceil(n/2) complex slots ---- */
+    const int64_t n_panel = (n + 1) / 2, ldp = (n_panel + 63) / 64 * 64;
+    aks_ws_layout layr;
+    CHECK_AKS(aks_workspace_layout(n_panel, m, &layr));
+    aks_c128 *d_Vr, *d_Hr;
+    void *d_wsr;
+    CHECK_HIP(hipMalloc((void **)&d_Vr, (size_t)(m + 1) * ldp * 16));
+    CHECK_HIP(hipMalloc((void **)&d_Hr, (size_t)(m + 1) * m * 16));
+    CHECK_HIP(hipMalloc(&d_wsr, layr.total_bytes));
+    CHECK_HIP(hipMemset(d_Vr, 0, (size_t)(m + 1) * ldp * 16));
+    CHECK_HIP(hipMemset(d_Hr, 0, (size_t)(m + 1) * m * 16));
+    double *Vr = calloc((size_t)(m + 1) * ldp * 2, sizeof *Vr);      /* column c starts at Vr + c * 2 * ldp */
+    nrm = 0.0;
+    for (int64_t i = 0; i < n; ++i) { Vr[i] = sin(0.37 * (double)i + 1.0); nrm += Vr[i] * Vr[i]; }
+    for (int64_t i = 0; i < n; ++i) Vr[i] /= sqrt(nrm);
+    CHECK_HIP(hipMemcpy(d_Vr, Vr, (size_t)n * 8, hipMemcpyHostToDevice));
+    CHECK_AKS(aks_workspace_init(d_wsr, layr.total_bytes, n_panel, m, NULL));
+    CHECK_AKS(aks_workspace_set_real(d_wsr, 1, NULL));
+    CHECK_AKS(aks_arnoldi_expand_ex(n, d_indptr, d_indices, d_values, 0, d_tiles, n_tiles, 0, NULL, d_Vr, ldp, d_Hr, m,
+                                    0, m, 1e-8, sqrt(0.5), d_wsr, layr.total_bytes, m, NULL, NULL,
+                                    AKS_EXPAND_REAL_PACKED));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(Vr, d_Vr, (size_t)(m + 1) * ldp * 16, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(H, d_Hr, (size_t)(m + 1) * m * 16, hipMemcpyDeviceToHost));
+    double worst_r = 0.0, worst_o = 0.0, worst_im = 0.0;
+    for (int a = 0; a <= m; ++a)
+        for (int b = 0; b <= m; ++b) {
+            double sdot = 0.0;
+            for (int64_t i = 0; i < n; ++i) sdot += Vr[(size_t)a * 2 * ldp + i] * Vr[(size_t)b * 2 * ldp + i];
+            const double d = fabs(sdot - (a == b ? 1.0 : 0.0));
+            if (d > worst_o) worst_o = d;
+        }
+    for (int j = 0; j < m; ++j) {
+        for (int c = 0; c <= j + 1; ++c)
+            if (fabs(cimag(H[c * m + j])) > worst_im) worst_im = fabs(cimag(H[c * m + j]));
+        for (int64_t i = 0; i < n; ++i) {
+            const double *vj = Vr + (size_t)j * 2 * ldp;
+            double r = -2.0 * vj[i] + (i > 0 ? vj[i - 1] : 0.0) + (i < n - 1 ? vj[i + 1] : 0.0);
+            for (int c = 0; c <= j + 1; ++c) r -= Vr[(size_t)c * 2 * ldp + i] * creal(H[c * m + j]);
+            if (fabs(r) > worst_r) worst_r = fabs(r);
+        }
+    }
+    printf("real-packed: |V^T V - I| = %.2e, |A V - V H| = %.2e, max |Im H| = %.1e\n", worst_o, worst_r, worst_im);
+    return (worst_o < 1e-12 && worst_r < 1e-12 && worst_im == 0.0) ? 0 : 1;
 }

@@ -625,7 +625,7 @@ def test_c_abi_from_plain_c():
     assert os.path.exists(exe), "tests/c_abi/abi_smoke missing: run __graft_entry__.build()"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
-    assert "|A V - V H|" in r.stdout
+    assert "|A V - V H|" in r.stdout and "real-packed:" in r.stdout
 
 
 def test_lookahead_is_bitwise_neutral(amd, monkeypatch):
