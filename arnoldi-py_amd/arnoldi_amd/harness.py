@@ -113,7 +113,8 @@ def krylov_schur_eig(A, parameters: EigensolverParameters, **solver_kw):
     vecs = Q @ S
     order = WHICH_TO_SORT[parameters.which](vals)
     return vals[order], vecs[:, order], Statistics(
-        elapsed, np.dtype(np.complex128), int(stats["matvecs"]), int(np.max(history.restarts)),
+        elapsed, np.dtype(np.float64 if stats.get("arithmetic") == "real" else np.complex128),
+        int(stats["matvecs"]), int(np.max(history.restarts)),
         int(np.max(history.matvecs)))
 
 

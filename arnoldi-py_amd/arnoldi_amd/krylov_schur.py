@@ -137,7 +137,7 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
     arithmetic  "complex" (default: the reference's complex128 iteration, identical restart history) or
             "real": for a real matrix and a real start vector, iterate in real arithmetic on a
             real-packed basis (krylov_schur_real.py) -- half the memory traffic; same ``(Q, T)`` contract,
-            restart counts may differ from the reference's.
+            restart counts may differ from the reference's.  "auto" picks "real" whenever it applies.
     stats   optional dict that receives ``restarts``, ``matvecs`` (true operator
             applications), ``second_passes`` and the solver object.
 
@@ -160,7 +160,15 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
         p = min(nev + 5, max_dim - 1)               # size of the basis kept at a restart
     assert nev <= p < max_dim
     assert on_breakdown in ("raise", "deflate")
-    assert arithmetic in ("complex", "real")
+    assert arithmetic in ("complex", "real", "auto")
+    if arithmetic == "auto":      # real whenever it applies: a real CSR-able matrix and a real start vector
+        from . import device as _dev
+        from .engine import CsrOperator
+
+        real_matrix = not np.issubdtype(np.dtype(A.dtype), np.complexfloating)
+        real_start = v0 is None or not (np.iscomplexobj(v0) and np.asarray(v0).imag.any())
+        csr_able = (A.real if isinstance(A, CsrOperator) else _dev.canonical_csr(A) is not None)
+        arithmetic = "real" if (real_matrix and real_start and csr_able and on_breakdown == "raise") else "complex"
 
     if comm is None:
         comm = default_comm()

@@ -105,6 +105,22 @@ def check_errors():
     assert abs(T[0, 0] - 1.0) < 1e-8
 
 
+def check_auto():
+    """arithmetic="auto": real for a real matrix + real start vector, complex otherwise."""
+    import arnoldi_amd
+    from arnoldi_amd import matrices
+
+    A = matrices.mark(12)
+    kw = dict(max_dim=12, sort_function=oracle.arg_largest_real, stopping_criterion=1e-9)
+    for M, v0, want in ((A, None, "real"), (A.astype(C128), None, "complex"),
+                        (A, np.exp(1j * np.arange(A.shape[0])) / np.sqrt(A.shape[0]), "complex"),
+                        (A.toarray(), None, "real")):
+        st = {}
+        np.random.seed(5)
+        Q, T, _ = arnoldi_amd.partial_schur(M, 2, arithmetic="auto", v0=v0, stats=st, **kw)
+        assert st["arithmetic"] == want and abs(T[0, 0] - 1.0) < 1e-8
+
+
 def check_reorder_real_schur():
     """Block reordering with dtrexc: every sort key, random quasi-triangular inputs with pairs."""
     import scipy.linalg as sla

@@ -163,6 +163,7 @@ def test_real_arithmetic_solves(amd, name):
 
 def test_real_arithmetic_errors(amd):
     rc.check_errors()
+    rc.check_auto()
 
 
 def test_real_arithmetic_chained_path_is_bitwise_the_native_one(amd):

@@ -539,3 +539,4 @@ def test_real_arithmetic_errors(fake):
     import real_cases as rc
 
     rc.check_errors()
+    rc.check_auto()

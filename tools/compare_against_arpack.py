@@ -50,18 +50,22 @@ def main():
     ap.add_argument("--max-it", type=int, default=100_000)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--sweep", metavar="CSV", help="run the whole stress grid and write this CSV")
+    ap.add_argument("--arithmetic", choices=["complex", "real", "auto"], default="complex",
+                    help="complex = the reference's iteration (default); real = real Schur form on a real-packed "
+                         "basis (real matrices only)")
     args = ap.parse_args()
 
     A = build(args.matrix)
     print(f"Matrix: {args.matrix}  shape={A.shape[0]}x{A.shape[1]}, nnz={A.nnz}, dtype={A.dtype}")
     np.random.seed(args.seed)
     if args.sweep:
-        rows = harness.sweep(A, args.sweep, tol=args.tol, max_restarts=args.max_it, verbose=True)
+        rows = harness.sweep(A, args.sweep, tol=args.tol, max_restarts=args.max_it, verbose=True,
+                             arithmetic=args.arithmetic)
         bad = [r for r in rows if not r["match"]]
         print(f"wrote {args.sweep}: {len(rows)} rows, {len(bad) // 2} parameter sets without eigenvalue match")
         return 1 if bad else 0
     params = harness.EigensolverParameters(args.nev, args.ncv, args.tol, args.max_it, args.p, args.which)
-    rows = harness.compare(A, params, verbose=True)
+    rows = harness.compare(A, params, verbose=True, arithmetic=args.arithmetic)
     return 0 if rows[0]["match"] else 1
 
 
