@@ -168,7 +168,8 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
         real_matrix = not np.issubdtype(np.dtype(A.dtype), np.complexfloating)
         real_start = v0 is None or not (np.iscomplexobj(v0) and np.asarray(v0).imag.any())
         csr_able = (A.real if isinstance(A, CsrOperator) else _dev.canonical_csr(A) is not None)
-        arithmetic = "real" if (real_matrix and real_start and csr_able and on_breakdown == "raise") else "complex"
+        arithmetic = ("real" if (real_matrix and real_start and csr_able and on_breakdown == "raise"
+                                 and max_dim >= nev + 2) else "complex")
 
     if comm is None:
         comm = default_comm()
@@ -179,6 +180,8 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
             raise ValueError("arithmetic='real' needs a real matrix")
         if on_breakdown != "raise":
             raise ValueError("on_breakdown='deflate' is only implemented for arithmetic='complex'")
+        if max_dim < nev + 2:      # room to keep the partner of a conjugate pair cut at nev
+            raise ValueError("arithmetic='real' needs max_dim >= nev + 2")
         solver = RealKrylovSchurSolver(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)
     else:
         solver = KrylovSchurSolver(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)

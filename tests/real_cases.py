@@ -94,6 +94,8 @@ def check_errors():
         arnoldi_amd.partial_schur(A, 2, arithmetic="real", v0=np.full(A.shape[0], 1 + 1j))
     with pytest.raises(AssertionError):
         arnoldi_amd.partial_schur(A, 2, arithmetic="quaternion")
+    with pytest.raises(ValueError, match="max_dim >= nev"):
+        arnoldi_amd.partial_schur(A, 3, max_dim=4, arithmetic="real")
     np.random.seed(0)
     with pytest.raises(ValueError, match="Has not converged"):
         arnoldi_amd.partial_schur(matrices.random_csr(2000, 5, 1234), 5, max_dim=20, max_restarts=3,

@@ -206,3 +206,23 @@ def test_real_arithmetic_full_size_planted(amd):
     res = np.linalg.norm(A @ Q - Q @ T, axis=0)
     assert res.max() < 1e-6
     np.testing.assert_allclose(Q.conj().T @ Q, np.eye(5), atol=1e-10)
+
+
+@pytest.mark.parametrize("which", ["LM", "LR"])
+def test_real_arithmetic_stress_grid(amd, which):
+    """The reference's stress grid (nev, ncv, p) in real arithmetic against the oracle of the complex
+    iteration: on the symmetric Laplacian (real spectrum) the two iterations coincide restart for restart."""
+    from arnoldi_amd import matrices
+    from arnoldi_amd.harness import STRESS_GRID
+
+    if which == "LM":
+        A, sort_o, tol = matrices.laplace2d(30, 31), oracle.arg_largest_magnitude, None
+    else:
+        A, sort_o, tol = matrices.mark(44), oracle.arg_largest_real, 1e-8
+    for nev, ncv, p in STRESS_GRID:
+        kw = dict(max_dim=ncv, p=p, stopping_criterion=tol, max_restarts=4000, sort_function=sort_o)
+        st = rc.check_case(A, nev, nev + ncv, **kw)
+        if which == "LM":
+            np.random.seed(nev + ncv)
+            _, _, ho = oracle.krylov_schur(A, nev, **kw)
+            assert int(st["restarts"]) == int(ho.restarts.max()), (nev, ncv, p)
