@@ -648,3 +648,34 @@ def test_lookahead_is_bitwise_neutral(amd, monkeypatch):
     np.testing.assert_array_equal(res["1"][1], res["0"][1])
     np.testing.assert_array_equal(res["1"][2], res["0"][2])
     assert res["1"][4] == res["0"][4]
+
+
+def test_bench_contract_line():
+    """bench.py prints exactly one JSON line with the fields the driver reads (small n: the numbers mean
+    nothing here, the schema does)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--rows", "300000", "--cpu-sample-n", "50000", "--cpu-restarts", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "complex128" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.02 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "restarts/s" and cb["sample"]
+    assert d["real_arithmetic"]["value"] > 0
