@@ -327,35 +327,12 @@ class ArnoldiContext:
         """``(vals, ||A v_k - l_k v_k||, the same / |l_k|)`` for the eigenpairs of the partial Schur
         form held in the first ``k = T.shape[0]`` basis columns -- what the reference's
         ``RitzDecomposition.compute_true_residuals`` (decomposition.py:134-146) and its scripts
-        compute on the host -- without moving any n-vector off the GPU.  Built from existing entry
-        points: ``aks_truncate`` forms ``vecs = Q S`` on a scratch copy, the operator gives
-        ``A v_k`` and ``aks_gs_update_project`` with J = 1 and coefficient ``l_k`` yields
-        ``||A v_k - l_k v_k||^2`` (its re-projection output is ignored)."""
-        if self.real:
-            raise NotImplementedError("device-side residuals need the complex basis (eigenvectors are complex)")
+        compute on the host -- without moving any n-vector off the GPU: ``aks_combine`` forms
+        ``vecs = Q S``, ``residual_norms`` does the rest."""
         k = T.shape[0]
         vals, S = np.linalg.eig(T)
-        b = self.basis
-        scratch = dev.KrylovBasis(b.n_rows, k, b.device)          # k + 1 columns: vecs | work
-        scratch.V[:k].copy_(b.V[:k])
-        dev.truncate(scratch, k, k, torch.from_numpy(np.ascontiguousarray(S, dtype=C128)).to(b.device))
-        ws = dev.Workspace(b.n_rows, k, b.device)
-        lam = torch.from_numpy(np.ascontiguousarray(vals, dtype=C128)).to(b.device).view(torch.float64)
-        red1, red2 = ws.red(1, 1), ws.red(2, 2)
-        out = torch.zeros(k, dtype=torch.float64, device=b.device)
-        y = scratch.col(k)
-        lib = _hip.load()
-        multi = self.comm is not None and self.comm.active
-        for i in range(k):
-            self.op.apply(scratch.col(i), y, ws)
-            red1.copy_(lam[2 * i: 2 * i + 2])
-            rc = lib.aks_gs_update_project(b.n_rows, 1, dev._ptr(scratch.col(i)), scratch.ldv, dev._ptr(y),
-                                           dev._ptr(ws.buf), ws.nbytes, ws.max_dim, dev._stream())
-            _hip.check(rc, "aks_gs_update_project")
-            if multi:
-                self.comm.allreduce_sum_(red2)
-            out[i] = red2[2]                                      # red2[1].re = ||r||^2
-        res = np.sqrt(out.cpu().numpy())
+        vecs = self.combine(0, k, S)                              # aks_combine: vecs = Q S, out of place
+        res = self.residual_norms(vecs, vals)
         return vals, res, res / np.abs(vals)
 
     # -- building blocks of the explicit-restart solvers (SURVEY 8(f) rank 3) ---------------------
