@@ -182,3 +182,49 @@ def check_happy_breakdown_deflate():
     assert st["restarts"] == 1 and list(hist.restarts) == [1, 1, 1]
     with pytest.raises(ValueError, match="invariant subspace of dimension 6 < nev"):
         arnoldi_amd.partial_schur(A, 8, max_dim=20, v0=v0, on_breakdown="deflate")
+
+
+def check_ritz_reference_tests():
+    """TestRitzDecomposition of the reference (tests/test_decomposition.py:174-261) restated on the
+    device-backed class: overlap with ARPACK's vectors, true vs approximate residuals, ``max_dim``."""
+    from scipy.sparse.linalg import eigs
+
+    from arnoldi_amd.decomposition import RitzDecomposition, arnoldi_decomposition
+    from arnoldi_amd.matrices import laplace, mark
+    from arnoldi_amd.utils import rand_normalized_vector
+
+    RTOL, ATOL = 1e-4, 1e-8
+
+    def factorise(A, m):
+        n = A.shape[0]
+        V = np.zeros((n, m + 1), dtype=C128)
+        H = np.zeros((m + 1, m), dtype=C128)
+        V[:, 0] = rand_normalized_vector(n, C128)
+        V, H, n_iter = arnoldi_decomposition(A, V, H)
+        return V, H
+
+    np.random.seed(11)
+    A = mark(10)
+    for which, sort_function in (("LM", lambda x: np.argsort(-np.abs(x))), ("LR", lambda x: np.argsort(-np.real(x)))):
+        r_vecs = eigs(A, 2, which=which)[1]                                    # test_simple
+        V, H = factorise(A, 30)
+        ritz = RitzDecomposition.from_v_and_h(V, H, 2, sort_function=sort_function)
+        overlap = np.linalg.norm(ritz.vectors.T @ r_vecs) / np.sqrt(2)
+        np.testing.assert_allclose(overlap, 1, rtol=1e-4, atol=ATOL)
+        assert np.linalg.norm(A @ ritz.vectors - ritz.values * ritz.vectors) <= 2e-3
+    for M, m in ((mark(10), 20), (laplace(100), 10)):                          # test_residual_computation
+        V, H = factorise(M, m)
+        ritz = RitzDecomposition.from_v_and_h(V, H, 2)
+        residuals = np.linalg.norm(M @ ritz.vectors - ritz.values * ritz.vectors, axis=0)
+        np.testing.assert_allclose(ritz.compute_true_residuals(M), residuals, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(ritz.approximate_residuals, residuals, rtol=RTOL, atol=ATOL)
+    m, max_dim = 20, 15                                                         # test_max_dim
+    V, H = factorise(A, m)
+    V, H = np.array(V), np.array(H)
+    V[:, max_dim:] = np.random.randn(*V[:, max_dim:].shape)
+    H[max_dim + 1:, max_dim:] = np.random.randn(*H[max_dim + 1:, max_dim:].shape)
+    broken = RitzDecomposition.from_v_and_h(V, H, 2)
+    good = RitzDecomposition.from_v_and_h(V, H, 2, max_dim=max_dim)
+    with pytest.raises(AssertionError):
+        np.testing.assert_allclose(broken.compute_true_residuals(A), broken.approximate_residuals, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(good.compute_true_residuals(A), good.approximate_residuals, rtol=RTOL, atol=ATOL)

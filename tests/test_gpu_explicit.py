@@ -83,6 +83,7 @@ def test_building_blocks(amd):
     ec.check_ritz_decomposition()
     ec.check_ritz_wide()
     ec.check_mgs()
+    ec.check_ritz_reference_tests()
 
 
 def test_context_blocks_against_numpy(amd):

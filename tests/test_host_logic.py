@@ -464,6 +464,7 @@ def test_explicit_restart_building_blocks(fake):
     ec.check_ritz_decomposition()
     ec.check_ritz_wide(n=500, m=100, q=100)
     ec.check_mgs()
+    ec.check_ritz_reference_tests()
     assert "combine" in fake.calls
 
 
