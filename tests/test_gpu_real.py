@@ -226,3 +226,22 @@ def test_real_arithmetic_stress_grid(amd, which):
             np.random.seed(nev + ncv)
             _, _, ho = oracle.krylov_schur(A, nev, **kw)
             assert int(st["restarts"]) == int(ho.restarts.max()), (nev, ncv, p)
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 17, 63, 64, 65, 129, 257])
+def test_real_arithmetic_tiny_sizes(amd, n):
+    """Odd and tiny dimensions (panels of 2 .. 129 packed rows, Krylov space = whole space for n <= 20):
+    the dominant eigenpair of a dense real matrix, against the complex path and numpy."""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)) + np.diag(np.arange(n) * 2.0)
+    m = min(20, n)
+    out = {}
+    for arith in ("real", "complex"):
+        np.random.seed(1)
+        Q, T, _ = amd.partial_schur(A, 1, max_dim=m, arithmetic=arith, max_restarts=500)
+        assert Q.shape == (n, 1)
+        out[arith] = T[0, 0]
+        assert np.linalg.norm(A @ Q - Q @ T) < 1e-5 * abs(T[0, 0])
+    ev = np.linalg.eigvals(A)
+    assert abs(out["real"] - out["complex"]) < 1e-7 * abs(out["complex"])
+    assert np.abs(ev - out["real"]).min() < 1e-6 * abs(out["real"])
