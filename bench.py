@@ -370,6 +370,13 @@ def main():
             out["restart_roofline"]["algorithmic_GB_per_restart"] * world / (elapsed / args.steps), 1)
         out["restart_roofline"]["frac_of_peak"] = round(
             out["restart_roofline"]["achieved_GBs"] / (HBM_PEAK_GBS * world), 4)
+        # SURVEY 8(d)'s own per-restart figure (three panel reads per step whether or not the second pass
+        # runs): (m-p) B_spmv + 16 n 3 S(m,p) + B_tr, with S = sum of the panel widths J = p+1 .. m
+        S = sum(range(p + 1, m + 1))
+        survey_bytes = (m - p) * spmv_bytes + 16 * op.n_local * 3 * S + 16 * op.n_local * (m + p) + 32 * op.n_local
+        out["restart_roofline"]["survey_fused_GB_per_restart"] = round(survey_bytes / 1e9, 2)
+        out["restart_roofline"]["survey_fused_frac_of_peak"] = round(
+            survey_bytes * world / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, n)
 
