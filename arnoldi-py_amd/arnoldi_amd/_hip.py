@@ -10,7 +10,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_DIM = 128          # AKS_MAX_DIM
 MAX_TRUNC = 96         # AKS_MAX_TRUNC
 SPMV_TILE_NNZ = 256    # AKS_SPMV_TILE_NNZ
@@ -57,20 +57,32 @@ class Ctrl(C.Structure):
 _P = C.c_void_p
 _I32, _I64, _F64 = C.c_int32, C.c_int64, C.c_double
 
-PB_SLAB_BITS = 16       # AKS_PB_SLAB_BITS
-PB_ROWBLOCK_BITS = 10   # AKS_PB_ROWBLOCK_BITS
-PB_CHUNK_NNZ = 2048     # AKS_PB_CHUNK_NNZ
+PB_SLAB_BITS = 13       # AKS_PB_SLAB_BITS
+PB_ROWBLOCK_BITS = 13   # AKS_PB_ROWBLOCK_BITS
+PB_RUNS_PER_ROUND = 32  # AKS_PB_WAVES * AKS_PB_RUNS_PER_WAVE
 EXPAND_FROM_W, EXPAND_REAL_PACKED = 1, 2   # AKS_EXPAND_* flags of aks_arnoldi_expand_ex
 
 
+class PbRun(C.Structure):
+    """Mirror of ``aks_pb_run`` (16 bytes)."""
+
+    _fields_ = [("start", C.c_uint32), ("info", C.c_uint32), ("lbase", C.c_uint32), ("lcount", C.c_uint32)]
+
+
+class PbSizes(C.Structure):
+    """Mirror of ``aks_pb_sizes``."""
+
+    _fields_ = [("nnz_pad", _I64), ("n_runs", _I64), ("n_lrow", _I64), ("n_slabs", _I32), ("n_rowblocks", _I32)]
+
+
 class PbMatrix(C.Structure):
-    """Mirror of ``aks_pb_matrix`` (device pointers of the slab-binned SpMV form)."""
+    """Mirror of ``aks_pb_matrix`` (device pointers of the tile-binned SpMV form)."""
 
     _fields_ = [
-        ("n_rows", _I64), ("n_cols", _I64), ("nnz", _I64), ("n_chunks", _I64),
+        ("n_rows", _I64), ("n_cols", _I64), ("nnz", _I64), ("nnz_pad", _I64), ("n_runs", _I64), ("n_lrow", _I64),
         ("n_slabs", _I32), ("n_rowblocks", _I32), ("values_complex", _I32), ("pad_", _I32),
-        ("d_val", _P), ("d_lcol", _P), ("d_dest", _P), ("d_lrow", _P), ("d_rb_ptr", _P),
-        ("d_slab_ptr", _P), ("d_chunk_begin", _P), ("d_chunk_slab", _P), ("d_prod", _P),
+        ("d_val", _P), ("d_lcol", _P), ("d_slab_begin", _P), ("d_slab_end", _P), ("d_runs", _P),
+        ("d_rb_run_ptr", _P), ("d_lrow", _P), ("d_prod", _P),
     ]
 
 # name -> (restype, argtypes); one entry per function declared in include/arnoldi_hip.h
@@ -87,8 +99,9 @@ SIGNATURES = {
     "aks_gs_finish": (C.c_int, [_I64, _I32, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
     "aks_dgks_gs": (C.c_int, [_I64, _I32, _P, _I64, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
     "aks_pb_params": (C.c_int, [C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
-    "aks_pb_plan_count": (_I64, [_P, _P, _I64, _I64, _P]),
-    "aks_pb_plan_fill": (C.c_int, [_P, _P, _P, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "aks_pb_plan_create": (_P, [_P, _P, _P, _I32, _I64, _I64, C.POINTER(PbSizes)]),
+    "aks_pb_plan_export": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "aks_pb_plan_destroy": (None, [_P]),
     "aks_pb_spmv": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),
     "aks_arnoldi_expand": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, C.POINTER(PbMatrix), _P, _I64,
                                      _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P]),
@@ -183,7 +196,7 @@ class Probe:
 
 
 def pb_params():
-    """(slab_bits, rowblock_bits, chunk_nnz) of the loaded library's slab-binned SpMV form."""
+    """(sub-slab bits, row-block bits, runs per round) of the loaded library's tile-binned SpMV form."""
     a, b, c = _I32(0), _I32(0), _I32(0)
     check(load().aks_pb_params(C.byref(a), C.byref(b), C.byref(c)), "aks_pb_params")
     return a.value, b.value, c.value

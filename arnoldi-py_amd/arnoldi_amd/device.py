@@ -154,7 +154,7 @@ class DeviceCSR:
         return self.binned
 
     def autotune(self, min_nnz=2_000_000, reps=3, force=None, real=False):
-        """Pick the CSR-stream or the slab-binned SpMV by timing both on this device.
+        """Pick the CSR-stream or the tile-binned SpMV by timing both on this device.
         Only matrices that are large and scattered enough to miss L2 are candidates.
         ``force`` = "csr" | "binned" skips the measurement.  Frees the host copy.
         ``real``: time the real-vector kernels (real-packed mode)."""
@@ -164,7 +164,11 @@ class DeviceCSR:
             if not candidate:
                 choice = "csr"
         if choice is None:
-            self.build_binned()
+            try:
+                self.build_binned()
+            except _hip.HipLibraryError:      # too many tiles / non-zeros for the binned form
+                choice = "csr"
+        if choice is None:
             x = torch.zeros(self.n_cols, dtype=torch.complex128, device=self.device)
             y = torch.empty(self.n_rows, dtype=torch.complex128, device=self.device)
             times = {}
@@ -221,8 +225,8 @@ class DeviceCSR:
 
 
 class BinnedCSR:
-    """Slab-binned two-phase form of a CSR block (``aks_pb_matrix``): arrays planned on the
-    host by ``aks_pb_plan_count`` / ``aks_pb_plan_fill``, uploaded, plus the product scratch."""
+    """Tile-binned two-phase form of a CSR block (``aks_pb_matrix``): arrays planned on the host by
+    ``aks_pb_plan_create`` / ``aks_pb_plan_export``, uploaded, plus the product scratch."""
 
     def __init__(self, M, device):
         lib = _hip.load()
@@ -232,45 +236,48 @@ class BinnedCSR:
         indices = np.ascontiguousarray(M.indices, dtype=np.int32)
         cplx = int(M.data.dtype == C128)
         values = np.ascontiguousarray(M.data)
-        slab_bits, rb_bits, _ = _hip.pb_params()
-        n_slabs = (n_cols + (1 << slab_bits) - 1) >> slab_bits
-        n_rb = (n_rows + (1 << rb_bits) - 1) >> rb_bits
-        slab_ptr = np.empty(n_slabs + 1, np.int32)
-        n_chunks = lib.aks_pb_plan_count(indptr.ctypes.data, indices.ctypes.data, n_rows, n_cols,
-                                         slab_ptr.ctypes.data)
-        _hip.check(n_chunks, "aks_pb_plan_count")
-        val = np.empty(nnz, values.dtype)
-        lcol = np.empty(nnz, np.uint16)
-        dest = np.empty(nnz, np.int32)
-        lrow = np.empty(nnz, np.uint16)
-        rb_ptr = np.empty(n_rb + 1, np.int32)
-        chunk_begin = np.empty(max(n_chunks, 1), np.int32)
-        chunk_slab = np.empty(max(n_chunks, 1), np.int32)
-        rc = lib.aks_pb_plan_fill(indptr.ctypes.data, indices.ctypes.data, values.ctypes.data, cplx, n_rows,
-                                  n_cols, slab_ptr.ctypes.data, val.ctypes.data, lcol.ctypes.data,
-                                  dest.ctypes.data, lrow.ctypes.data, rb_ptr.ctypes.data,
-                                  chunk_begin.ctypes.data, chunk_slab.ctypes.data)
-        _hip.check(rc, "aks_pb_plan_fill")
-        up = lambda a: torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to(device)  # noqa: E731
-        self.val, self.lcol, self.dest, self.lrow = up(val), up(lcol), up(dest), up(lrow)
-        self.rb_ptr, self.slab_ptr = up(rb_ptr), up(slab_ptr)
-        self.chunk_begin, self.chunk_slab = up(chunk_begin), up(chunk_slab)
-        self.prod = torch.empty(max(nnz, 1), dtype=torch.complex128, device=device)
-        self.n_chunks, self.n_slabs, self.n_rowblocks = int(n_chunks), int(n_slabs), int(n_rb)
+        sz = _hip.PbSizes()
+        plan = lib.aks_pb_plan_create(indptr.ctypes.data, indices.ctypes.data, values.ctypes.data, cplx,
+                                      n_rows, n_cols, C.byref(sz))
+        if not plan:
+            msg = lib.aks_last_error()
+            raise _hip.HipLibraryError(f"aks_pb_plan_create failed: {msg.decode() if msg else '?'}")
+        try:
+            val = np.empty(sz.nnz_pad, values.dtype)
+            lcol = np.empty(sz.nnz_pad, np.uint16)
+            slab_begin = np.empty(sz.n_slabs, np.int32)
+            slab_end = np.empty(sz.n_slabs, np.int32)
+            runs = np.empty((sz.n_runs, 4), np.uint32)
+            rb_run_ptr = np.empty(sz.n_rowblocks + 1, np.int32)
+            lrow = np.empty(sz.n_lrow, np.uint16)
+            rc = lib.aks_pb_plan_export(plan, val.ctypes.data, lcol.ctypes.data, slab_begin.ctypes.data,
+                                        slab_end.ctypes.data, runs.ctypes.data, rb_run_ptr.ctypes.data,
+                                        lrow.ctypes.data)
+            _hip.check(rc, "aks_pb_plan_export")
+        finally:
+            lib.aks_pb_plan_destroy(plan)
+        narrow = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32}     # torch has no unsigned 16/32
+        up = lambda a: torch.from_numpy(a.view(narrow.get(a.dtype, a.dtype))).to(device)  # noqa: E731
+        self.val, self.lcol, self.lrow, self.runs = up(val), up(lcol), up(lrow), up(runs)
+        self.slab_begin, self.slab_end, self.rb_run_ptr = up(slab_begin), up(slab_end), up(rb_run_ptr)
+        self.prod = torch.zeros(int(sz.nnz_pad), dtype=torch.complex128, device=device)
+        self.n_slabs, self.n_rowblocks = int(sz.n_slabs), int(sz.n_rowblocks)
+        self.levels_per_round = float(((runs[::_hip.PB_RUNS_PER_ROUND, 1] >> 8) & 255).mean()) if len(runs) else 0.0
         d = _hip.PbMatrix()
-        d.n_rows, d.n_cols, d.nnz, d.n_chunks = n_rows, n_cols, nnz, n_chunks
-        d.n_slabs, d.n_rowblocks, d.values_complex, d.pad_ = n_slabs, n_rb, cplx, 0
-        d.d_val, d.d_lcol, d.d_dest, d.d_lrow = (t.data_ptr() for t in (self.val, self.lcol, self.dest, self.lrow))
-        d.d_rb_ptr, d.d_slab_ptr = self.rb_ptr.data_ptr(), self.slab_ptr.data_ptr()
-        d.d_chunk_begin, d.d_chunk_slab = self.chunk_begin.data_ptr(), self.chunk_slab.data_ptr()
-        d.d_prod = self.prod.data_ptr()
+        d.n_rows, d.n_cols, d.nnz, d.nnz_pad = n_rows, n_cols, nnz, int(sz.nnz_pad)
+        d.n_runs, d.n_lrow = int(sz.n_runs), int(sz.n_lrow)
+        d.n_slabs, d.n_rowblocks, d.values_complex, d.pad_ = int(sz.n_slabs), int(sz.n_rowblocks), cplx, 0
+        d.d_val, d.d_lcol, d.d_lrow, d.d_runs = (t.data_ptr() for t in (self.val, self.lcol, self.lrow, self.runs))
+        d.d_slab_begin, d.d_slab_end = self.slab_begin.data_ptr(), self.slab_end.data_ptr()
+        d.d_rb_run_ptr, d.d_prod = self.rb_run_ptr.data_ptr(), self.prod.data_ptr()
         self.desc = d
 
-    def moved_bytes(self):
-        """Bytes the two phases stream per SpMV (excluding x and y): 8|16 + 2 + 4 + 16 written,
-        then 16 + 2 read, per non-zero."""
-        per = (16 if self.desc.values_complex else 8) + 2 + 4 + 16 + 16 + 2
-        return per * int(self.desc.nnz)
+    def moved_bytes(self, real=False):
+        """Bytes the two phases stream per SpMV (excluding x and y): value + 2-byte column read and the
+        product written in phase 1; product + 2-byte (level, row) word + run descriptors read in phase 2."""
+        d = self.desc
+        v, pr = (16 if d.values_complex else 8), (8 if real else 16)
+        return (v + 2 + pr) * int(d.nnz_pad) + (pr + 2) * int(d.nnz) + 16 * int(d.n_runs)
 
 
 class Workspace:

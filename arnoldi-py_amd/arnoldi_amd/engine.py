@@ -59,6 +59,22 @@ class CsrOperator:
         self.dtype = rows.dtype
         if self.real and np.iscomplexobj(rows.data):
             raise ValueError("real arithmetic needs a real matrix")
+        if world > 1:
+            # Every rank must describe the same partition of the same matrix BEFORE the first data-path
+            # collective: ranks that disagree would otherwise die inside the all-to-all of the ghost plan
+            # ("collective mismatch") instead of getting an error message.  One small all-gather.
+            mine = np.concatenate([self.offsets, [rows.shape[0], rows.shape[1]]]).astype(np.int64)
+            views = comm.allgather_int64(mine)
+            for r, theirs in enumerate(views):
+                ok = (len(theirs) == len(mine) and np.array_equal(theirs[:-2], mine[:-2])
+                      and theirs[-1] == mine[-1] and theirs[-2] == theirs[r + 1] - theirs[r])
+                if not ok:
+                    raise ValueError(
+                        f"row shards disagree: rank {r} has offsets {list(map(int, theirs[:-2]))} and a "
+                        f"{int(theirs[-2])} x {int(theirs[-1])} block, rank {rank} has offsets "
+                        f"{list(map(int, mine[:-2]))} and a {rows.shape[0]} x {rows.shape[1]} block")
+            if rows.shape[1] != self.n or len(self.offsets) != world + 1:
+                raise ValueError(f"shard of shape {rows.shape} does not fit offsets {self.offsets.tolist()}")
         if world == 1:
             self.diag = dev.DeviceCSR(rows, device)
             self.spmv_form = self.diag.autotune(force=force, real=self.real)
@@ -185,6 +201,7 @@ class ArnoldiContext:
         self._graphs = {}
         # look-ahead operator application (see expand): off with AKS_LOOKAHEAD=0
         self.allow_lookahead = os.environ.get("AKS_LOOKAHEAD", "1") != "0"
+        self.lazy_third = False     # multi-rank: third all-reduce only when a second pass can have fired
         self._look = None           # scratch column holding A V[:, end] of the last expansion
         self._look_valid = False
         self.lookahead_applies = 0  # operator applications issued ahead of time (the last one of a solve is unused)
@@ -298,6 +315,14 @@ class ArnoldiContext:
             H[:rows, j] = Hd[:rows, j]
         self.last_ctrl = ctrl
         return n_iter
+
+    def collectives_per_step(self):
+        """Data-path collectives one Arnoldi step issues on the multi-rank path (0 on one GPU): the ghost
+        exchange of the SpMV plus the all-reduces between the Gram-Schmidt stages."""
+        if self.comm is None or not self.comm.active:
+            return 0
+        exchange = 1 if getattr(self.op, "any_exchange", False) else 0
+        return exchange + (2 if self.lazy_third else 3)
 
     # -- seam 2 ------------------------------------------------------------------
     def truncate(self, Qp, m, p):

@@ -11,9 +11,9 @@
 //   k_proj<NC>      tall-skinny  V[:, c0:c0+NC]^H w  with one lane per row and NC
 //                   complex accumulators per lane (exact NC: no masked loads), plus
 //                   ||w||^2.                            (ortho.py:92-94, 102)
-//   k_pb_phase1/2   the same operator for matrices without column locality: products are
-//                   formed slab by slab (x slab L2-resident) and written in row-block order,
-//                   then summed per 1024-row block from LDS.
+//   k_pb_phase1/2   the same operator for matrices without column locality: products are formed
+//                   sub-slab by sub-slab (8192 x entries staged in LDS) and written sequentially,
+//                   then summed per 8192-row block in LDS (levels + barriers keep the order fixed).
 //   k_update_proj<NC>  w -= V h fused with the re-projection V^H w and ||w||^2: the
 //                   row's NC panel entries stay in registers between the two uses,
 //                   so the panel is read once instead of twice.   (ortho.py:96-98,102)
@@ -35,6 +35,8 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <algorithm>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -697,181 +699,177 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int64_t count, const int32_t *
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) dst[i] = src[idx[i]];
 }
 
-// ------------------------------------------------------------------ slab-binned two-phase SpMV
-constexpr int PB_SLAB_BITS = AKS_PB_SLAB_BITS;
-constexpr int PB_RB_BITS = AKS_PB_ROWBLOCK_BITS;
-constexpr int PB_RB = 1 << PB_RB_BITS;
-constexpr int PB_CHUNK = AKS_PB_CHUNK_NNZ;
-constexpr int PB_PER_THREAD = PB_CHUNK / BLOCK;
+// ------------------------------------------------------------------ tile-binned two-phase SpMV
+// (include/arnoldi_hip.h, "tile-binned two-phase SpMV"; measurements behind the shape of both kernels:
+// profiles/microbench/tile_binned_spmv.hip, vmem_issue_cost.hip)
+constexpr int PB_CW_BITS = AKS_PB_SLAB_BITS, PB_CW = 1 << PB_CW_BITS;       // columns per sub-slab
+constexpr int PB_RB_BITS = AKS_PB_ROWBLOCK_BITS, PB_RB = 1 << PB_RB_BITS;   // rows per row block
+constexpr int PB_W = AKS_PB_WAVES, PB_K = AKS_PB_RUNS_PER_WAVE, PB_RPR = PB_W * PB_K;
+constexpr int PB_D = 4;                      // rounds of products in flight per wave (the words of a round are needed one step earlier)
+constexpr int PB_B = 8;                      // rounds whose descriptors one vector load fetches (PB_B * PB_K lanes)
+constexpr int PB_P1_THREADS = 1024, PB_P1_U = 4;
+constexpr int PB_STAGE = PB_RPR * AKS_PB_RUN_MAX;   // (level, row) words of one round, at most
+static_assert(PB_CW_BITS <= 13 && PB_RB_BITS <= 13, "lcol / lrow are 13-bit fields");
+static_assert(PB_B % PB_D == 0 && (PB_B & 1) == 0 && PB_B * PB_K <= 64, "descriptor block: even, multiple of the depth");
+static_assert(PB_W * 64 * 4 >= PB_STAGE, "one 8-byte load per lane must cover a round's words");
 
-// Phase 1: prod[dest[k]] = val[k] * x[slab*65536 + lcol[k]] for the chunk's entries.
-// Chunks are dealt so that the workgroups of one XCD (blockIdx % 8, observed placement; speed
-// only) walk a contiguous range of slabs: the slab's 1 MiB of x stays in that XCD's L2.
-template <typename VT>
-__global__ __launch_bounds__(BLOCK) void k_pb_phase1(int64_t n_chunks, int64_t chunks_per_xcd,
-                                                    const int32_t *__restrict__ chunk_begin,
-                                                    const int32_t *__restrict__ chunk_slab,
-                                                    const int32_t *__restrict__ slab_ptr,
-                                                    const VT *__restrict__ val, const uint16_t *__restrict__ lcol,
-                                                    const int32_t *__restrict__ dest, const c128 *__restrict__ x,
-                                                    c128 *__restrict__ prod, const aks_ctrl *__restrict__ ctrl) {
-    if (ctrl != nullptr && ctrl->broken) return;
-    const int64_t c = (int64_t)(blockIdx.x & 7) * chunks_per_xcd + (blockIdx.x >> 3);
-    if ((int64_t)(blockIdx.x >> 3) >= chunks_per_xcd || c >= n_chunks) return;
-    const int slab = chunk_slab[c];
-    const int b = chunk_begin[c];
-    const int e = min(b + PB_CHUNK, slab_ptr[slab + 1]);
-    const c128 *xs = x + ((int64_t)slab << PB_SLAB_BITS);
-    int lc[PB_PER_THREAD], d[PB_PER_THREAD];
-    VT a[PB_PER_THREAD];
-    c128 xv[PB_PER_THREAD];
-#pragma unroll
-    for (int q = 0; q < PB_PER_THREAD; ++q) {
-        const int k = min(b + q * BLOCK + (int)threadIdx.x, e - 1);
-        lc[q] = lcol[k];
-        a[q] = val[k];
-        d[q] = dest[k];
-    }
-#pragma unroll
-    for (int q = 0; q < PB_PER_THREAD; ++q) xv[q] = xs[lc[q]];
-#pragma unroll
-    for (int q = 0; q < PB_PER_THREAD; ++q)
-        if (b + q * BLOCK + (int)threadIdx.x < e) prod[d[q]] = cmul(a[q], xv[q]);
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_stream(c128 v, c128 *p) {      // written once, read by another kernel
+    v2d t; t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<v2d *>(p));
 }
+__device__ __forceinline__ void store_stream(double v, double *p) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ double cmul(double a, double x) { return a * x; }
 
-// Phase 2: one wave per block of 1024 rows; its products are one contiguous range.  Sums go
-// through LDS float64 atomics issued by that wave only, in program order, so the result does
-// not depend on timing.
-template <bool ACC>
-__global__ __launch_bounds__(BLOCK) void k_pb_phase2(int64_t n_rows, int n_rowblocks,
-                                                    const int32_t *__restrict__ rb_ptr,
-                                                    const uint16_t *__restrict__ lrow,
-                                                    const c128 *__restrict__ prod, c128 *__restrict__ y,
-                                                    const aks_ctrl *__restrict__ ctrl) {
+// Phase 1: prod[k] = val[k] * x[slab * 8192 + lcol[k]] for the sub-slab's entries; x slice in LDS.
+// VT: value type (double | c128), XT: vector entry type (c128 | double for real-packed vectors).
+template <typename VT, typename XT>
+__global__ __launch_bounds__(PB_P1_THREADS) void k_pb_phase1(int64_t n_cols, const int32_t *__restrict__ slab_begin,
+                                                            const int32_t *__restrict__ slab_end,
+                                                            const VT *__restrict__ val, const uint16_t *__restrict__ lcol,
+                                                            const XT *__restrict__ x, XT *__restrict__ prod,
+                                                            const aks_ctrl *__restrict__ ctrl) {
     if (ctrl != nullptr && ctrl->broken) return;
-    __shared__ double acc_re[WAVES][PB_RB], acc_im[WAVES][PB_RB];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rb = blockIdx.x * WAVES + wave;
-    if (rb >= n_rowblocks) return;  // waves are independent
-    double *are = acc_re[wave], *aim = acc_im[wave];
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
+    XT *xs = reinterpret_cast<XT *>(pb_smem);
+    const int s = blockIdx.x;
+    const int64_t c0 = (int64_t)s << PB_CW_BITS;
+    const int cw = (int)min((int64_t)PB_CW, n_cols - c0);
+    for (int i = threadIdx.x; i < cw; i += PB_P1_THREADS) xs[i] = x[c0 + i];
+    __syncthreads();
+    const int k0 = slab_begin[s], k1 = (slab_end[s] + 7) & ~7;       // pad slots hold val = 0, lcol = 0
+    for (int base = k0; base < k1; base += PB_P1_THREADS * PB_P1_U) {
+        VT a[PB_P1_U];
+        int c[PB_P1_U];
 #pragma unroll
-    for (int q = 0; q < PB_RB / 64; ++q) { are[q * 64 + lane] = 0.0; aim[q * 64 + lane] = 0.0; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int k0 = rb_ptr[rb], k1 = rb_ptr[rb + 1];
-    constexpr int U = 8;
-    for (int base = k0; base < k1; base += 64 * U) {
-        c128 p[U];
-        int r[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = min(base + u * 64 + lane, k1 - 1);
-            p[u] = prod[k];
-            r[u] = lrow[k];
+        for (int u = 0; u < PB_P1_U; ++u) {
+            const int k = min(base + u * PB_P1_THREADS + (int)threadIdx.x, k1 - 1);
+            a[u] = val[k];
+            c[u] = lcol[k];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (base + u * 64 + lane < k1) {
-                unsafeAtomicAdd(&are[r[u]], p[u].x);
-                unsafeAtomicAdd(&aim[r[u]], p[u].y);
+        for (int u = 0; u < PB_P1_U; ++u) {
+            const int k = base + u * PB_P1_THREADS + (int)threadIdx.x;
+            if (k < k1) store_stream(cmul(a[u], xs[c[u]]), &prod[k]);
+        }
+    }
+}
+
+__device__ __forceinline__ void pb_lds_barrier() {
+    // LDS-only release/acquire + barrier: loads already in flight (the product prefetch) stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void pb_acc_add(double *acc, int row, c128 p) {
+    unsafeAtomicAdd(&acc[row], p.x);
+    unsafeAtomicAdd(&acc[PB_RB + row], p.y);
+}
+__device__ __forceinline__ void pb_acc_add(double *acc, int row, double p) { unsafeAtomicAdd(&acc[row], p); }
+__device__ __forceinline__ c128 pb_acc_get(const double *acc, int i, c128) { return make_double2(acc[i], acc[PB_RB + i]); }
+__device__ __forceinline__ double pb_acc_get(const double *acc, int i, double) { return acc[i]; }
+__device__ __forceinline__ c128 pb_sum(c128 a, c128 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double pb_sum(double a, double b) { return a + b; }
+template <typename XT> __device__ __forceinline__ XT pb_zero();
+template <> __device__ __forceinline__ c128 pb_zero<c128>() { return make_double2(0.0, 0.0); }
+template <> __device__ __forceinline__ double pb_zero<double>() { return 0.0; }
+
+// Phase 2: one workgroup per row block.  Software pipeline per wave, one step per round:
+//   descriptors (a block of 16 rounds per vector load, one block ahead, broadcast with v_readlane)
+//   -> products + the round's (level, row) words (PB_D rounds ahead, unconditional loads so that the
+//      compiler's s_waitcnt counts stay exact) -> words through LDS (written one step before use)
+//   -> LDS adds level by level, workgroup barrier after each level.
+template <typename XT, bool ACC>
+__global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_rb, int rb_per_xcd,
+                                                        const int32_t *__restrict__ rb_run_ptr,
+                                                        const uint4 *__restrict__ runs,
+                                                        const uint16_t *__restrict__ lrow,
+                                                        const XT *__restrict__ prod, XT *__restrict__ y,
+                                                        const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl != nullptr && ctrl->broken) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
+    constexpr int T = PB_W * 64, NACC = PB_RB * (int)(sizeof(XT) / sizeof(double));
+    double *acc = reinterpret_cast<double *>(pb_smem);                      // re plane [, im plane]
+    uint16_t *stage = reinterpret_cast<uint16_t *>(acc + NACC);            // 2 buffers of PB_STAGE words
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // consecutive row blocks on one XCD (blockIdx % 8, observed placement; speed only): their runs are
+    // neighbours in memory, so the lines two of them share are fetched once into that XCD's L2
+    if ((int)(blockIdx.x >> 3) >= rb_per_xcd) return;
+    const int rb = (blockIdx.x & 7) * rb_per_xcd + (blockIdx.x >> 3);
+    if (rb >= n_rb) return;
+    for (int i = threadIdx.x; i < NACC; i += T) acc[i] = 0.0;
+    const int R0 = rb_run_ptr[rb];
+    const int n_rounds = (rb_run_ptr[rb + 1] - R0) / PB_RPR;
+    const uint4 *my_runs = runs + R0 + wave * PB_K;
+    auto load_block = [&](int first_round) {
+        const int l = lane & (PB_B * PB_K - 1);
+        const int round = first_round + l / PB_K;
+        uint4 v = my_runs[(size_t)min(round, max(n_rounds - 1, 0)) * PB_RPR + l % PB_K];
+        if (round >= n_rounds) v = make_uint4(0u, 0u, 0u, 0u);
+        return v;
+    };
+    XT p[PB_D][PB_K];
+    unsigned info[PB_D][PB_K], lcount[PB_D];
+    uint2 words[PB_D];
+#pragma unroll
+    for (int d = 0; d < PB_D; ++d) {
+        lcount[d] = 0u;
+        words[d] = make_uint2(0u, 0u);
+#pragma unroll
+        for (int k = 0; k < PB_K; ++k) { info[d][k] = 0u; p[d][k] = pb_zero<XT>(); }
+    }
+    uint4 dv, dvn = load_block(0);
+    pb_lds_barrier();
+    // Whole blocks of PB_B steps, with NO branch around any load: steps past the last round work on
+    // all-zero descriptors (no adds; their loads re-read entry 0).  A guard here would make the
+    // compiler's s_waitcnt placement fall back to vmcnt(0) and serialise the prefetch.
+    const int n_steps = n_rounds + PB_D;
+    for (int i0 = 0; i0 < n_steps; i0 += PB_B) {
+        dv = dvn;
+        dvn = load_block(i0 + PB_B);
+#pragma unroll
+        for (int j = 0; j < PB_B; ++j) {
+            constexpr int D = PB_D;
+            const int d = j % D, dn = (j + 1) % D;
+            // stage d holds round C = i0 + j - D, stage dn round C + 1; (level, row) words of round X live
+            // in staging buffer X & 1 (i0 is a multiple of the even PB_B, so parities follow j)
+            uint16_t *buf_c = stage + ((j + D) & 1) * PB_STAGE, *buf_n = stage + ((j + D + 1) & 1) * PB_STAGE;
+            const int w4 = (wave * 64 + lane) * 4;
+            if (w4 < (int)lcount[dn]) *reinterpret_cast<uint2 *>(buf_n + w4) = words[dn];   // for the next step
+            unsigned m[PB_K];
+#pragma unroll
+            for (int k = 0; k < PB_K; ++k) {
+                const int len = (int)(info[d][k] & 255u);
+                m[k] = lane < len ? (unsigned)buf_c[(info[d][k] >> 16) + lane] : 0xffffu;
+            }
+            const int nph = max((int)((info[d][0] >> 8) & 255u), 1);
+            for (int ph = 0; ph < nph; ++ph) {
+#pragma unroll
+                for (int k = 0; k < PB_K; ++k)
+                    if (lane < (int)(info[d][k] & 255u) && (int)(m[k] >> 13) == ph)
+                        pb_acc_add(acc, (int)(m[k] & (PB_RB - 1)), p[d][k]);
+                pb_lds_barrier();
+            }
+            // issue round i0 + j into stage d: its words first (they are needed one step before its products)
+            const unsigned lb = __builtin_amdgcn_readlane(dv.z, j * PB_K);
+            lcount[d] = __builtin_amdgcn_readlane(dv.w, j * PB_K);
+            const unsigned wmax = (max(lcount[d], 1u) - 1u) & ~3u;     // last 4-word group of the block
+            words[d] = *reinterpret_cast<const uint2 *>(lrow + lb + min((unsigned)w4, wmax));
+#pragma unroll
+            for (int k = 0; k < PB_K; ++k) {
+                const unsigned start = __builtin_amdgcn_readlane(dv.x, j * PB_K + k);
+                const unsigned inf = __builtin_amdgcn_readlane(dv.y, j * PB_K + k);
+                info[d][k] = inf;
+                p[d][k] = prod[start + min((unsigned)lane, max(inf & 255u, 1u) - 1u)];
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int64_t row0 = (int64_t)rb << PB_RB_BITS;
-#pragma unroll 4
-    for (int q = 0; q < PB_RB / 64; ++q) {
-        const int i = q * 64 + lane;
-        const int64_t row = row0 + i;
-        if (row < n_rows) {
-            double sr = are[i], si = aim[i];
-            if (ACC) {
-                const c128 old = y[row];
-                sr += old.x;
-                si += old.y;
-            }
-            y[row] = make_double2(sr, si);
+    for (int i = threadIdx.x; i < PB_RB; i += T) {
+        if (row0 + i < n_rows) {
+            XT v = pb_acc_get(acc, i, XT());
+            if (ACC) v = pb_sum(v, y[row0 + i]);
+            y[row0 + i] = v;
         }
-    }
-}
-
-// The two phases for real vectors (x, y, products float64).
-__global__ __launch_bounds__(BLOCK) void k_pb_phase1_real(int64_t n_chunks, int64_t chunks_per_xcd,
-                                                         const int32_t *__restrict__ chunk_begin,
-                                                         const int32_t *__restrict__ chunk_slab,
-                                                         const int32_t *__restrict__ slab_ptr,
-                                                         const double *__restrict__ val,
-                                                         const uint16_t *__restrict__ lcol,
-                                                         const int32_t *__restrict__ dest,
-                                                         const double *__restrict__ x, double *__restrict__ prod,
-                                                         const aks_ctrl *__restrict__ ctrl) {
-    if (ctrl != nullptr && ctrl->broken) return;
-    const int64_t c = (int64_t)(blockIdx.x & 7) * chunks_per_xcd + (blockIdx.x >> 3);
-    if ((int64_t)(blockIdx.x >> 3) >= chunks_per_xcd || c >= n_chunks) return;
-    const int slab = chunk_slab[c];
-    const int b = chunk_begin[c];
-    const int e = min(b + PB_CHUNK, slab_ptr[slab + 1]);
-    const double *xs = x + ((int64_t)slab << PB_SLAB_BITS);
-    int lc[PB_PER_THREAD], d[PB_PER_THREAD];
-    double a[PB_PER_THREAD], xv[PB_PER_THREAD];
-#pragma unroll
-    for (int q = 0; q < PB_PER_THREAD; ++q) {
-        const int k = min(b + q * BLOCK + (int)threadIdx.x, e - 1);
-        lc[q] = lcol[k];
-        a[q] = val[k];
-        d[q] = dest[k];
-    }
-#pragma unroll
-    for (int q = 0; q < PB_PER_THREAD; ++q) xv[q] = xs[lc[q]];
-#pragma unroll
-    for (int q = 0; q < PB_PER_THREAD; ++q)
-        if (b + q * BLOCK + (int)threadIdx.x < e) prod[d[q]] = a[q] * xv[q];
-}
-
-template <bool ACC>
-__global__ __launch_bounds__(BLOCK) void k_pb_phase2_real(int64_t n_rows, int n_rowblocks,
-                                                         const int32_t *__restrict__ rb_ptr,
-                                                         const uint16_t *__restrict__ lrow,
-                                                         const double *__restrict__ prod, double *__restrict__ y,
-                                                         const aks_ctrl *__restrict__ ctrl) {
-    if (ctrl != nullptr && ctrl->broken) return;
-    __shared__ double acc_re[WAVES][PB_RB];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rb = blockIdx.x * WAVES + wave;
-    if (rb >= n_rowblocks) return;
-    double *are = acc_re[wave];
-#pragma unroll
-    for (int q = 0; q < PB_RB / 64; ++q) are[q * 64 + lane] = 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int k0 = rb_ptr[rb], k1 = rb_ptr[rb + 1];
-    constexpr int U = 8;
-    for (int base = k0; base < k1; base += 64 * U) {
-        double p[U];
-        int r[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = min(base + u * 64 + lane, k1 - 1);
-            p[u] = prod[k];
-            r[u] = lrow[k];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (base + u * 64 + lane < k1) unsafeAtomicAdd(&are[r[u]], p[u]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int64_t row0 = (int64_t)rb << PB_RB_BITS;
-#pragma unroll 4
-    for (int q = 0; q < PB_RB / 64; ++q) {
-        const int i = q * 64 + lane;
-        const int64_t row = row0 + i;
-        if (row < n_rows) y[row] = ACC ? y[row] + are[i] : are[i];
     }
 }
 
@@ -1019,6 +1017,68 @@ struct Probe {
         return stop[used++];
     }
 };
+
+// ---- tile-binned SpMV: host-side plan and launcher
+struct PbPlan {
+    aks_pb_sizes sz;
+    int32_t values_complex;
+    std::vector<double> val;             // nnz_pad (x2 if complex)
+    std::vector<uint16_t> lcol, lrow;
+    std::vector<int32_t> slab_begin, slab_end, rb_run_ptr;
+    std::vector<aks_pb_run> runs;
+};
+
+int check_pb(const aks_pb_matrix *A, const void *x, const void *y) {
+    if (A == nullptr || x == nullptr || y == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    if (A->n_rows <= 0 || A->n_cols <= 0 || A->nnz < 0 || A->nnz_pad < 8 || A->n_runs < 1 || A->n_lrow < 8)
+        return fail(AKS_ERR_ARG, "bad sizes");
+    if (A->n_slabs != (int32_t)((A->n_cols + PB_CW - 1) >> PB_CW_BITS) ||
+        A->n_rowblocks != (int32_t)((A->n_rows + PB_RB - 1) >> PB_RB_BITS))
+        return fail(AKS_ERR_ARG, "n_slabs / n_rowblocks do not match the shape");
+    if (!A->d_val || !A->d_lcol || !A->d_slab_begin || !A->d_slab_end || !A->d_runs || !A->d_rb_run_ptr ||
+        !A->d_lrow || !A->d_prod)
+        return fail(AKS_ERR_ARG, "null array in aks_pb_matrix");
+    if ((reinterpret_cast<uintptr_t>(A->d_lrow) & 7) || (reinterpret_cast<uintptr_t>(A->d_runs) & 15) ||
+        (reinterpret_cast<uintptr_t>(A->d_prod) & 15))
+        return fail(AKS_ERR_ARG, "d_lrow / d_runs / d_prod are not 8 / 16 / 16-byte aligned");
+    if (x == y) return fail(AKS_ERR_ARG, "x and y must not alias");
+    return AKS_OK;
+}
+
+// dynamic LDS above the default limit has to be allowed once per kernel (one process drives one GPU)
+template <typename K> int allow_lds(K kernel, size_t bytes, bool *done) {
+    if (*done) return AKS_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(binned SpMV)");
+    *done = true;
+    return AKS_OK;
+}
+
+template <typename VT, typename XT>
+int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const aks_ctrl *ctrl, hipStream_t s) {
+    XT *prod = reinterpret_cast<XT *>(A->d_prod);       // real vectors use the first 8 nnz_pad bytes
+    const size_t lds1 = (size_t)PB_CW * sizeof(XT);
+    const size_t lds2 = (size_t)PB_RB * sizeof(XT) + 2 * PB_STAGE * sizeof(uint16_t);
+    static bool ok1 = false, ok2a = false, ok2b = false;
+    int rc = allow_lds(k_pb_phase1<VT, XT>, lds1, &ok1);
+    if (rc == AKS_OK) rc = allow_lds(k_pb_phase2<XT, true>, lds2, &ok2a);
+    if (rc == AKS_OK) rc = allow_lds(k_pb_phase2<XT, false>, lds2, &ok2b);
+    if (rc != AKS_OK) return rc;
+    if (A->nnz > 0)
+        hipLaunchKernelGGL((k_pb_phase1<VT, XT>), dim3((unsigned)A->n_slabs), dim3(PB_P1_THREADS), lds1, s, A->n_cols,
+                           A->d_slab_begin, A->d_slab_end, static_cast<const VT *>(A->d_val), A->d_lcol, x, prod, ctrl);
+    const int rbx = (A->n_rowblocks + 7) / 8;
+    const uint4 *runs = reinterpret_cast<const uint4 *>(A->d_runs);
+    if (accumulate)
+        hipLaunchKernelGGL((k_pb_phase2<XT, true>), dim3((unsigned)(rbx * 8)), dim3(PB_W * 64), lds2, s, A->n_rows,
+                           A->n_rowblocks, rbx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
+    else
+        hipLaunchKernelGGL((k_pb_phase2<XT, false>), dim3((unsigned)(rbx * 8)), dim3(PB_W * 64), lds2, s, A->n_rows,
+                           A->n_rowblocks, rbx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
+    AKS_CHECK_LAUNCH("aks_pb_spmv");
+    return AKS_OK;
+}
 
 }  // namespace
 
@@ -1213,196 +1273,189 @@ int aks_dgks_gs(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks
     return aks_gs_finish(n_rows, J, d_w, d_Hcol, ldh, tol, eta, normalize, d_ws, ws_bytes, max_dim, stream);
 }
 
-// ---- slab-binned form: host planner -------------------------------------------------------
-int aks_pb_params(int32_t *slab_bits, int32_t *rowblock_bits, int32_t *chunk_nnz) {
-    if (!slab_bits || !rowblock_bits || !chunk_nnz) return fail(AKS_ERR_ARG, "null pointer");
-    *slab_bits = PB_SLAB_BITS;
+// ---- tile-binned form: host planner --------------------------------------------------------
+int aks_pb_params(int32_t *slab_bits, int32_t *rowblock_bits, int32_t *runs_per_round) {
+    if (!slab_bits || !rowblock_bits || !runs_per_round) return fail(AKS_ERR_ARG, "null pointer");
+    *slab_bits = PB_CW_BITS;
     *rowblock_bits = PB_RB_BITS;
-    *chunk_nnz = PB_CHUNK;
+    *runs_per_round = PB_RPR;
     return AKS_OK;
 }
 
-int64_t aks_pb_plan_count(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
-                          int32_t *slab_ptr_out) try {
-    if (!indptr || !indices || !slab_ptr_out) return fail(AKS_ERR_ARG, "null pointer");
-    if (n_rows <= 0 || n_cols <= 0 || n_rows >= INT32_MAX || n_cols >= INT32_MAX)
-        return fail(AKS_ERR_ARG, "matrix shape out of range");
-    const int64_t n_slabs = (n_cols + (1 << PB_SLAB_BITS) - 1) >> PB_SLAB_BITS;
+void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const void *values, int32_t values_complex,
+                         int64_t n_rows, int64_t n_cols, aks_pb_sizes *sizes) try {
+    if (!indptr || !indices || !values || !sizes) { fail(AKS_ERR_ARG, "null pointer"); return nullptr; }
+    if (n_rows <= 0 || n_cols <= 0 || n_rows >= INT32_MAX || n_cols >= INT32_MAX) {
+        fail(AKS_ERR_ARG, "matrix shape out of range");
+        return nullptr;
+    }
+    const int64_t n_ss = (n_cols + PB_CW - 1) >> PB_CW_BITS, n_rb = (n_rows + PB_RB - 1) >> PB_RB_BITS;
+    if (n_ss * n_rb > ((int64_t)1 << 26)) {        // (checked before any array is read)
+        fail(AKS_ERR_UNSUPPORTED, "too many (sub-slab, row block) tiles for the binned form");
+        return nullptr;
+    }
     const int64_t nnz = indptr[n_rows];
-    if (nnz < 0 || nnz > (int64_t)INT32_MAX - 2 * PB_CHUNK)   // 32-bit entry positions in the kernels
-        return fail(AKS_ERR_UNSUPPORTED, "too many non-zeros for the binned form");
-    std::vector<int64_t> cnt(n_slabs, 0);
-    for (int64_t k = 0; k < nnz; ++k) {
-        const int32_t c = indices[k];
-        if (c < 0 || c >= n_cols) return fail(AKS_ERR_ARG, "column index out of range");
-        ++cnt[c >> PB_SLAB_BITS];
+    if (nnz < 0 || nnz + 8 * n_ss > (int64_t)INT32_MAX - 64) {       // 32-bit entry positions in the kernels
+        fail(AKS_ERR_UNSUPPORTED, "too many non-zeros for the binned form");
+        return nullptr;
     }
-    int64_t acc = 0, chunks = 0;
-    for (int64_t s = 0; s < n_slabs; ++s) {
-        slab_ptr_out[s] = (int32_t)acc;
-        acc += cnt[s];
-        chunks += (cnt[s] + PB_CHUNK - 1) / PB_CHUNK;
-    }
-    slab_ptr_out[n_slabs] = (int32_t)acc;
-    return chunks;
-} catch (const std::exception &e) {
-    return fail(AKS_ERR_ARG, e.what());      // e.g. std::bad_alloc: nothing may cross the C boundary
-} catch (...) {
-    return fail(AKS_ERR_ARG, "unexpected C++ exception");
-}
-
-int aks_pb_plan_fill(const int32_t *indptr, const int32_t *indices, const void *values, int32_t values_complex,
-                     int64_t n_rows, int64_t n_cols, const int32_t *slab_ptr, void *val_out, uint16_t *lcol_out,
-                     int32_t *dest_out, uint16_t *lrow_out, int32_t *rb_ptr_out, int32_t *chunk_begin_out,
-                     int32_t *chunk_slab_out) try {
-    if (!indptr || !indices || !values || !slab_ptr || !val_out || !lcol_out || !dest_out || !lrow_out ||
-        !rb_ptr_out || !chunk_begin_out || !chunk_slab_out)
-        return fail(AKS_ERR_ARG, "null pointer");
-    const int64_t n_slabs = (n_cols + (1 << PB_SLAB_BITS) - 1) >> PB_SLAB_BITS;
-    const int64_t n_rb = (n_rows + PB_RB - 1) >> PB_RB_BITS;
-    const int64_t nnz = indptr[n_rows];
-    // tile (slab, rowblock) sizes; rows are visited in order, so entries keep (row, column) order
-    // inside a tile.  Visiting by row block keeps the counter array small: one row block at a time.
-    std::vector<int32_t> p1_next(n_slabs * n_rb + 1, 0);   // becomes the phase-1 write cursor per tile
-    {
-        std::vector<int32_t> &cnt = p1_next;
-        for (int64_t r = 0; r < n_rows; ++r) {
-            const int64_t rb = r >> PB_RB_BITS;
-            for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k)
-                ++cnt[(int64_t)(indices[k] >> PB_SLAB_BITS) * n_rb + rb];
-        }
-    }
-    // phase-2 start of every tile (order: rowblock-major) and rb_ptr
-    std::vector<int32_t> p2_next(n_slabs * n_rb, 0);
-    {
-        int64_t acc = 0;
-        for (int64_t rb = 0; rb < n_rb; ++rb) {
-            rb_ptr_out[rb] = (int32_t)acc;
-            for (int64_t s = 0; s < n_slabs; ++s) {
-                p2_next[s * n_rb + rb] = (int32_t)acc;
-                acc += p1_next[s * n_rb + rb];
-            }
-        }
-        rb_ptr_out[n_rb] = (int32_t)acc;
-        if (acc != nnz) return fail(AKS_ERR_ARG, "inconsistent CSR arrays");
-    }
-    // phase-1 start of every tile (order: slab-major) -- exclusive scan in place
-    {
-        int64_t acc = 0;
-        for (int64_t t = 0; t < n_slabs * n_rb; ++t) {
-            const int32_t c = p1_next[t];
-            p1_next[t] = (int32_t)acc;
-            acc += c;
-        }
-        for (int64_t s = 0; s <= n_slabs; ++s) {
-            const int64_t at = s < n_slabs ? p1_next[s * n_rb] : nnz;
-            if (at != slab_ptr[s]) return fail(AKS_ERR_ARG, "slab_ptr does not match the matrix");
-        }
-    }
-    const double *vr = static_cast<const double *>(values);
-    double *vo = static_cast<double *>(val_out);
+    PbPlan *P = new PbPlan();
+    std::unique_ptr<PbPlan> guard(P);
+    P->values_complex = values_complex ? 1 : 0;
+    // tile sizes
+    std::vector<int32_t> cnt(n_ss * n_rb, 0), start(n_ss * n_rb);
     for (int64_t r = 0; r < n_rows; ++r) {
         const int64_t rb = r >> PB_RB_BITS;
-        const uint16_t lr = (uint16_t)(r & (PB_RB - 1));
+        if (indptr[r + 1] < indptr[r]) { fail(AKS_ERR_ARG, "indptr is not monotone"); return nullptr; }
         for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
             const int32_t c = indices[k];
-            const int64_t t = (int64_t)(c >> PB_SLAB_BITS) * n_rb + rb;
-            const int32_t k1 = p1_next[t]++;
-            const int32_t k2 = p2_next[t]++;
-            lcol_out[k1] = (uint16_t)(c & ((1 << PB_SLAB_BITS) - 1));
-            dest_out[k1] = k2;
-            lrow_out[k2] = lr;
-            if (values_complex) {
-                vo[2 * (int64_t)k1] = vr[2 * (int64_t)k];
-                vo[2 * (int64_t)k1 + 1] = vr[2 * (int64_t)k + 1];
-            } else {
-                vo[k1] = vr[k];
+            if (c < 0 || c >= n_cols) { fail(AKS_ERR_ARG, "column index out of range"); return nullptr; }
+            ++cnt[(int64_t)(c >> PB_CW_BITS) * n_rb + rb];
+        }
+    }
+    // phase-1 order: (sub-slab, row block, row, column); a sub-slab's slots start on a multiple of 8
+    P->slab_begin.resize(n_ss);
+    P->slab_end.resize(n_ss);
+    int64_t pos = 0;
+    for (int64_t s = 0; s < n_ss; ++s) {
+        pos = (pos + 7) & ~(int64_t)7;
+        P->slab_begin[s] = (int32_t)pos;
+        for (int64_t rb = 0; rb < n_rb; ++rb) { start[s * n_rb + rb] = (int32_t)pos; pos += cnt[s * n_rb + rb]; }
+        P->slab_end[s] = (int32_t)pos;
+    }
+    const int64_t nnz_pad = std::max<int64_t>((pos + 7) & ~(int64_t)7, 8);
+    const int vw = values_complex ? 2 : 1;
+    P->val.assign((size_t)nnz_pad * vw, 0.0);
+    P->lcol.assign(nnz_pad, 0);
+    std::vector<uint16_t> row13(nnz_pad, 0);       // row inside its row block, phase-1 order
+    {
+        std::vector<int32_t> cur(start);
+        const double *vr = static_cast<const double *>(values);
+        for (int64_t r = 0; r < n_rows; ++r) {
+            const int64_t rb = r >> PB_RB_BITS;
+            for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
+                const int32_t c = indices[k];
+                const int32_t q = cur[(int64_t)(c >> PB_CW_BITS) * n_rb + rb]++;
+                P->lcol[q] = (uint16_t)(c & (PB_CW - 1));
+                row13[q] = (uint16_t)(r & (PB_RB - 1));
+                if (values_complex) {
+                    P->val[2 * (size_t)q] = vr[2 * (size_t)k];
+                    P->val[2 * (size_t)q + 1] = vr[2 * (size_t)k + 1];
+                } else {
+                    P->val[q] = vr[k];
+                }
             }
         }
     }
-    int64_t c = 0;
-    for (int64_t s = 0; s < n_slabs; ++s)
-        for (int32_t b = slab_ptr[s]; b < slab_ptr[s + 1]; b += PB_CHUNK) {
-            chunk_begin_out[c] = b;
-            chunk_slab_out[c] = (int32_t)s;
-            ++c;
+    // phase-2 schedule: runs, rounds, levels
+    P->rb_run_ptr.resize(n_rb + 1);
+    std::vector<uint8_t> seen(PB_RB, 0);
+    std::vector<int64_t> stamp(PB_RB, -1);
+    int64_t round_id = 0;
+    for (int64_t rb = 0; rb < n_rb; ++rb) {
+        P->rb_run_ptr[rb] = (int32_t)P->runs.size();
+        const size_t first = P->runs.size();
+        for (int64_t s = 0; s < n_ss; ++s) {
+            const int32_t c = cnt[s * n_rb + rb], q0 = start[s * n_rb + rb];
+            for (int32_t o = 0; o < c; o += AKS_PB_RUN_MAX) {
+                aks_pb_run run = {(uint32_t)(q0 + o), (uint32_t)std::min<int32_t>(AKS_PB_RUN_MAX, c - o), 0u, 0u};
+                P->runs.push_back(run);
+            }
         }
-    return AKS_OK;
+        while ((P->runs.size() - first) % PB_RPR) P->runs.push_back(aks_pb_run{0u, 0u, 0u, 0u});
+        for (size_t rr = first; rr < P->runs.size(); rr += PB_RPR, ++round_id) {
+            // which waves touch each row in this round (slot j of the round belongs to wave j / PB_K)
+            for (int j = 0; j < PB_RPR; ++j) {
+                const aks_pb_run &run = P->runs[rr + j];
+                for (uint32_t i = 0; i < run.info; ++i) {
+                    const int row = row13[run.start + i];
+                    if (stamp[row] != round_id) { stamp[row] = round_id; seen[row] = 0; }
+                    seen[row] |= (uint8_t)(1u << (j / PB_K));
+                }
+            }
+            const uint32_t lbase = (uint32_t)P->lrow.size();
+            uint32_t off = 0, levels = 1;
+            for (int j = 0; j < PB_RPR; ++j) {
+                aks_pb_run &run = P->runs[rr + j];
+                const uint32_t len = run.info, w = (uint32_t)(j / PB_K);
+                for (uint32_t i = 0; i < len; ++i) {
+                    const int row = row13[run.start + i];
+                    // level = waves with a smaller index that add to this row in this round: entries of one
+                    // row then run in wave order, one barrier-separated level per wave (<= PB_W - 1 = 7)
+                    const uint32_t lv = (uint32_t)__builtin_popcount(seen[row] & ((1u << w) - 1u));
+                    P->lrow.push_back((uint16_t)(row | (lv << 13)));
+                    levels = std::max(levels, lv + 1);
+                }
+                run.info = len | (off << 16);
+                off += len;
+            }
+            while (P->lrow.size() & 3) P->lrow.push_back(0);
+            for (int j = 0; j < PB_RPR; ++j) {
+                aks_pb_run &run = P->runs[rr + j];
+                run.info |= levels << 8;
+                run.lbase = lbase;
+                run.lcount = off;
+            }
+        }
+    }
+    P->rb_run_ptr[n_rb] = (int32_t)P->runs.size();
+    if (P->runs.size() >= (size_t)INT32_MAX || P->lrow.size() >= (size_t)UINT32_MAX - 8) {
+        fail(AKS_ERR_UNSUPPORTED, "binned form: schedule too large");
+        return nullptr;
+    }
+    while (P->lrow.size() < 8) P->lrow.push_back(0);           // padding rounds read lrow[0 .. 3]
+    if (P->runs.empty()) P->runs.push_back(aks_pb_run{0u, 0u, 0u, 0u});
+    P->sz.nnz_pad = nnz_pad;
+    P->sz.n_runs = (int64_t)P->runs.size();
+    P->sz.n_lrow = (int64_t)P->lrow.size();
+    P->sz.n_slabs = (int32_t)n_ss;
+    P->sz.n_rowblocks = (int32_t)n_rb;
+    *sizes = P->sz;
+    return guard.release();
 } catch (const std::exception &e) {
-    return fail(AKS_ERR_ARG, e.what());      // e.g. std::bad_alloc: nothing may cross the C boundary
+    fail(AKS_ERR_ARG, e.what());      // e.g. std::bad_alloc: nothing may cross the C boundary
+    return nullptr;
 } catch (...) {
-    return fail(AKS_ERR_ARG, "unexpected C++ exception");
+    fail(AKS_ERR_ARG, "unexpected C++ exception");
+    return nullptr;
 }
+
+int aks_pb_plan_export(const void *plan, void *val_out, uint16_t *lcol_out, int32_t *slab_begin_out,
+                       int32_t *slab_end_out, aks_pb_run *runs_out, int32_t *rb_run_ptr_out, uint16_t *lrow_out) {
+    const PbPlan *P = static_cast<const PbPlan *>(plan);
+    if (!P || !val_out || !lcol_out || !slab_begin_out || !slab_end_out || !runs_out || !rb_run_ptr_out || !lrow_out)
+        return fail(AKS_ERR_ARG, "null pointer");
+    memcpy(val_out, P->val.data(), P->val.size() * sizeof(double));
+    memcpy(lcol_out, P->lcol.data(), P->lcol.size() * sizeof(uint16_t));
+    memcpy(slab_begin_out, P->slab_begin.data(), P->slab_begin.size() * sizeof(int32_t));
+    memcpy(slab_end_out, P->slab_end.data(), P->slab_end.size() * sizeof(int32_t));
+    memcpy(runs_out, P->runs.data(), P->runs.size() * sizeof(aks_pb_run));
+    memcpy(rb_run_ptr_out, P->rb_run_ptr.data(), P->rb_run_ptr.size() * sizeof(int32_t));
+    memcpy(lrow_out, P->lrow.data(), P->lrow.size() * sizeof(uint16_t));
+    return AKS_OK;
+}
+
+void aks_pb_plan_destroy(void *plan) { delete static_cast<PbPlan *>(plan); }
 
 int aks_pb_spmv(const aks_pb_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate, const void *d_ws,
                 void *stream) {
-    if (A == nullptr || d_x == nullptr || d_y == nullptr) return fail(AKS_ERR_ARG, "null pointer");
-    if (A->n_rows <= 0 || A->n_cols <= 0 || A->nnz < 0 || A->n_chunks < 0) return fail(AKS_ERR_ARG, "bad sizes");
-    if (A->n_slabs != (int32_t)((A->n_cols + (1 << PB_SLAB_BITS) - 1) >> PB_SLAB_BITS) ||
-        A->n_rowblocks != (int32_t)((A->n_rows + PB_RB - 1) >> PB_RB_BITS))
-        return fail(AKS_ERR_ARG, "n_slabs / n_rowblocks do not match the shape");
-    if (!A->d_rb_ptr || (A->nnz > 0 && (!A->d_val || !A->d_lcol || !A->d_dest || !A->d_lrow || !A->d_slab_ptr ||
-                                        !A->d_chunk_begin || !A->d_chunk_slab || !A->d_prod)))
-        return fail(AKS_ERR_ARG, "null array in aks_pb_matrix");
-    if (d_x == d_y) return fail(AKS_ERR_ARG, "x and y must not alias");
+    int rc = check_pb(A, d_x, d_y);
+    if (rc != AKS_OK) return rc;
     const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const c128 *x = reinterpret_cast<const c128 *>(d_x);
     c128 *y = reinterpret_cast<c128 *>(d_y);
-    c128 *prod = reinterpret_cast<c128 *>(A->d_prod);
-    if (A->n_chunks > 0) {
-        const int64_t cpx = (A->n_chunks + 7) / 8;
-        const dim3 grid((unsigned)(cpx * 8));
-        if (A->values_complex)
-            hipLaunchKernelGGL(k_pb_phase1<c128>, grid, dim3(BLOCK), 0, s, A->n_chunks, cpx, A->d_chunk_begin,
-                               A->d_chunk_slab, A->d_slab_ptr, static_cast<const c128 *>(A->d_val), A->d_lcol,
-                               A->d_dest, x, prod, ctrl);
-        else
-            hipLaunchKernelGGL(k_pb_phase1<double>, grid, dim3(BLOCK), 0, s, A->n_chunks, cpx, A->d_chunk_begin,
-                               A->d_chunk_slab, A->d_slab_ptr, static_cast<const double *>(A->d_val), A->d_lcol,
-                               A->d_dest, x, prod, ctrl);
-    }
-    const dim3 grid2((unsigned)((A->n_rowblocks + WAVES - 1) / WAVES));
-    if (accumulate)
-        hipLaunchKernelGGL(k_pb_phase2<true>, grid2, dim3(BLOCK), 0, s, A->n_rows, A->n_rowblocks, A->d_rb_ptr,
-                           A->d_lrow, prod, y, ctrl);
-    else
-        hipLaunchKernelGGL(k_pb_phase2<false>, grid2, dim3(BLOCK), 0, s, A->n_rows, A->n_rowblocks, A->d_rb_ptr,
-                           A->d_lrow, prod, y, ctrl);
-    AKS_CHECK_LAUNCH("aks_pb_spmv");
-    return AKS_OK;
+    return A->values_complex ? launch_pb<c128, c128>(A, x, y, accumulate, ctrl, s)
+                             : launch_pb<double, c128>(A, x, y, accumulate, ctrl, s);
 }
 
 int aks_pb_spmv_real(const aks_pb_matrix *A, const double *d_x, double *d_y, int32_t accumulate, const void *d_ws,
                      void *stream) {
-    if (A == nullptr || d_x == nullptr || d_y == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    int rc = check_pb(A, d_x, d_y);
+    if (rc != AKS_OK) return rc;
     if (A->values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
-    if (A->n_rows <= 0 || A->n_cols <= 0 || A->nnz < 0 || A->n_chunks < 0) return fail(AKS_ERR_ARG, "bad sizes");
-    if (A->n_slabs != (int32_t)((A->n_cols + (1 << PB_SLAB_BITS) - 1) >> PB_SLAB_BITS) ||
-        A->n_rowblocks != (int32_t)((A->n_rows + PB_RB - 1) >> PB_RB_BITS))
-        return fail(AKS_ERR_ARG, "n_slabs / n_rowblocks do not match the shape");
-    if (!A->d_rb_ptr || (A->nnz > 0 && (!A->d_val || !A->d_lcol || !A->d_dest || !A->d_lrow || !A->d_slab_ptr ||
-                                        !A->d_chunk_begin || !A->d_chunk_slab || !A->d_prod)))
-        return fail(AKS_ERR_ARG, "null array in aks_pb_matrix");
-    if (d_x == d_y) return fail(AKS_ERR_ARG, "x and y must not alias");
-    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    double *prod = reinterpret_cast<double *>(A->d_prod);        // the first 8 nnz bytes of the c128 scratch
-    if (A->n_chunks > 0) {
-        const int64_t cpx = (A->n_chunks + 7) / 8;
-        hipLaunchKernelGGL(k_pb_phase1_real, dim3((unsigned)(cpx * 8)), dim3(BLOCK), 0, s, A->n_chunks, cpx,
-                           A->d_chunk_begin, A->d_chunk_slab, A->d_slab_ptr, static_cast<const double *>(A->d_val),
-                           A->d_lcol, A->d_dest, d_x, prod, ctrl);
-    }
-    const dim3 grid2((unsigned)((A->n_rowblocks + WAVES - 1) / WAVES));
-    if (accumulate)
-        hipLaunchKernelGGL(k_pb_phase2_real<true>, grid2, dim3(BLOCK), 0, s, A->n_rows, A->n_rowblocks, A->d_rb_ptr,
-                           A->d_lrow, prod, d_y, ctrl);
-    else
-        hipLaunchKernelGGL(k_pb_phase2_real<false>, grid2, dim3(BLOCK), 0, s, A->n_rows, A->n_rowblocks, A->d_rb_ptr,
-                           A->d_lrow, prod, d_y, ctrl);
-    AKS_CHECK_LAUNCH("aks_pb_spmv_real");
-    return AKS_OK;
+    return launch_pb<double, double>(A, d_x, d_y, accumulate, static_cast<const aks_ctrl *>(d_ws),
+                                     static_cast<hipStream_t>(stream));
 }
 
 int aks_workspace_set_real(void *d_ws, int32_t real_packed, void *stream) {

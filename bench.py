@@ -9,18 +9,27 @@ nev = 5, max_dim = 20, p = 10, start vector np.random.seed(0).  A "step" is one 
 Krylov-Schur restart: host Schur + reorder of the 20x20 projected matrix, the truncation
 V[:, :10] = V[:, :20] Qp, and 10 Arnoldi steps (SpMV + DGKS Gram-Schmidt) back to width 20.
 The matrix has no dominant eigenvalues, so the solve never converges: K restarts are timed.
-For N > 1 the same n = 10M problem is row-sharded over the ranks (strong scaling).
+For N > 1 the same n = 10M problem is row-sharded over the ranks (strong scaling); without
+torch.distributed.run around it, ``--gpus N`` starts its own N ranks (one process per GPU).
 
 The line printed by rank 0 also carries
-  roofline      live HIP-event timing of the SpMV kernel launches inside the timed region,
-                algorithmic bytes (12 nnz + 36 n + 4) / average launch time vs 8 TB/s;
+  roofline        live HIP-event timing of the SpMV launches inside the timed region,
+                  algorithmic bytes (12 nnz + 36 n + 4) / average launch time vs 8 TB/s;
   roofline_ortho  the same for the Gram-Schmidt launches of the timed region;
-  cpu_baseline  the CPU oracle (NumPy/SciPy restatement of the reference, validated against
-                the reference's golden outputs) timed on this host on a bounded sample.
+  workloads       (N = 1) the structured matrices the north star names -- Markov n = 10M and the
+                  2-D Laplacian of BASELINE config 2 -- through the same measurement, a few restarts each;
+  real_arithmetic (N = 1) the same default workload with partial_schur(arithmetic="real");
+  cpu_baseline    (N = 1) the CPU oracle (NumPy/SciPy restatement of the reference, validated against
+                  the reference's golden outputs) timed on this host at the full problem size.
+The three extra legs run in child processes after the headline measurement, so nothing in them can
+cost the run its line; a failed leg is reported as {"error": ...} inside the line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,13 +39,13 @@ for _p in (ROOT, os.path.join(ROOT, "arnoldi-py_amd")):
         sys.path.insert(0, _p)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CONFIG_OF = {"random": 5, "laplace2d": 2, "laplace3d": 4, "markov": 1, "banded": 3}   # BASELINE.json configs[] (1-based)
+FAKE = os.environ.get("AKS_BENCH_FAKE_DEVICE") == "1"   # CPU rehearsal of the launcher / rank logic (tests only)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -47,25 +56,81 @@ def parse_args():
     ap.add_argument("--per-row", type=int, default=5)
     ap.add_argument("--nev", type=int, default=5)
     ap.add_argument("--max-dim", type=int, default=20)
-    ap.add_argument("--workload", choices=["random", "laplace2d", "laplace3d", "markov", "banded"],
-                    default="random",
+    ap.add_argument("--workload", choices=sorted(CONFIG_OF), default="random",
                     help="random = BASELINE config 5 (default); laplace2d / laplace3d = configs 2 / 4; "
                          "markov = mark(M) of the reference's README scaled to ~n rows (sorted LR); "
                          "banded = stand-in for config 3 (af_shell10 is not available offline): use "
                          "--n 1500000 --per-row 35 --nev 20 --max-dim 41")
     ap.add_argument("--cpu-sample-n", type=int, default=1_000_000)
-    ap.add_argument("--cpu-restarts", type=int, default=4)
+    ap.add_argument("--cpu-restarts", type=int, default=3)
+    ap.add_argument("--cpu-budget-s", type=float, default=150.0,
+                    help="run the CPU baseline at the full size if the sample predicts at most this many seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-leg", action="store_true",
                     help="skip the extra measurement of partial_schur(arithmetic='real') on the same matrix")
-    ap.add_argument("--real-leg", action="store_true",
-                    help="run that extra measurement with several GPUs too (default: one GPU only, so that "
-                         "nothing after the main measurement can cost a multi-GPU run its JSON line)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the Markov / Laplace legs")
     ap.add_argument("--chained", action="store_true",
                     help="force the Python-chained stage path on one GPU (the multi-GPU code path)")
-    return ap.parse_args()
+    ap.add_argument("--arithmetic", choices=["complex", "real"], default="complex",
+                    help="complex = the drop-in path (headline); real = partial_schur(arithmetic='real')")
+    ap.add_argument("--leg", choices=["measure", "cpu"], default=None,
+                    help="(internal) run one extra leg and print its JSON object")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------- launcher
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """``--gpus N`` without a launcher around us: start N ranks (one process per GPU), wait, forward
+    rank 0's JSON line.  This parent never touches the GPU.  A failed rank => the others are stopped
+    (by PID) and the exit status is non-zero."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    failed = None
+    line = ""
+    pending = set(range(args.gpus))
+    while pending and failed is None:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+        time.sleep(0.05)
+    if failed is not None:
+        for r in pending:
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    for ln in out.splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with status {failed[1]}\n")
+        return 1
+    if not line:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------- workloads
 def grid_dims(workload, n):
     if workload == "markov":                      # mark(M): n = M (M + 1) / 2
         return (int(round((2 * n) ** 0.5)),)
@@ -74,6 +139,15 @@ def grid_dims(workload, n):
         return (nx, nx + 1)
     nx = int(round(n ** (1.0 / 3.0)))
     return (nx, nx + 1, nx + 2)
+
+
+def problem_size(args):
+    """(n, dims), computed ONCE per process from the arguments: every rank must agree on them."""
+    if args.workload in ("random", "banded"):
+        return args.n, None
+    dims = grid_dims(args.workload, args.n)
+    n = dims[0] * (dims[0] + 1) // 2 if args.workload == "markov" else int(np.prod(dims))
+    return n, dims
 
 
 def build_rows(args, r0, r1, n, dims):
@@ -100,133 +174,127 @@ def ortho_algorithmic_bytes(n_local, J, second):
     return panel + w
 
 
-def cpu_baseline(args, n_full):
-    """Steady-state restarts/s of the CPU oracle on a bounded sample of the same workload."""
-    import scipy.sparse as sp  # noqa: F401
+def source_stamp():
+    """sha256 over the kernel source and the ABI header: profiles/pmc_summary.json carries the stamp of the
+    build its counters were collected on, so a stale file is detectable."""
+    h = hashlib.sha256()
+    for rel in ("arnoldi-py_amd/csrc/aks_kernels.hip", "include/arnoldi_hip.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(args):
+    """Steady-state restarts/s of the CPU oracle on this host.  A bounded sample (n = --cpu-sample-n) is timed
+    first; if it predicts that the full-size problem fits --cpu-budget-s, the full size is timed and reported
+    (``n == config.n``), otherwise the sample's rate scaled by the size ratio."""
     import oracle
     from arnoldi_amd import matrices
 
-    ns = min(args.cpu_sample_n, n_full)
-    if args.workload == "random":
-        A = matrices.random_csr(ns, args.per_row, 1234)
-        what = f"random CSR n={ns} ({args.per_row}/row, same generator)"
-    elif args.workload == "banded":
-        A = matrices.banded_csr(ns, args.per_row, 1234)
-        what = f"banded CSR n={ns} ({args.per_row}/row, same generator)"
-    elif args.workload == "markov":
-        mm = grid_dims("markov", ns)[0]
-        A = matrices.mark(mm)
-        ns = A.shape[0]
-        what = f"mark({mm})"
-    else:
+    n_full, _ = problem_size(args)
+
+    def build(ns):
+        if args.workload == "random":
+            return matrices.random_csr(ns, args.per_row, 1234), f"random CSR n={ns} ({args.per_row}/row, same generator)"
+        if args.workload == "banded":
+            return matrices.banded_csr(ns, args.per_row, 1234), f"banded CSR n={ns} ({args.per_row}/row, same generator)"
+        if args.workload == "markov":
+            mm = grid_dims("markov", ns)[0]
+            return matrices.mark(mm), f"mark({mm})"
         dims = grid_dims(args.workload, ns)
-        ns = int(np.prod(dims))
-        A = matrices.laplace_rows(dims, 0, ns)
-        what = f"{args.workload} grid {dims}"
-    A = A.astype(np.complex128)  # as the reference's scripts do (benchmark-partial-schur.py:78)
-    np.random.seed(0)
-    trace = {}
-    t0 = time.perf_counter()
-    try:
-        oracle.krylov_schur(A, args.nev, max_dim=args.max_dim, max_restarts=args.cpu_restarts, trace=trace,
-                            sort_function=oracle.arg_largest_real if args.workload == "markov" else None)
-    except ValueError:
-        pass
-    wall = time.perf_counter() - t0
-    ts = trace.get("t_restart", [])
-    if len(ts) < 2:
-        return None
-    per_restart = (ts[-1] - ts[0]) / (len(ts) - 1)
-    scale = ns / n_full
+        return matrices.laplace_rows(dims, 0, int(np.prod(dims))), f"{args.workload} grid {dims}"
+
+    def timed(ns, restarts):
+        A, what = build(ns)
+        A = A.astype(np.complex128)  # as the reference's scripts do (benchmark-partial-schur.py:78)
+        np.random.seed(0)
+        trace = {}
+        t0 = time.perf_counter()
+        try:
+            oracle.krylov_schur(A, args.nev, max_dim=args.max_dim, max_restarts=restarts, trace=trace,
+                                sort_function=oracle.arg_largest_real if args.workload == "markov" else None)
+        except ValueError:
+            pass
+        wall = time.perf_counter() - t0
+        ts = trace.get("t_restart", [])
+        per = (ts[-1] - ts[0]) / (len(ts) - 1) if len(ts) >= 2 else None
+        return A, what, per, wall, len(ts) - 1
+
     try:
         from threadpoolctl import threadpool_info
 
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         blas_threads = len(os.sched_getaffinity(0))
-    # per-phase split of the CPU path at the sample size (SURVEY 8(d)): one operator apply and one
-    # dgks_gs call at the mean panel width of a restart
+    ns = min(args.cpu_sample_n, n_full)
+    A, what, per, wall, intervals = timed(ns, 2 if ns < n_full else args.cpu_restarts)
+    if per is None:
+        return None
+    n_used, scaled = A.shape[0], True
+    sample_note = f"sample n={n_used}: {per:.3f} s per restart"
+    m, p_ = args.max_dim, min(args.nev + 5, args.max_dim - 1)
+    predicted = per * (n_full / n_used) * (m / (m - p_) + args.cpu_restarts)      # initial expansion + restarts
+    if n_used < n_full and predicted <= args.cpu_budget_s:
+        del A
+        A, what, per_full, wall, intervals = timed(n_full, args.cpu_restarts)
+        if per_full is not None:
+            per, n_used, scaled = per_full, A.shape[0], False
+    # per-phase split of the CPU path at the measured size (SURVEY 8(d))
     rng = np.random.default_rng(0)
-    xs = (rng.standard_normal(ns) + 1j * rng.standard_normal(ns)).astype(np.complex128)
+    xs = (rng.standard_normal(n_used) + 1j * rng.standard_normal(n_used)).astype(np.complex128)
     t0 = time.perf_counter()
-    for _ in range(3):
+    for _ in range(2):
         oracle.csr_matvec(A, xs)
-    ms_matvec = (time.perf_counter() - t0) / 3 * 1e3
-    p_ = min(args.nev + 5, args.max_dim - 1)
-    Jm = (p_ + 1 + args.max_dim) // 2
-    Vp, _ = np.linalg.qr(rng.standard_normal((ns, Jm)) + 0j)
-    Vp = np.asfortranarray(Vp)
-    t0 = time.perf_counter()
-    for _ in range(3):
-        oracle.dgks_gs(xs.copy(), Vp, np.zeros(Jm, np.complex128), 1e-8)
-    ms_dgks = (time.perf_counter() - t0) / 3 * 1e3
+    ms_matvec = (time.perf_counter() - t0) / 2 * 1e3
+    scale = n_used / n_full if scaled else 1.0
     return {
-        "value": (1.0 / per_restart) * scale,
+        "value": (1.0 / per) * scale,
         "unit": "restarts/s",
         "cores": int(blas_threads),
-        "ms_per_matvec_at_sample_n": round(ms_matvec, 2),
-        "ms_per_dgks_gs_at_sample_n": round(ms_dgks, 2),
-        "dgks_panel_width": Jm,
+        "n": int(n_used),
+        "full_size": not scaled,
+        "ms_per_matvec": round(ms_matvec, 2),
         "kind": "port",
-        "sample": (f"oracle.krylov_schur on {what}, A.astype(complex128), {len(ts) - 1} steady-state "
-                   f"restarts timed ({per_restart:.3f} s each, {wall:.1f} s CPU wall in all); all work is "
-                   f"O(n), so the rate is scaled by {ns}/{n_full}; SciPy SpMV is single-threaded, "
-                   f"BLAS uses {blas_threads} threads of {os.cpu_count()} host CPUs"),
-        "measured_restart_s_at_sample_n": per_restart,
+        "sample": (f"oracle.krylov_schur on {what}, A.astype(complex128), {intervals} steady-state restart intervals "
+                   f"timed ({per:.3f} s each, {wall:.1f} s CPU wall in all)"
+                   + (f"; all work is O(n), so the rate is scaled by {n_used}/{n_full}" if scaled else
+                      f" at the full problem size ({sample_note})")
+                   + f"; SciPy SpMV is single-threaded, BLAS uses {blas_threads} threads of {os.cpu_count()} host CPUs"),
+        "measured_restart_s": per,
     }
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    # AKS_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path with all ranks sharing the visible GPU(s)
-    # (collectives staged through host memory); the measured numbers then mean nothing.
-    backend = os.environ.get("AKS_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-
-    import torch.distributed as dist
+# ------------------------------------------------------------------------------------------- one measurement
+def measure(args, comm, world, rank):
+    """Build the operator for args.workload, run warmup + steps restarts, return (dict, context for extras)."""
+    import torch
     from arnoldi_amd import _hip
-    from arnoldi_amd.dist import Comm, row_offsets
+    from arnoldi_amd.dist import row_offsets
     from arnoldi_amd.engine import CsrOperator
     from arnoldi_amd.krylov_schur import KrylovSchurSolver
     from arnoldi_amd.utils import arg_largest_magnitude, arg_largest_real
 
-    comm = None
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-        comm = Comm()
-    elif os.environ.get("AKS_FORCE_COMM") == "1":
-        # rehearsal of the multi-rank host path on one GPU: a one-rank RCCL group whose
-        # all-reduces are really issued (measures the per-step host + collective latency)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        comm = Comm(force=True)
-
-    n, dims = args.n, None
-    if args.workload not in ("random", "banded"):
-        dims = grid_dims(args.workload, args.n)      # computed ONCE: n below is the grid's row count
-        n = dims[0] * (dims[0] + 1) // 2 if args.workload == "markov" else int(np.prod(dims))
+    real = args.arithmetic == "real"
+    n, dims = problem_size(args)
     offsets = row_offsets(n, world)
     r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
     t_setup = time.perf_counter()
     rows = build_rows(args, r0, r1, n, dims)
-    op = CsrOperator(local_rows=rows, offsets=offsets, comm=comm)
+    op = CsrOperator(local_rows=rows, offsets=offsets, comm=comm, real=real)
+    del rows
     nnz_local = op.nnz
 
     nev, m = args.nev, args.max_dim
     p = min(nev + 5, m - 1)
     np.random.seed(0)
     sort_key = arg_largest_real if args.workload == "markov" else arg_largest_magnitude
-    solver = KrylovSchurSolver(op, nev, m, p, 1e-8, sort_key, comm=comm)
+    if real:
+        from arnoldi_amd.krylov_schur_real import RealKrylovSchurSolver
+
+        solver = RealKrylovSchurSolver(op, nev, m, p, 1e-8, sort_key, comm=comm)
+    else:
+        solver = KrylovSchurSolver(op, nev, m, p, 1e-8, sort_key, comm=comm)
     ctx = solver.ctx
     native = world == 1 and not args.chained and comm is None
     if not native:
@@ -234,14 +302,16 @@ def main():
     t_setup = time.perf_counter() - t_setup
 
     def sync():
-        torch.cuda.synchronize()
+        if not FAKE:
+            torch.cuda.synchronize()
         if comm is not None:
             comm.barrier()
 
     sync()
     t0 = time.perf_counter()
     assert solver.start() == m
-    torch.cuda.synchronize()
+    if not FAKE:
+        torch.cuda.synchronize()
     initial_ms = (time.perf_counter() - t0) * 1e3
 
     for i in range(args.warmup):
@@ -249,10 +319,10 @@ def main():
         solver.expand()
 
     probe = None
-    if native:
-        probe = _hip.Probe(capacity=2 * (m - p) * args.steps + 8)
+    if native and not FAKE:
+        probe = _hip.Probe(capacity=2 * m * args.steps + 8)
         ctx.probe = probe
-    else:
+    elif not FAKE:
         ctx.spmv_events = []
     second0 = int(ctx.last_ctrl.second_passes)
     steps0 = int(ctx.last_ctrl.steps_done)
@@ -266,6 +336,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if comm is not None:
+        import torch.distributed as dist
+
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if comm.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -275,164 +347,274 @@ def main():
         n_spmv, spmv_ms = probe.read(_hip.PROBE_SPMV)
         n_ortho, ortho_ms = probe.read(_hip.PROBE_ORTHO)
     else:
-        ev = ctx.spmv_events
+        ev = ctx.spmv_events or []
         n_spmv, spmv_ms = len(ev), sum(a.elapsed_time(b) for a, b in ev)
         n_ortho, ortho_ms = 0, 0.0
     spmv_avg_ms = spmv_ms / max(n_spmv, 1)
     spmv_bytes = op.algorithmic_bytes()
-    achieved = spmv_bytes / (spmv_avg_ms * 1e-3) / 1e9 if n_spmv else None
+    achieved = spmv_bytes / (spmv_avg_ms * 1e-3) / 1e9 if n_spmv and spmv_avg_ms > 0 else None
 
     steps_done = int(ctx.last_ctrl.steps_done) - steps0
     seconds = int(ctx.last_ctrl.second_passes) - second0
-    ortho = None
     frac_second = seconds / max(steps_done, 1)
-    per_cycle = 0.0   # Gram-Schmidt bytes of one restart's m - p steps, at the measured second-pass rate
-    for J in range(p + 1, m + 1):
-        per_cycle += (frac_second * ortho_algorithmic_bytes(op.n_local, J, True)
-                      + (1 - frac_second) * ortho_algorithmic_bytes(op.n_local, J, False))
+    n_panel = ctx.basis.n_rows                      # rows of the panel the Gram-Schmidt kernels see
+    per_cycle = 0.0   # Gram-Schmidt bytes of one restart's steps, at the measured second-pass rate
+    widths = range(p + 1, m + 1)
+    for J in widths:
+        per_cycle += (frac_second * ortho_algorithmic_bytes(n_panel, J, True)
+                      + (1 - frac_second) * ortho_algorithmic_bytes(n_panel, J, False))
+    ortho = None
     if n_ortho:
-        total = per_cycle * args.steps
+        total = per_cycle * n_ortho / max(len(widths), 1)
         a = total / (ortho_ms * 1e-3) / 1e9
         ortho = {"bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(a / HBM_PEAK_GBS, 4), "launch_groups": n_ortho,
                  "avg_ms_per_step": round(ortho_ms / n_ortho, 4),
                  "second_pass_fraction": round(frac_second, 3), "traffic": None}
 
-    if rank == 0:
-        # HBM bytes per SpMV from the committed rocprofv3 --pmc passes of this same command on the
-        # default workload (profiles/collect_pmc.sh -> profiles/pmc_summary.json): FETCH_SIZE is
-        # doubled for the coalesced streams of the binned kernels (gfx950 counts their 128-B
-        # requests as 64 B, MI355X_MICROARCH.md "HBM"); the CSR kernel's 16-B gathers are
-        # reported raw (64-B requests).
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        default_workload = args.workload == "random" and n == 10_000_000 and world == 1
-        if os.path.exists(pmc_path) and default_workload:
+    exchange = None
+    if world > 1:
+        w = 8 if real else 16
+        exchange = {"ghost_bytes_received_per_spmv_rank0": int(op.n_ghost) * w,
+                    "packed_bytes_sent_per_spmv_rank0": int(getattr(op, "n_send", 0)) * w,
+                    "collectives_per_arnoldi_step": ctx.collectives_per_step(),
+                    "allreduce_payload_bytes": 16 * (m + 1)}
+    res = {
+        "value": round(args.steps / elapsed, 4),
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "elapsed": elapsed,
+        "n": n, "nnz_local": nnz_local, "nev": nev, "m": m, "p": p, "native": native,
+        "initial_ms": initial_ms, "setup_s": t_setup, "steps_done": steps_done,
+        "spmv_form": op.spmv_form, "spmv_tune_ms": getattr(op.diag, "tune_ms", None),
+        "spmv_bytes": spmv_bytes, "spmv_avg_ms": spmv_avg_ms, "n_spmv": n_spmv, "achieved": achieved,
+        "ortho": ortho, "frac_second": frac_second, "per_cycle": per_cycle, "n_panel": n_panel,
+        "n_local": op.n_local, "exchange": exchange,
+        "levels_per_round": getattr(getattr(op.diag, "binned", None), "levels_per_round", None),
+    }
+    return res
+
+
+def spmv_kernel_name(res, world):
+    if world > 1:
+        return f"sharded SpMV, rank 0 (pack + exchange + diag[{res['spmv_form']}] + off-diag)"
+    if res["spmv_form"] == "binned":
+        return "k_pb_phase1 + k_pb_phase2 (tile-binned SpMV, one pair per launch)"
+    return "k_spmv (CSR-stream SpMV)"
+
+
+def pmc_traffic(res, default_workload):
+    """HBM bytes per SpMV from the committed rocprofv3 --pmc passes of this same command on the default
+    workload (profiles/collect_pmc.sh -> profiles/pmc_summary.json), valid only for the build it was collected
+    on (source stamp).  FETCH_SIZE is doubled for the coalesced streams of the binned kernels (gfx950 counts
+    their 128-B requests as 64 B, MI355X_MICROARCH.md "HBM"); the CSR kernel's 16-B gathers are reported raw."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if not (default_workload and os.path.exists(path)):
+        return None, None
+    try:
+        pmc = json.load(open(path))
+        stamp = pmc.get("_source_stamp")
+        if stamp != source_stamp():
+            return None, f"profiles/pmc_summary.json was collected on another build (stamp {stamp}); not reported"
+        if res["spmv_form"] == "binned":
+            return (pmc["k_pb_phase1"]["hbm_bytes_per_launch_fetch_x2"]
+                    + pmc["k_pb_phase2"]["hbm_bytes_per_launch_fetch_x2"]), "rocprofv3 --pmc, same build"
+        return pmc["k_spmv"]["hbm_bytes_per_launch_raw"], "rocprofv3 --pmc, same build"
+    except Exception as e:  # noqa: BLE001
+        return None, f"pmc summary unreadable: {e}"
+
+
+def leg_summary(res):
+    """What an extra leg (child process) reports back."""
+    out = {"restarts_per_s": res["value"], "ms_per_step": res["ms_per_step"], "n": res["n"], "nnz": res["nnz_local"],
+           "nev": res["nev"], "max_dim": res["m"], "spmv_form": res["spmv_form"],
+           "spmv_avg_ms": round(res["spmv_avg_ms"], 4), "spmv_algorithmic_bytes": res["spmv_bytes"],
+           "spmv_achieved_GBs": round(res["achieved"], 1) if res["achieved"] else None,
+           "spmv_frac": round(res["achieved"] / HBM_PEAK_GBS, 4) if res["achieved"] else None,
+           "ortho_achieved_GBs": res["ortho"]["achieved"] if res["ortho"] else None,
+           "ortho_frac": res["ortho"]["frac"] if res["ortho"] else None,
+           "second_pass_fraction": round(res["frac_second"], 3), "setup_s": round(res["setup_s"], 2)}
+    return out
+
+
+def run_child(extra_argv, timeout_s):
+    """Run this script again as a child process for one extra leg; returns its JSON object or {"error": ...}."""
+    cmd = [sys.executable, os.path.abspath(__file__)] + extra_argv
+    try:
+        cp = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout_s} s"}
+    for ln in reversed(cp.stdout.splitlines()):
+        if ln.startswith("{"):
             try:
-                pmc = json.load(open(pmc_path))
-                if op.spmv_form == "binned":
-                    traffic = (pmc["k_pb_phase1"]["hbm_bytes_per_launch_fetch_x2"]
-                               + pmc["k_pb_phase2"]["hbm_bytes_per_launch_fetch_x2"])
-                else:
-                    traffic = pmc["k_spmv"]["hbm_bytes_per_launch_raw"]
-            except Exception:
-                traffic = None
+                return json.loads(ln)
+            except ValueError:
+                break
+    tail = (cp.stderr or cp.stdout or "").strip().splitlines()[-3:]
+    return {"error": f"exit status {cp.returncode}: " + " | ".join(tail)}
+
+
+# ------------------------------------------------------------------------------------------- rank main
+def run_rank(args, argv):
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start the ranks with "
+                         f"torch.distributed.run --nproc-per-node {args.gpus}, or drop WORLD_SIZE and let "
+                         f"`bench.py --gpus {args.gpus}` start them)")
+    # AKS_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path with all ranks sharing the visible GPU(s)
+    # (collectives staged through host memory); the measured numbers then mean nothing.
+    backend = os.environ.get("AKS_BENCH_BACKEND", "nccl")
+    if FAKE:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import fake_hip          # TEST INFRASTRUCTURE: NumPy stand-in for the device entry points
+
+        fake_hip.install()
+        backend = "gloo"
+    else:
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+
+    import torch.distributed as dist
+    from arnoldi_amd.dist import Comm
+
+    comm = None
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        comm = Comm()
+    elif os.environ.get("AKS_FORCE_COMM") == "1":
+        # rehearsal of the multi-rank host path on one GPU: a one-rank RCCL group whose
+        # all-reduces are really issued (measures the per-step host + collective latency)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        comm = Comm(force=True)
+
+    res = measure(args, comm, world, rank)
+
+    if args.leg == "measure":                      # child process of a one-GPU run: report and leave
+        print(json.dumps(leg_summary(res)), flush=True)
+        return 0
+
+    out = None
+    if rank == 0:
+        n, m, p, nev = res["n"], res["m"], res["p"], res["nev"]
+        default_workload = (args.workload == "random" and n == 10_000_000 and world == 1
+                            and args.arithmetic == "complex" and args.per_row == 5)
+        traffic, traffic_note = pmc_traffic(res, default_workload)
+        achieved, spmv_bytes = res["achieved"], res["spmv_bytes"]
         out = {
             "metric": "krylov_restarts_per_sec",
-            "value": round(args.steps / elapsed, 4),
+            "value": res["value"],
             "unit": "restarts/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "complex128",
-            "data": "synthetic",
+            "dtype": "complex128" if args.arithmetic == "complex" else "float64",
+            "data": "synthetic" if not FAKE else "rehearsal (NumPy stand-in for the device, numbers meaningless)",
             "config": {
-                "workload": (f"{args.workload} CSR n={n} nnz={nnz_local if world == 1 else 'sharded'} "
+                "workload": (f"{args.workload} CSR n={n} nnz={res['nnz_local'] if world == 1 else 'sharded'} "
                              f"(BASELINE config {CONFIG_OF[args.workload]} shape), "
                              f"partial_schur k={nev} max_dim={m} p={p}, "
                              f"1 step = 1 Krylov-Schur restart ({m - p} Arnoldi steps + host Schur + truncation)"),
-                "n": n, "nnz_rank0": nnz_local, "nev": nev, "max_dim": m, "p": p,
+                "n": n, "nnz_rank0": res["nnz_local"], "nev": nev, "max_dim": m, "p": p,
                 "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
-                "path": "aks_arnoldi_expand (C-chained)" if native else "python-chained stages + RCCL",
+                "path": "aks_arnoldi_expand (C-chained)" if res["native"] else "python-chained stages + collectives",
+                "exchange": res["exchange"],
             },
-            "initial_expand_ms": round(initial_ms, 2),
-            "setup_s": round(t_setup, 2),
-            "arnoldi_steps_timed": steps_done,
+            "initial_expand_ms": round(res["initial_ms"], 2),
+            "setup_s": round(res["setup_s"], 2),
+            "arnoldi_steps_timed": res["steps_done"],
             "roofline": {
-                "kernel": (("k_pb_phase1<double> + k_pb_phase2<false> (slab-binned SpMV, one pair per launch)"
-                            if op.spmv_form == "binned" else "k_spmv<double,false> (CSR-stream SpMV)")
-                           if world == 1 else
-                           f"sharded SpMV, rank 0 (pack + all-to-all + diag[{op.spmv_form}] + off-diag)"),
-                "spmv_form": op.spmv_form,
-                "spmv_autotune_ms": getattr(op.diag, "tune_ms", None),
+                "kernel": spmv_kernel_name(res, world),
+                "spmv_form": res["spmv_form"],
+                "spmv_autotune_ms": res["spmv_tune_ms"],
                 "bound": "hbm",
                 "achieved": round(achieved, 1) if achieved else None,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                 "traffic": traffic,
+                "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": spmv_bytes,
-                "avg_launch_ms": round(spmv_avg_ms, 4),
-                "launches": n_spmv,
+                "avg_launch_ms": round(res["spmv_avg_ms"], 4),
+                "launches": res["n_spmv"],
             },
-            "roofline_ortho": ortho,
-            "restart_roofline": {
-                "algorithmic_GB_per_restart": round(
-                    ((m - p) * spmv_bytes + per_cycle + 16 * op.n_local * (m + p) + 32 * op.n_local) / 1e9, 2),
-                "second_pass_fraction": round(frac_second, 3),
-            },
+            "roofline_ortho": res["ortho"],
         }
-        out["restart_roofline"]["achieved_GBs"] = round(
-            out["restart_roofline"]["algorithmic_GB_per_restart"] * world / (elapsed / args.steps), 1)
-        out["restart_roofline"]["frac_of_peak"] = round(
-            out["restart_roofline"]["achieved_GBs"] / (HBM_PEAK_GBS * world), 4)
+        n_loc, per_cycle, elapsed = res["n_panel"], res["per_cycle"], res["elapsed"]
+        rr = {"algorithmic_GB_per_restart": round(((m - p) * spmv_bytes + per_cycle + 16 * n_loc * (m + p) + 32 * n_loc) / 1e9, 2),
+              "second_pass_fraction": round(res["frac_second"], 3)}
+        rr["achieved_GBs"] = round(rr["algorithmic_GB_per_restart"] * world / (elapsed / args.steps), 1)
+        rr["frac_of_peak"] = round(rr["achieved_GBs"] / (HBM_PEAK_GBS * world), 4)
         # SURVEY 8(d)'s own per-restart figure (three panel reads per step whether or not the second pass
         # runs): (m-p) B_spmv + 16 n 3 S(m,p) + B_tr, with S = sum of the panel widths J = p+1 .. m
         S = sum(range(p + 1, m + 1))
-        survey_bytes = (m - p) * spmv_bytes + 16 * op.n_local * 3 * S + 16 * op.n_local * (m + p) + 32 * op.n_local
-        out["restart_roofline"]["survey_fused_GB_per_restart"] = round(survey_bytes / 1e9, 2)
-        out["restart_roofline"]["survey_fused_frac_of_peak"] = round(
-            survey_bytes * world / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, n)
-
-    # ---- extra leg: the same workload in real arithmetic (opt-in mode of the product; `value` above stays
-    # the drop-in complex128 path).  Every rank takes part (collectives inside).
-    real_leg = None
-    if not args.no_real_leg and (world == 1 or args.real_leg):
-        from arnoldi_amd.krylov_schur_real import RealKrylovSchurSolver
-
-        del solver, ctx, op
-        torch.cuda.empty_cache()
-        op_r = CsrOperator(local_rows=rows, offsets=offsets, comm=comm, real=True)
-        np.random.seed(0)
-        rs = RealKrylovSchurSolver(op_r, nev, m, p, 1e-8, sort_key, comm=comm)
-        if not native:
-            rs.ctx.force_chained = True
-        assert rs.start() == m
-        for i in range(args.warmup):
-            rs.contract(i)
-            rs.expand()
-        pr = None
-        if native:
-            pr = _hip.Probe(capacity=2 * m * args.steps + 8)
-            rs.ctx.probe = pr
-        sync()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            rs.contract(args.warmup + i)
-            rs.expand()
-        sync()
-        el = time.perf_counter() - t0
-        if comm is not None:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda" if comm.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        real_leg = {"value": round(args.steps / el, 4), "unit": "restarts/s", "ms_per_step": round(el / args.steps * 1e3, 3),
-                    "dtype": "float64 (real-packed basis, real Schur form on the host)", "spmv_form": op_r.spmv_form,
-                    "spmv_autotune_ms": getattr(op_r.diag, "tune_ms", None),
-                    "note": "partial_schur(arithmetic='real'): same (Q, T) contract; restart size moves by one "
-                            "when it would cut a conjugate pair"}
-        if pr is not None:
-            ns, ms_s = pr.read(_hip.PROBE_SPMV)
-            no, ms_o = pr.read(_hip.PROBE_ORTHO)
-            b = op_r.algorithmic_bytes()
-            real_leg.update(spmv_avg_ms=round(ms_s / max(ns, 1), 4), spmv_algorithmic_bytes=b,
-                            spmv_achieved_GBs=round(b / (ms_s / max(ns, 1) * 1e-3) / 1e9, 1) if ns else None,
-                            ortho_avg_ms_per_step=round(ms_o / max(no, 1), 4))
-    if rank == 0:
-        if real_leg is not None:
-            out["real_arithmetic"] = real_leg
-        print(json.dumps(out), flush=True)
+        survey_bytes = (m - p) * spmv_bytes + 16 * n_loc * 3 * S + 16 * n_loc * (m + p) + 32 * n_loc
+        rr["survey_fused_GB_per_restart"] = round(survey_bytes / 1e9, 2)
+        rr["survey_fused_frac_of_peak"] = round(survey_bytes * world / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)
+        out["restart_roofline"] = rr
 
     if comm is not None:
         comm.barrier()
         dist.destroy_process_group()
 
+    # ---- extra legs (one GPU only): child processes, after this process has released the GPU memory
+    if rank == 0 and world == 1 and not FAKE:
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        base = ["--steps", str(min(args.steps, 5)), "--warmup", "1", "--leg", "measure"]
+        if args.workload == "random" and args.arithmetic == "complex":
+            if not args.no_real_leg:
+                leg = run_child(["--rows", str(args.n), "--per-row", str(args.per_row), "--nev", str(args.nev),
+                                 "--max-dim", str(args.max_dim), "--arithmetic", "real"] + base, 600)
+                if "error" not in leg:
+                    leg.update(dtype="float64 (real-packed basis, real Schur form on the host)",
+                               note="partial_schur(arithmetic='real'): same (Q, T) contract; restart size moves by "
+                                    "one when it would cut a conjugate pair")
+                out["real_arithmetic"] = leg
+            if not args.no_workloads:
+                legs = []
+                for name, extra in (("markov", ["--workload", "markov", "--rows", "10000000"]),
+                                    ("laplace2d", ["--workload", "laplace2d", "--rows", "1000000", "--nev", "10",
+                                                   "--max-dim", "40"])):
+                    leg = run_child(extra + base, 600)
+                    leg["name"] = name
+                    legs.append(leg)
+                out["workloads"] = legs
+        if not args.no_cpu_baseline:
+            leg = run_child(["--leg", "cpu", "--workload", args.workload, "--rows", str(args.n), "--per-row",
+                             str(args.per_row), "--nev", str(args.nev), "--max-dim", str(args.max_dim),
+                             "--cpu-sample-n", str(args.cpu_sample_n), "--cpu-restarts", str(args.cpu_restarts),
+                             "--cpu-budget-s", str(args.cpu_budget_s)], 900)
+            out["cpu_baseline"] = leg
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.leg == "cpu":
+        print(json.dumps(cpu_baseline(args)), flush=True)
+        return 0
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    return run_rank(args, argv)
+
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AKS_ABI_VERSION 1
+#define AKS_ABI_VERSION 2
 
 #define AKS_OK 0
 #define AKS_ERR_ARG (-1)         /* bad argument (null pointer, size, alignment) */
@@ -104,53 +104,78 @@ int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indic
                  int64_t n_tiles, int32_t lanes_per_row, const aks_c128 *d_x, aks_c128 *d_y,
                  int32_t accumulate, const void *d_ws, void *stream);
 
-/* ---- slab-binned two-phase SpMV (same operation, for matrices without column locality) ----
+/* ---- tile-binned two-phase SpMV (same operation, for matrices without column locality) ----
  * When the columns of a row are scattered over all of x (random graphs), every 16-B gather of
  * the CSR kernel misses the 4 MiB L2 of its XCD and the kernel runs at the fabric's request
- * rate.  The binned form trades that for two streaming passes:
- *   phase 1  non-zeros ordered by (column slab of 2^16 entries = 1 MiB of x, row block, row):
- *            workgroups of one XCD sweep one slab at a time, so gathers hit L2; each product
- *            val * x[col] is written to its slot in phase-2 order (runs of one tile);
- *   phase 2  one wave per block of 1024 rows streams its products (contiguous) and sums them
- *            into LDS accumulators, then writes y.
+ * rate (one 128-B request per non-zero).  The binned form trades that for two streaming passes
+ * over an intermediate array of products; every global access of both is a coalesced stream:
+ *   phase 1  one workgroup per SUB-SLAB of 2^13 columns: the sub-slab's 8192 x entries (128 KiB)
+ *            are staged in LDS, the sub-slab's non-zeros -- ordered by (row block, row) -- are
+ *            streamed (value, 13-bit local column) and val * x[col] is written SEQUENTIALLY;
+ *   phase 2  one workgroup (8 waves) per ROW BLOCK of 2^13 rows with the block's 8192 complex
+ *            accumulators in LDS.  The block's products are RUNS (the <= 64 entries of one
+ *            (sub-slab, row block) tile, contiguous in phase-1 order); a wave-load takes one run.
+ *            32 consecutive runs (4 per wave) form a ROUND.  Two entries of one round that hit the
+ *            same row from different waves get different LEVELS; the round's LDS adds are issued
+ *            level by level with a workgroup barrier after each, and rounds follow each other in
+ *            order, so every row receives its addends in one fixed order: results are bitwise
+ *            reproducible.  The per-entry (level, row) words of a round are one contiguous block
+ *            (fetched with one 8-byte load per lane and handed out through LDS).
  * aks_pb_plan_* are pure host functions that build the arrays from a canonical CSR matrix
  * (int32 indices); the caller uploads them and fills aks_pb_matrix with device pointers.     */
 #ifndef AKS_PB_SLAB_BITS         /* (overridable at build time for tuning experiments)        */
-#define AKS_PB_SLAB_BITS 16      /* columns per slab = 65536 (<= 16: lcol is uint16)          */
+#define AKS_PB_SLAB_BITS 13      /* columns per sub-slab = 8192 (x slice in LDS: 128 KiB)     */
 #endif
 #ifndef AKS_PB_ROWBLOCK_BITS
-#define AKS_PB_ROWBLOCK_BITS 10  /* rows per phase-2 wave = 1024                              */
+#define AKS_PB_ROWBLOCK_BITS 13  /* rows per phase-2 workgroup = 8192 (accumulators: 128 KiB) */
 #endif
-#ifndef AKS_PB_CHUNK_NNZ
-#define AKS_PB_CHUNK_NNZ 2048    /* non-zeros per phase-1 workgroup (multiple of 256)         */
-#endif
+#define AKS_PB_WAVES 8           /* waves of a phase-2 workgroup                              */
+#define AKS_PB_RUNS_PER_WAVE 4   /* runs a wave takes per round (round = 32 runs)             */
+#define AKS_PB_RUN_MAX 64        /* entries per run (one lane each)                           */
+
+typedef struct aks_pb_run {      /* 16 bytes; n_runs of them, a multiple of 32 per row block  */
+    uint32_t start;              /* first entry of the run in phase-1 order                   */
+    uint32_t info;               /* bits 0-7 entries (0 = padding run), 8-15 levels of the
+                                    run's round (>= 1), 16-31 offset of the run's words in
+                                    the round's block of d_lrow                               */
+    uint32_t lbase;              /* first word of the round's block in d_lrow (multiple of 4) */
+    uint32_t lcount;             /* words in the round's block                                */
+} aks_pb_run;
 
 typedef struct aks_pb_matrix {
-    int64_t n_rows, n_cols, nnz, n_chunks;
+    int64_t n_rows, n_cols, nnz;
+    int64_t nnz_pad;                /* phase-1 slots: every sub-slab starts on a multiple of 8 */
+    int64_t n_runs, n_lrow;         /* lengths of d_runs / d_lrow                              */
     int32_t n_slabs, n_rowblocks, values_complex, pad_;
-    const void *d_val;              /* nnz values (f64 or c128), phase-1 order                */
-    const uint16_t *d_lcol;         /* nnz: column - slab * 65536, phase-1 order              */
-    const int32_t *d_dest;          /* nnz: phase-2 position of each phase-1 entry            */
-    const uint16_t *d_lrow;         /* nnz: row - rowblock * 1024, phase-2 order              */
-    const int32_t *d_rb_ptr;        /* n_rowblocks + 1: phase-2 range of each row block       */
-    const int32_t *d_slab_ptr;      /* n_slabs + 1: phase-1 range of each slab                */
-    const int32_t *d_chunk_begin;   /* n_chunks: first phase-1 entry of each workgroup chunk  */
-    const int32_t *d_chunk_slab;    /* n_chunks: slab the chunk lies in                       */
-    aks_c128 *d_prod;               /* nnz complex128 scratch (the products)                  */
+    const void *d_val;              /* nnz_pad values (f64 or c128), phase-1 order, pads = 0   */
+    const uint16_t *d_lcol;         /* nnz_pad: column - sub-slab * 8192                       */
+    const int32_t *d_slab_begin;    /* n_slabs: first phase-1 slot of each sub-slab            */
+    const int32_t *d_slab_end;      /* n_slabs: one past its last entry                        */
+    const aks_pb_run *d_runs;       /* n_runs run descriptors, row block by row block          */
+    const int32_t *d_rb_run_ptr;    /* n_rowblocks + 1: first run of each row block            */
+    const uint16_t *d_lrow;         /* n_lrow: level << 13 | row - rowblock * 8192, round by round */
+    aks_c128 *d_prod;               /* nnz_pad complex128 scratch (the products)               */
 } aks_pb_matrix;
 
-/* The three constants above as compiled into the library (the host needs them for array sizes). */
-int aks_pb_params(int32_t *slab_bits, int32_t *rowblock_bits, int32_t *chunk_nnz);
+typedef struct aks_pb_sizes {       /* array lengths a plan needs (see aks_pb_matrix)          */
+    int64_t nnz_pad, n_runs, n_lrow;
+    int32_t n_slabs, n_rowblocks;
+} aks_pb_sizes;
 
-/* Pass 1 (host): entries per slab -> slab_ptr_out[0 .. n_slabs] (n_slabs = ceil(n_cols / 65536)).
- * Returns the number of phase-1 chunks, or a negative error. */
-int64_t aks_pb_plan_count(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int64_t n_cols,
-                          int32_t *slab_ptr_out);
-/* Pass 2 (host): fills every array of the binned form (sizes as in aks_pb_matrix). */
-int aks_pb_plan_fill(const int32_t *indptr, const int32_t *indices, const void *values,
-                     int32_t values_complex, int64_t n_rows, int64_t n_cols, const int32_t *slab_ptr,
-                     void *val_out, uint16_t *lcol_out, int32_t *dest_out, uint16_t *lrow_out,
-                     int32_t *rb_ptr_out, int32_t *chunk_begin_out, int32_t *chunk_slab_out);
+/* The constants above as compiled into the library: sub-slab bits, row-block bits, runs per round. */
+int aks_pb_params(int32_t *slab_bits, int32_t *rowblock_bits, int32_t *runs_per_round);
+
+/* Host planner.  aks_pb_plan_create reads a canonical CSR matrix (host pointers) and returns an opaque
+ * plan (NULL on error: aks_last_error) whose array lengths are written to *sizes; aks_pb_plan_export
+ * copies the planned arrays into caller-provided host buffers of those lengths; aks_pb_plan_destroy
+ * frees the plan.  AKS_ERR_UNSUPPORTED (via aks_last_error / a NULL plan) if the matrix is too large
+ * for 32-bit entry positions or has more than 2^26 (sub-slab, row block) tiles. */
+void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const void *values,
+                         int32_t values_complex, int64_t n_rows, int64_t n_cols, aks_pb_sizes *sizes);
+int aks_pb_plan_export(const void *plan, void *val_out, uint16_t *lcol_out, int32_t *slab_begin_out,
+                       int32_t *slab_end_out, aks_pb_run *runs_out, int32_t *rb_run_ptr_out,
+                       uint16_t *lrow_out);
+void aks_pb_plan_destroy(void *plan);
 /* y = A x or y += A x with the binned form (two launches on `stream`). */
 int aks_pb_spmv(const aks_pb_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate,
                 const void *d_ws, void *stream);

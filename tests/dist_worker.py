@@ -155,6 +155,29 @@ def main():
                     "n_local": int(st["solver"].op.n_local)}
     verdict["real"] = rl
 
+    # 9. ranks that disagree on the partition get a ValueError on EVERY rank before any data-path collective
+    #    (round 1: bench.py built a different n per rank and the ranks died in gloo's all-to-all)
+    mism = {}
+    n_bad = 500 + 7 * rank                                     # each rank believes in a different matrix size
+    offs_bad = row_offsets(n_bad, world)
+    rows_bad = matrices.random_csr(n_bad, 5, 1, row_range=(int(offs_bad[rank]), int(offs_bad[rank + 1])))
+    try:
+        CsrOperator(local_rows=rows_bad, offsets=offs_bad, comm=comm)
+        mism["size"] = "no error"
+    except ValueError as e:
+        mism["size"] = "ValueError: " + str(e)[:60]
+    offs_ok = row_offsets(600, world)
+    shift = 1 if rank == world - 1 else 0                      # one rank cuts the rows differently
+    offs_shift = offs_ok.copy()
+    offs_shift[1:-1] += shift
+    rows_s = matrices.random_csr(600, 5, 1, row_range=(int(offs_shift[rank]), int(offs_shift[rank + 1])))
+    try:
+        CsrOperator(local_rows=rows_s, offsets=offs_shift, comm=comm)
+        mism["offsets"] = "no error"
+    except ValueError as e:
+        mism["offsets"] = "ValueError: " + str(e)[:60]
+    verdict["mismatch"] = mism
+
     with open(os.path.join(args.out, f"rank{rank}.json"), "w") as f:
         json.dump(verdict, f)
     dist.barrier()

@@ -35,7 +35,7 @@ class FakeHip:
     def __init__(self, real):
         self._real = real
         for name in ("aks_last_error", "aks_abi_version", "aks_workspace_layout", "aks_csr_plan_tiles",
-                     "aks_pb_params", "aks_pb_plan_count", "aks_pb_plan_fill"):
+                     "aks_pb_params", "aks_pb_plan_create", "aks_pb_plan_export", "aks_pb_plan_destroy"):
             setattr(self, name, getattr(real, name))
         self.calls = []
 
@@ -80,28 +80,49 @@ class FakeHip:
         yv[:] = yv + r if acc else r
         return 0
 
+    def _pb_replay(self, A, x, y, acc, vec_dtype):
+        """The two phases of the tile-binned form, replayed with NumPy on the planned arrays: phase 1 walks
+        the sub-slab ranges, phase 2 the run descriptors and their (level, row) words."""
+        d = A._obj if hasattr(A, "_obj") else A.contents
+        nnz, n_rows, n_cols, npad = int(d.nnz), int(d.n_rows), int(d.n_cols), int(d.nnz_pad)
+        yv = _view(y, vec_dtype, n_rows)
+        out = np.zeros(n_rows, vec_dtype)
+        if nnz:
+            val = _view(d.d_val, C128 if d.values_complex else np.float64, npad)
+            lcol = _view(d.d_lcol, np.uint16, npad).astype(np.int64)
+            sb = _view(d.d_slab_begin, np.int32, d.n_slabs).astype(np.int64)
+            se = _view(d.d_slab_end, np.int32, d.n_slabs).astype(np.int64)
+            assert np.all(sb % 8 == 0) and np.all(sb <= se) and np.all(se[:-1] <= sb[1:]) and se[-1] <= npad
+            assert int((se - sb).sum()) == nnz
+            xv = _view(x, vec_dtype, n_cols)
+            prod = _view(d.d_prod, vec_dtype, npad)                                 # (real: first half of the scratch)
+            slab_of = np.repeat(np.arange(d.n_slabs, dtype=np.int64), se - sb)
+            k = np.concatenate([np.arange(b, e) for b, e in zip(sb, se)]) if d.n_slabs else np.zeros(0, np.int64)
+            prod[k] = val[k] * xv[(slab_of << 13) + lcol[k]]                        # phase 1
+            runs = _view(d.d_runs, np.uint32, 4 * int(d.n_runs)).reshape(-1, 4).astype(np.int64)
+            rbp = _view(d.d_rb_run_ptr, np.int32, d.n_rowblocks + 1).astype(np.int64)
+            lrow = _view(d.d_lrow, np.uint16, int(d.n_lrow)).astype(np.int64)
+            assert rbp[0] == 0 and rbp[-1] == len(runs) and np.all(np.diff(rbp) % 32 == 0)
+            lens, levels, loff = runs[:, 1] & 255, (runs[:, 1] >> 8) & 255, runs[:, 1] >> 16
+            assert lens.max() <= 64 and int(lens.sum()) == nnz and np.all(levels[lens > 0] >= 1)
+            assert np.all(runs[:, 2] % 4 == 0) and np.all(loff + lens <= runs[:, 3])
+            rb_of_run = np.repeat(np.arange(d.n_rowblocks, dtype=np.int64), np.diff(rbp))
+            rep = np.repeat(np.arange(len(runs)), lens)
+            within = np.arange(nnz) - np.repeat(np.cumsum(lens) - lens, lens)
+            words = lrow[runs[rep, 2] + loff[rep] + within]
+            assert np.all((words >> 13) < levels[rep])                               # every level gets its barrier
+            rows = (rb_of_run[rep] << 13) + (words & 8191)
+            assert rows.max() < n_rows
+            np.add.at(out, rows, prod[runs[rep, 0] + within])                       # phase 2
+        yv[:] = yv + out if acc else out
+
     def aks_pb_spmv_real(self, A, x, y, acc, ws, stream):
         self.calls.append("pb_spmv_real")
         if _addr(ws) and _view(ws, np.int32, 1)[0]:
             return 0
         d = A._obj if hasattr(A, "_obj") else A.contents
-        nnz, n_rows, n_cols = int(d.nnz), int(d.n_rows), int(d.n_cols)
         assert not d.values_complex
-        yv = _view(y, np.float64, n_rows)
-        out = np.zeros(n_rows)
-        if nnz:
-            val = _view(d.d_val, np.float64, nnz)
-            lcol = _view(d.d_lcol, np.uint16, nnz).astype(np.int64)
-            dest = _view(d.d_dest, np.int32, nnz)
-            lrow = _view(d.d_lrow, np.uint16, nnz).astype(np.int64)
-            slab_ptr = _view(d.d_slab_ptr, np.int32, d.n_slabs + 1)
-            rb_ptr = _view(d.d_rb_ptr, np.int32, d.n_rowblocks + 1)
-            slab_of = np.repeat(np.arange(d.n_slabs, dtype=np.int64), np.diff(slab_ptr))
-            prod = _view(d.d_prod, np.float64, nnz)                              # first half of the c128 scratch
-            prod[dest] = val * _view(x, np.float64, n_cols)[(slab_of << 16) + lcol]
-            rb_of = np.repeat(np.arange(d.n_rowblocks, dtype=np.int64), np.diff(rb_ptr))
-            np.add.at(out, (rb_of << 10) + lrow, prod)
-        yv[:] = yv + out if acc else out
+        self._pb_replay(A, x, y, acc, np.float64)
         return 0
 
     def aks_gather_f64(self, count, idx, src, dst, stream):
@@ -132,31 +153,10 @@ class FakeHip:
         return 0
 
     def aks_pb_spmv(self, A, x, y, acc, ws, stream):
-        """The two phases of the slab-binned form, replayed with NumPy on the planned arrays."""
         self.calls.append("pb_spmv")
         if _addr(ws) and _view(ws, np.int32, 1)[0]:
             return 0
-        d = A._obj if hasattr(A, "_obj") else A.contents
-        nnz, n_rows, n_cols = int(d.nnz), int(d.n_rows), int(d.n_cols)
-        yv = _view(y, C128, n_rows)
-        out = np.zeros(n_rows, C128)
-        if nnz:
-            val = _view(d.d_val, C128 if d.values_complex else np.float64, nnz)
-            lcol = _view(d.d_lcol, np.uint16, nnz).astype(np.int64)
-            dest = _view(d.d_dest, np.int32, nnz)
-            lrow = _view(d.d_lrow, np.uint16, nnz).astype(np.int64)
-            slab_ptr = _view(d.d_slab_ptr, np.int32, d.n_slabs + 1)
-            rb_ptr = _view(d.d_rb_ptr, np.int32, d.n_rowblocks + 1)
-            cb = _view(d.d_chunk_begin, np.int32, d.n_chunks)
-            cs = _view(d.d_chunk_slab, np.int32, d.n_chunks)
-            assert np.all(slab_ptr[cs] <= cb) and np.all(cb < slab_ptr[cs + 1])
-            slab_of = np.repeat(np.arange(d.n_slabs, dtype=np.int64), np.diff(slab_ptr))
-            xv = _view(x, C128, n_cols)
-            prod = _view(d.d_prod, C128, nnz)
-            prod[dest] = val * xv[(slab_of << 16) + lcol]                      # phase 1
-            rb_of = np.repeat(np.arange(d.n_rowblocks, dtype=np.int64), np.diff(rb_ptr))
-            np.add.at(out, (rb_of << 10) + lrow, prod)                          # phase 2
-        yv[:] = yv + out if acc else out
+        self._pb_replay(A, x, y, acc, C128)
         return 0
 
     # ---- Gram-Schmidt stages ---------------------------------------------------------

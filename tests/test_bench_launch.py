@@ -1,0 +1,46 @@
+"""bench.py as the driver runs it: ``python bench.py --gpus N`` must start its own N ranks (VERDICT r01:
+`assert world == args.gpus` killed it).  Rehearsed here on CPU: AKS_BENCH_FAKE_DEVICE=1 swaps the device
+entry points for tests/fake_hip.py (test infrastructure) and the ranks talk over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _run(extra, timeout=600):
+    env = dict(os.environ, AKS_BENCH_FAKE_DEVICE="1", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
+                          timeout=timeout, env=env)
+
+
+def test_bench_starts_its_own_ranks():
+    res = _run(["--gpus", "2", "--rows", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout                      # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["metric"] == "krylov_restarts_per_sec"
+    assert out["scaling"] == "strong" and out["config"]["parallelism"] == "row-sharded x2"
+    ex = out["config"]["exchange"]
+    assert ex["ghost_bytes_received_per_spmv_rank0"] > 0 and ex["collectives_per_arnoldi_step"] in (3, 4)
+    assert 0 < out["config"]["nnz_rank0"] < 20000 * 5
+    assert out["data"].startswith("rehearsal")              # a CPU stand-in never reports as a measurement
+
+
+def test_bench_reports_a_failed_rank():
+    # nev > max_dim - 1: every rank trips the reference's assertion; the launcher must come back non-zero
+    res = _run(["--gpus", "2", "--rows", "5000", "--steps", "1", "--warmup", "0", "--nev", "5", "--max-dim", "4",
+                "--no-cpu-baseline"], timeout=300)
+    assert res.returncode != 0
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_refuses_a_half_launched_world():
+    env = dict(os.environ, AKS_BENCH_FAKE_DEVICE="1", WORLD_SIZE="1", RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "5000"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr

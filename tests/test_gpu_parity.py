@@ -98,11 +98,13 @@ def test_spmv_configs_small(amd):
         assert _relerr(dy.cpu().numpy(), oracle.csr_matvec(A, x)) < RTOL
 
 
-@pytest.mark.parametrize("kind", ["ragged_real", "ragged_complex", "random", "wide", "tall", "laplace"])
+@pytest.mark.parametrize("kind", ["ragged_real", "ragged_complex", "random", "wide", "tall", "laplace", "hubs"])
 def test_spmv_binned_form(amd, kind):
-    """The slab-binned two-phase kernels (aks_pb_spmv) against the oracle: several slabs and row
-    blocks, empty rows, a long row, complex values, non-square blocks, accumulate; and bitwise
-    run-to-run reproducibility (LDS atomics are issued by one wave in program order)."""
+    """The tile-binned two-phase kernels (aks_pb_spmv) against the oracle: several sub-slabs and row
+    blocks, empty rows, long rows, complex values, non-square blocks, accumulate; and bitwise
+    run-to-run reproducibility (the LDS adds of a round are issued level by level, a workgroup
+    barrier after each level: every row sees its addends in one fixed order).  "hubs": rows with
+    entries in every sub-slab (all eight levels of a round in use) and a dense column."""
     import torch
     from arnoldi_amd import matrices
     from arnoldi_amd.device import DeviceCSR
@@ -116,6 +118,17 @@ def test_spmv_binned_form(amd, kind):
         A = sp.random(2500, 400_000, density=2e-5, random_state=np.random.RandomState(1), format="csr")
     elif kind == "tall":
         A = sp.random(150_000, 700, density=4e-3, random_state=np.random.RandomState(2), format="csr")
+    elif kind == "hubs":
+        n = 120_000
+        base = matrices.random_csr(n, 3, 5).tocoo()
+        hub_rows = np.array([7, 8191, 8192, 50_000, n - 1])
+        hr = np.repeat(hub_rows, 30_000)
+        hc = np.concatenate([rng.choice(n, 30_000, replace=False) for _ in hub_rows])
+        col_rows = rng.choice(n, 40_000, replace=False)                # one dense column
+        A = sp.csr_matrix((np.concatenate([base.data, rng.standard_normal(hr.size + col_rows.size)]),
+                           (np.concatenate([base.row, hr, col_rows]),
+                            np.concatenate([base.col, hc, np.full(col_rows.size, 4242)]))), shape=(n, n))
+        A.sum_duplicates()
     else:
         A = matrices.laplace2d(300, 311)
     A = sp.csr_matrix(A)
@@ -124,6 +137,8 @@ def test_spmv_binned_form(amd, kind):
     y0 = (rng.standard_normal(n_rows) + 1j * rng.standard_normal(n_rows)).astype(C128)
     dA = DeviceCSR(A)
     assert dA.autotune(force="binned") == "binned" and dA.use_binned
+    if kind == "hubs":
+        assert dA.binned.levels_per_round > 1.5
     dx = torch.from_numpy(x).cuda()
     dy = torch.from_numpy(y0).cuda()
     dA.spmv(dx, dy)
@@ -612,6 +627,37 @@ def test_stress_grid_against_oracle(amd, nev, ncv, p, which):
     _, _, rel_o = oracle.eig_residuals(A, Qo, To)
     assert rel.max() <= max(1.05 * rel_o.max(), 1e-12), (rel.max(), rel_o.max())
     np.testing.assert_allclose(Q.conj().T @ Q, np.eye(nev), atol=1e-11)
+
+
+def test_stress_grid_case_under_graph_capture(amd, monkeypatch):
+    """Regression for round 1's abort (gpurun_out/t8.log): the stress-grid case (LM, (3, 20, 10)) -- hundreds of
+    restarts on the 30 x 31 Laplacian, every step with a second Gram-Schmidt pass -- with the re-expansion
+    captured into a hipGraph (AKS_GRAPH=1).  A garbage collection during capture aborted the interpreter
+    then; capture now runs with the collector off.  Same History and eigenvalues as the oracle, and the graph
+    really was replayed."""
+    import gc
+
+    from arnoldi_amd import matrices
+
+    monkeypatch.setenv("AKS_GRAPH", "1")
+    A, nev, ncv, p = matrices.laplace2d(30, 31), 3, 20, 10
+    kw = dict(max_dim=ncv, p=p, stopping_criterion=None, max_restarts=4000)
+    np.random.seed(nev + ncv)
+    Qo, To, ho = oracle.krylov_schur(A, nev, sort_function=oracle.arg_largest_magnitude, **kw)
+    garbage = [[i, {}] for i in range(20000)]        # cyclic garbage waiting for a collection
+    for g in garbage:
+        g[1]["self"] = g
+    del garbage
+    assert gc.isenabled()
+    np.random.seed(nev + ncv)
+    st = {}
+    Q, T, h = amd.partial_schur(A, nev, sort_function=oracle.arg_largest_magnitude, stats=st, **kw)
+    assert gc.isenabled()                             # switched back on after the capture
+    ctx = st["solver"].ctx
+    assert ctx.use_graph and len(ctx._graphs) >= 1 and st["restarts"] > 20
+    np.testing.assert_array_equal(h.restarts, ho.restarts)
+    np.testing.assert_array_equal(h.matvecs, ho.matvecs)
+    np.testing.assert_allclose(np.diag(T), np.diag(To), rtol=1e-7, atol=1e-10)
 
 
 def test_c_abi_from_plain_c():

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in arnoldi_hip.h but not exported"
     assert sorted(_hip.SIGNATURES) == declared, "ctypes binding and header disagree"
     lib = _hip.load()
-    assert lib.aks_abi_version() == _hip.ABI_VERSION == 1
+    assert lib.aks_abi_version() == _hip.ABI_VERSION == 2
 
 
 def test_header_constants_match_binding():
@@ -370,6 +370,9 @@ def run_dist_worker(tmp_path, nproc, backend, device, timeout=600):
 
 def check_dist_verdicts(verdicts):
     for v in verdicts:
+        mm = v.pop("mismatch")
+        assert mm["size"].startswith("ValueError: row shards disagree"), mm
+        assert mm["offsets"].startswith("ValueError: row shards disagree"), mm
         rl = v.pop("real")
         for name, c in rl.items():
             assert c["eig_err"] < 10 * c["tol"] * 4.5 and c["orth_err"] < 1e-11, (name, c)
@@ -408,12 +411,14 @@ def test_row_sharded_solve_two_ranks_gloo(tmp_path):
     check_dist_verdicts(run_dist_worker(tmp_path, 2, "gloo", "cpu"))
 
 
-# ---------------------------------------------------------------------------- slab-binned SpMV form
-@pytest.mark.parametrize("shape,complex_vals", [((5000, 5000), False), ((3000, 200_000), True), ((70_000, 900), False)])
+# ---------------------------------------------------------------------------- tile-binned SpMV form
+@pytest.mark.parametrize("shape,complex_vals", [((5000, 5000), False), ((3000, 200_000), True), ((70_000, 900), False),
+                                                ((20_000, 20_000), False)])
 def test_binned_plan_represents_the_matrix(fake, shape, complex_vals):
-    """aks_pb_plan_count / aks_pb_plan_fill are host code: replaying the two phases on the planned
-    arrays (tests/fake_hip.py) must reproduce A @ x, including empty rows, several slabs, several
-    row blocks and non-square shapes (the off-diagonal blocks of a row shard)."""
+    """aks_pb_plan_create / aks_pb_plan_export are host code: replaying the two phases on the planned
+    arrays (tests/fake_hip.py) must reproduce A @ x, including empty rows, a long row, several
+    sub-slabs, several row blocks and non-square shapes (the off-diagonal blocks of a row shard).
+    The schedule invariants that make phase 2 reproducible are checked on the arrays themselves."""
     import torch
     from arnoldi_amd import _hip
     from arnoldi_amd.device import DeviceCSR
@@ -422,7 +427,7 @@ def test_binned_plan_represents_the_matrix(fake, shape, complex_vals):
     n_rows, n_cols = shape
     nnz = 6 * n_rows
     rows = rng.integers(0, n_rows, nnz)
-    rows[rows % 7 == 0] = 1                       # empty rows + one long row
+    rows[rows % 7 == 0] = 1                       # empty rows + one long row (many runs, every level)
     cols = rng.integers(0, n_cols, nnz)
     vals = rng.standard_normal(nnz) + (1j * rng.standard_normal(nnz) if complex_vals else 0)
     A = sp.csr_matrix((vals, (rows, cols)), shape=shape)
@@ -430,11 +435,30 @@ def test_binned_plan_represents_the_matrix(fake, shape, complex_vals):
     dA = DeviceCSR(A)
     b = dA.build_binned()
     d = b.desc
-    assert d.n_slabs == -(-n_cols // 65536) and d.n_rowblocks == -(-n_rows // 1024) and d.nnz == A.nnz
-    slab_ptr, rb_ptr = b.slab_ptr.numpy(), b.rb_ptr.numpy()
-    assert slab_ptr[0] == 0 and slab_ptr[-1] == A.nnz and rb_ptr[-1] == A.nnz
-    assert d.n_chunks == sum(-(-int(c) // _hip.PB_CHUNK_NNZ) for c in np.diff(slab_ptr))
-    assert sorted(b.dest.numpy().tolist()) == list(range(A.nnz))          # a permutation
+    assert d.n_slabs == -(-n_cols // 8192) and d.n_rowblocks == -(-n_rows // 8192) and d.nnz == A.nnz
+    runs = b.runs.numpy().view(np.uint32).astype(np.int64)
+    lens, levels, loff = runs[:, 1] & 255, (runs[:, 1] >> 8) & 255, runs[:, 1] >> 16
+    assert int(lens.sum()) == A.nnz and lens.max() <= 64 and levels.max() <= 8
+    # a round = 32 consecutive runs, 4 per wave: within a round, entries of one row that sit in runs of
+    # DIFFERENT waves carry different levels (their adds are separated by a barrier), ordered by wave
+    lrow = b.lrow.numpy().view(np.uint16).astype(np.int64)
+    RPR = _hip.PB_RUNS_PER_ROUND
+    for r0 in range(0, len(runs), RPR):
+        rr = runs[r0:r0 + RPR]
+        assert len(set(rr[:, 2].tolist())) == 1 and len(set((rr[:, 1] >> 8 & 255).tolist())) == 1
+        seen = {}
+        for j, (start, info, lbase, lcount) in enumerate(rr):
+            w = j // (RPR // 8)
+            for word in lrow[lbase + (info >> 16): lbase + (info >> 16) + (info & 255)]:
+                seen.setdefault(int(word & 8191), []).append((w, int(word >> 13)))
+        for row, hits in seen.items():
+            per_wave = {}
+            for w, lv in hits:
+                assert per_wave.setdefault(w, lv) == lv            # one level per (row, wave)
+            lv_by_wave = [per_wave[w] for w in sorted(per_wave)]
+            assert lv_by_wave == list(range(len(lv_by_wave)))      # levels 0, 1, 2 ... in wave order
+        if r0 > 40 * RPR:
+            break
     x = torch.from_numpy((rng.standard_normal(n_cols) + 1j * rng.standard_normal(n_cols)).astype(C128))
     y = torch.from_numpy((rng.standard_normal(n_rows) + 0j).astype(C128))
     y0 = y.numpy().copy()
@@ -444,6 +468,19 @@ def test_binned_plan_represents_the_matrix(fake, shape, complex_vals):
     dA.spmv(x, y, accumulate=True)
     np.testing.assert_allclose(y.numpy(), 2 * (A @ x.numpy()), rtol=1e-12, atol=1e-12)
     assert "pb_spmv" in fake.calls and not np.array_equal(y0, y.numpy())
+
+
+def test_binned_plan_refuses_what_it_cannot_index():
+    """Too many (sub-slab, row block) tiles: the planner reports it through a NULL plan + aks_last_error and
+    ``DeviceCSR.autotune`` keeps the CSR-stream kernel."""
+    from arnoldi_amd import _hip
+
+    lib = _hip.load()
+    n = 8192 * 9000                                # 9000 x 9000 tiles > 2^26
+    indptr = np.zeros(2, np.int32)                 # (the shape check comes before any array is read)
+    sz = _hip.PbSizes()
+    plan = lib.aks_pb_plan_create(indptr.ctypes.data, indptr.ctypes.data, indptr.ctypes.data, 0, n, n, C.byref(sz))
+    assert not plan and b"tiles" in lib.aks_last_error()
 
 
 def test_scatter_ratio_separates_stencils_from_random_graphs():
