@@ -60,7 +60,8 @@ _I32, _I64, _F64 = C.c_int32, C.c_int64, C.c_double
 PB_SLAB_BITS = 13       # AKS_PB_SLAB_BITS
 PB_ROWBLOCK_BITS = 13   # AKS_PB_ROWBLOCK_BITS
 PB_RUNS_PER_ROUND = 32  # AKS_PB_WAVES * AKS_PB_RUNS_PER_WAVE
-EXPAND_FROM_W, EXPAND_REAL_PACKED = 1, 2   # AKS_EXPAND_* flags of aks_arnoldi_expand_ex
+EXPAND_FROM_W, EXPAND_REAL_PACKED, EXPAND_LAZY_THIRD = 1, 2, 4   # AKS_EXPAND_* flags of aks_arnoldi_expand
+COMM_ID_BYTES = 128     # AKS_COMM_ID_BYTES
 
 
 class PbRun(C.Structure):
@@ -85,6 +86,26 @@ class PbMatrix(C.Structure):
         ("d_rb_run_ptr", _P), ("d_lrow", _P), ("d_prod", _P),
     ]
 
+class CsrBlock(C.Structure):
+    """Mirror of ``aks_csr_block``: one CSR block with its SpMV plan (either form)."""
+
+    _fields_ = [
+        ("n_rows", _I64), ("n_cols", _I64), ("d_indptr", _P), ("d_indices", _P), ("d_values", _P),
+        ("d_tiles", _P), ("n_tiles", _I64), ("values_complex", _I32), ("lanes_per_row", _I32),
+        ("pb", C.POINTER(PbMatrix)),
+    ]
+
+
+class Shard(C.Structure):
+    """Mirror of ``aks_shard``: this rank's rows of the operator and its ghost exchange."""
+
+    _fields_ = [
+        ("diag", CsrBlock), ("off", CsrBlock), ("comm", _P), ("d_send_idx", _P), ("d_sendbuf", _P),
+        ("d_ghostbuf", _P), ("n_send", _I64), ("n_ghost", _I64), ("send_counts", C.POINTER(_I64)),
+        ("recv_counts", C.POINTER(_I64)), ("any_exchange", _I32), ("pad_", _I32),
+    ]
+
+
 # name -> (restype, argtypes); one entry per function declared in include/arnoldi_hip.h
 SIGNATURES = {
     "aks_last_error": (C.c_char_p, []),
@@ -103,12 +124,13 @@ SIGNATURES = {
     "aks_pb_plan_export": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "aks_pb_plan_destroy": (None, [_P]),
     "aks_pb_spmv": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),
-    "aks_arnoldi_expand": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, C.POINTER(PbMatrix), _P, _I64,
-                                     _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P]),
-    "aks_arnoldi_expand_from_w": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, C.POINTER(PbMatrix), _P, _I64,
-                                            _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P]),
-    "aks_arnoldi_expand_ex": (C.c_int, [_I64, _P, _P, _P, _I32, _P, _I64, _I32, C.POINTER(PbMatrix), _P, _I64,
-                                        _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P, _I32]),
+    "aks_arnoldi_expand": (C.c_int, [C.POINTER(Shard), _P, _I64, _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P,
+                                     _I32]),
+    "aks_shard_apply": (C.c_int, [C.POINTER(Shard), _P, _P, _P, _P, _I32]),
+    "aks_comm_unique_id": (C.c_int, [_P]),
+    "aks_comm_create": (C.c_int, [_P, _I32, _I32, C.POINTER(_P)]),
+    "aks_comm_destroy": (C.c_int, [_P]),
+    "aks_comm_allreduce_sum": (C.c_int, [_P, _P, _I64, _P]),
     "aks_workspace_set_real": (C.c_int, [_P, _I32, _P]),
     "aks_csr_spmv_real": (C.c_int, [_I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _P]),
     "aks_pb_spmv_real": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),

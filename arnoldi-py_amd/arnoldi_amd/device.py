@@ -124,6 +124,16 @@ class DeviceCSR:
         self.binned = None        # BinnedCSR once built
         self.use_binned = False   # which form spmv() / aks_arnoldi_expand use
 
+    def block(self, out=None):
+        """Fill (and return) an ``aks_csr_block`` for this matrix with the SpMV form in use."""
+        b = out if out is not None else _hip.CsrBlock()
+        b.n_rows, b.n_cols = self.n_rows, self.n_cols
+        b.d_indptr, b.d_indices, b.d_values = self.indptr.data_ptr(), self.indices.data_ptr(), self.values.data_ptr()
+        b.d_tiles, b.n_tiles = self.tiles.data_ptr(), self.n_tiles
+        b.values_complex, b.lanes_per_row = self.values_complex, self.lanes_per_row
+        b.pb = C.pointer(self.binned.desc) if self.use_binned else None
+        return b
+
     def algorithmic_bytes(self, real=False):
         """12 nnz + 36 n + 4 (f64 values) or 20 nnz + 36 n + 4 (c128 values); with real
         vectors x and y are 8 bytes per row: 12 nnz + 20 n + 4."""

@@ -98,11 +98,49 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        self._native = None
 
     @property
     def active(self):
         """True when collectives have to be issued (more than one rank, or forced)."""
         return self.size > 1 or self.force
+
+    def native(self):
+        """``aks_comm`` handle (RCCL communicator owned by libarnoldi_hip.so) for this group, or None when the
+        group does not run over RCCL (gloo: CPU tests, several test ranks on one GPU).  With it the whole
+        expansion -- ghost exchange and the reductions between the Gram-Schmidt stages included -- is one C
+        call per rank (``aks_arnoldi_expand``); torch.distributed is then only the out-of-band channel that
+        carries the communicator's id.  AKS_DIST_PATH=python keeps the stage chaining in Python."""
+        import os
+
+        if self.backend != "nccl" or os.environ.get("AKS_DIST_PATH", "native") == "python":
+            return None
+        if self._native is None:
+            import ctypes as C
+
+            from . import _hip
+
+            lib = _hip.load()
+            ident = (C.c_char * _hip.COMM_ID_BYTES)()
+            if self.rank == 0:
+                _hip.check(lib.aks_comm_unique_id(C.cast(ident, C.c_void_p)), "aks_comm_unique_id")
+            box = [bytes(ident)]
+            if self.size > 1:
+                dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                           group=self.group)
+            handle = C.c_void_p()
+            ident = (C.c_char * _hip.COMM_ID_BYTES).from_buffer_copy(box[0])
+            _hip.check(lib.aks_comm_create(C.cast(ident, C.c_void_p), self.rank, self.size, C.byref(handle)),
+                       "aks_comm_create")
+            self._native = handle
+        return self._native
+
+    def close(self):
+        if self._native is not None:
+            from . import _hip
+
+            _hip.load().aks_comm_destroy(self._native)
+            self._native = None
 
     # -- small host-side exchanges used while building plans -----------------
     def allgather_int64(self, values):

@@ -79,7 +79,9 @@ class CsrOperator:
             self.diag = dev.DeviceCSR(rows, device)
             self.spmv_form = self.diag.autotune(force=force, real=self.real)
             self.off = None
-            self.n_ghost = 0
+            self.n_ghost = self.n_send = 0
+            self.any_exchange = False
+            self._build_shard()
             return
         plan = split_local_rows(rows, self.offsets, rank)
         self.diag = dev.DeviceCSR(plan.diag, device)
@@ -101,6 +103,29 @@ class CsrOperator:
         self.ghostbuf = torch.zeros(max(self.n_ghost, 1), dtype=vec_dtype, device=d)
         self.any_exchange = bool(sum(comm.allgather_int64([self.n_send + self.n_ghost])[r][0]
                                      for r in range(world)))
+        self._build_shard()
+
+    def _build_shard(self):
+        """``aks_shard`` for the C entry points (``aks_shard_apply``, ``aks_arnoldi_expand``): the two CSR blocks
+        with the SpMV form in use and, over RCCL, the communicator and the exchange plan."""
+        sh = _hip.Shard()
+        self.diag.block(sh.diag)
+        if self.off is not None:
+            self.off.block(sh.off)
+        handle = self.comm.native() if (self.comm is not None and self.comm.active) else None
+        self.native_comm = handle is not None
+        if handle is not None:
+            world = self.comm.size
+            sh.comm = handle
+            sh.any_exchange = int(self.any_exchange)
+            if self.any_exchange:
+                self._counts = ((C.c_int64 * world)(*self.send_counts), (C.c_int64 * world)(*self.recv_counts))
+                sh.send_counts, sh.recv_counts = self._counts
+                sh.d_send_idx, sh.n_send = self.send_idx.data_ptr(), self.n_send
+                sh.d_sendbuf, sh.d_ghostbuf, sh.n_ghost = self.sendbuf.data_ptr(), self.ghostbuf.data_ptr(), self.n_ghost
+        self.shard = sh
+        # in C whenever this rank's collectives can be issued from C: one GPU, or RCCL
+        self.c_driven = self.comm is None or not self.comm.active or self.native_comm
 
     @property
     def shape(self):
@@ -117,6 +142,12 @@ class CsrOperator:
     def apply(self, x, y, ws=None):
         """y = A x for this shard's rows; x, y are columns of V (local rows; real-packed if ``real``)."""
         real = self.real
+        if self.c_driven:
+            rc = _hip.load().aks_shard_apply(C.byref(self.shard), dev._ptr(x), dev._ptr(y),
+                                             dev._ptr(ws.buf) if ws is not None else C.c_void_p(0), dev._stream(),
+                                             _hip.EXPAND_REAL_PACKED if real else 0)
+            _hip.check(rc, "aks_shard_apply")
+            return
         if self.comm is None or self.comm.size == 1 or not self.any_exchange:
             self.diag.spmv(x, y, False, ws, real)
             return
@@ -201,8 +232,12 @@ class ArnoldiContext:
         self._graphs = {}
         # look-ahead operator application (see expand): off with AKS_LOOKAHEAD=0
         self.allow_lookahead = os.environ.get("AKS_LOOKAHEAD", "1") != "0"
-        self.lazy_third = False     # multi-rank: third all-reduce only when a second pass can have fired
-        self._look = None           # scratch column holding A V[:, end] of the last expansion
+        # multi-rank: leave the third all-reduce out until a step turns out to need a second DGKS pass
+        self.lazy_third = os.environ.get("AKS_LAZY_THIRD", "1") != "0"
+        self.lazy_redos = 0
+        self.last_ctrl = None
+        self._look = None           # scratch columns; [_look_col] holds A V[:, end] of the last expansion
+        self._look_col = 0
         self._look_valid = False
         self.lookahead_applies = 0  # operator applications issued ahead of time (the last one of a solve is unused)
 
@@ -223,89 +258,43 @@ class ArnoldiContext:
         # The reference's arnoldi_decomposition keeps no state between calls: a breakdown in the
         # last step of one expansion (n_iter == max_dim, accepted by the driver) must not turn the
         # next expansion into a no-op.  Clear the control block's (broken, n_iter) words.
-        ws.buf[:8].zero_()
         w_ready = bool(consume_lookahead and self._look_valid and end > start)
         self._look_valid = False
-        if w_ready:
-            b.V[start + 1].copy_(self._look.V[0])       # device-to-device, stream-ordered
-        native = (isinstance(op, CsrOperator) and (op.comm is None or not op.comm.active)
-                  and not self.force_chained)
-        if native:
-            d = op.diag
-
-            flags = (_hip.EXPAND_FROM_W if w_ready else 0) | (_hip.EXPAND_REAL_PACKED if self.real else 0)
-
-            def enqueue():
-                rc = _hip.load().aks_arnoldi_expand_ex(
-                    op.n_local, dev._ptr(d.indptr), dev._ptr(d.indices), dev._ptr(d.values), d.values_complex,
-                    dev._ptr(d.tiles), d.n_tiles, d.lanes_per_row,
-                    C.byref(d.binned.desc) if d.use_binned else None, dev._ptr(b.V), b.ldv, dev._ptr(b.H),
-                    self.max_dim, start, end, tol, eta, dev._ptr(ws.buf), ws.nbytes, ws.max_dim,
-                    self.probe.handle if self.probe is not None else C.c_void_p(0), dev._stream(), flags)
-                _hip.check(rc, "aks_arnoldi_expand_ex")
-
-            # The re-expansion (start = p) is the same launch sequence with the same arguments at
-            # every restart (DGKS decisions and breakdown are taken on the device), so it can be
-            # captured once into a hipGraph and replayed: one host call per restart instead of
-            # ~10 launches per Arnoldi step (opt-in: AKS_GRAPH=1; pays off when the host is slow
-            # relative to the kernels).  Not used while a probe records per-kernel events.
-            key = (start, end, float(tol), float(eta), w_ready)
-            if self.use_graph and self.probe is None and start > 0:
-                g = self._graphs.get(key)
-                if g is None:
-                    g = torch.cuda.CUDAGraph()
-                    gc_was_on = gc.isenabled()
-                    gc.disable()     # a collection during capture could free device objects (illegal in capture)
-                    try:
-                        with torch.cuda.graph(g, capture_error_mode="relaxed"):
-                            enqueue()
-                    finally:
-                        if gc_was_on:
-                            gc.enable()
-                    self._graphs[key] = g
-                g.replay()
+        native = isinstance(op, CsrOperator) and op.c_driven and not self.force_chained
+        multi = self.comm is not None and self.comm.active
+        # Multi-rank: the norm after a second DGKS pass needs a third all-reduce.  While no step has needed a
+        # second pass it is left out (two collectives per step); the control block's second_passes count --
+        # decided from all-reduced numbers, so identical on every rank -- tells afterwards whether a step
+        # did need it, and then the expansion is repeated with the third all-reduce (and keeps it from then
+        # on).  Its inputs V[:, :start+1] (and the look-ahead product) are untouched by the failed attempt.
+        lazy = multi and self.lazy_third
+        passes_before = int(self.last_ctrl.second_passes) if self.last_ctrl is not None else 0
+        want_look = lookahead and self.allow_lookahead and isinstance(op, CsrOperator) and end > start
+        if want_look and self._look is None:
+            # two scratch columns: the product consumed by this expansion stays intact (a repeated
+            # expansion needs it again) while the next look-ahead product is written to the other one
+            self._look = dev.DeviceColumns(b.n_rows, 2, b.device)
+        while True:
+            ws.buf[:8].zero_()
+            if w_ready:
+                b.V[start + 1].copy_(self._look.V[self._look_col])       # device-to-device, stream-ordered
+            if native:
+                self._expand_native(start, end, tol, eta, w_ready, lazy)
             else:
-                enqueue()
-        else:
-            hbase = b.H.data_ptr()
-            multi = self.comm is not None and self.comm.active
-            raw = isinstance(op, CsrOperator)      # columns as raw addresses: no per-step tensor views
-            vbase, stride = b.V.data_ptr(), 16 * b.ldv
-            with dev.cached_stream():
-                for j in range(start, end):
-                    J = j + 1
-                    x = vbase + stride * j if raw else b.col(j)
-                    w = vbase + stride * J if raw else b.col(J)
-                    if w_ready and j == start:
-                        pass                           # w = A V[:, start] was applied ahead of time
-                    elif self.spmv_events is not None:   # bench.py: device time of the sharded SpMV
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        op.apply(x, w, ws)
-                        e1.record()
-                        self.spmv_events.append((e0, e1))
-                    else:
-                        op.apply(x, w, ws)
-                    if not multi:
-                        dev.dgks_gs_device(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
-                        continue
-                    dev.gs_project(b, J, w, ws)
-                    self.comm.allreduce_sum_(ws.red(1, J + 1))
-                    dev.gs_update_project(b, J, w, ws)
-                    self.comm.allreduce_sum_(ws.red(2, J + 1))
-                    dev.gs_update_norm(b, J, w, ws, eta)
-                    self.comm.allreduce_sum_(ws.red(3, 1))
-                    dev.gs_finish(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
-        fetch = dev.fetch_H_and_ctrl(b, ws)                 # queued before the look-ahead, waited for after it
-        if lookahead and self.allow_lookahead and isinstance(op, CsrOperator) and end > start:
-            if self._look is None:
-                self._look = dev.DeviceColumns(b.n_rows, 1, b.device)
-            op.apply(b.col(end), self._look.col(0), ws)     # a no-op on the device if a step broke down
-            self.lookahead_applies += 1
-            self._look_valid = True
-        Hd, ctrl = fetch()
-        if ctrl.broken:
-            self._look_valid = False
+                self._expand_chained(start, end, tol, eta, w_ready, lazy, multi)
+            fetch = dev.fetch_H_and_ctrl(b, ws)             # queued before the look-ahead, waited for after it
+            if want_look:
+                op.apply(b.col(end), self._look.col(1 - self._look_col), ws)   # a device no-op after a breakdown
+                self.lookahead_applies += 1
+            Hd, ctrl = fetch()
+            if lazy and int(ctrl.second_passes) != passes_before:
+                self.lazy_third = lazy = False              # a step needed the second pass: do it over, exactly
+                self.lazy_redos += 1
+                continue
+            break
+        if want_look:
+            self._look_col = 1 - self._look_col
+            self._look_valid = not ctrl.broken
         n_iter = int(ctrl.n_iter) if ctrl.broken else end
         self.matvecs += n_iter - start
         if not np.iscomplexobj(H):
@@ -315,6 +304,78 @@ class ArnoldiContext:
             H[:rows, j] = Hd[:rows, j]
         self.last_ctrl = ctrl
         return n_iter
+
+    def _expand_native(self, start, end, tol, eta, w_ready, lazy):
+        """One C call: every kernel (and, over RCCL, every collective) of the expansion is enqueued by
+        ``aks_arnoldi_expand`` with no host round trip."""
+        b, ws, op = self.basis, self.ws, self.op
+        flags = ((_hip.EXPAND_FROM_W if w_ready else 0) | (_hip.EXPAND_REAL_PACKED if self.real else 0)
+                 | (_hip.EXPAND_LAZY_THIRD if lazy else 0))
+
+        def enqueue():
+            rc = _hip.load().aks_arnoldi_expand(
+                C.byref(op.shard), dev._ptr(b.V), b.ldv, dev._ptr(b.H), self.max_dim, start, end, tol, eta,
+                dev._ptr(ws.buf), ws.nbytes, ws.max_dim,
+                self.probe.handle if self.probe is not None else C.c_void_p(0), dev._stream(), flags)
+            _hip.check(rc, "aks_arnoldi_expand")
+
+        # The re-expansion (start = p) is the same launch sequence with the same arguments at
+        # every restart (DGKS decisions and breakdown are taken on the device), so it can be
+        # captured once into a hipGraph and replayed: one host call per restart instead of
+        # ~10 launches per Arnoldi step (opt-in: AKS_GRAPH=1; pays off when the host is slow
+        # relative to the kernels).  Not used while a probe records per-kernel events, nor with
+        # collectives in the sequence.
+        key = (start, end, float(tol), float(eta), w_ready)
+        if self.use_graph and self.probe is None and start > 0 and not op.native_comm:
+            g = self._graphs.get(key)
+            if g is None:
+                g = torch.cuda.CUDAGraph()
+                gc_was_on = gc.isenabled()
+                gc.disable()     # a collection during capture could free device objects (illegal in capture)
+                try:
+                    with torch.cuda.graph(g, capture_error_mode="relaxed"):
+                        enqueue()
+                finally:
+                    if gc_was_on:
+                        gc.enable()
+                self._graphs[key] = g
+            g.replay()
+        else:
+            enqueue()
+
+    def _expand_chained(self, start, end, tol, eta, w_ready, lazy, multi):
+        """The same stages chained from Python: opaque host operators, and row-sharded solves whose
+        collectives go through torch.distributed (gloo: CPU tests, several test ranks on one GPU)."""
+        b, ws, op = self.basis, self.ws, self.op
+        hbase = b.H.data_ptr()
+        raw = isinstance(op, CsrOperator)      # columns as raw addresses: no per-step tensor views
+        vbase, stride = b.V.data_ptr(), 16 * b.ldv
+        with dev.cached_stream():
+            for j in range(start, end):
+                J = j + 1
+                x = vbase + stride * j if raw else b.col(j)
+                w = vbase + stride * J if raw else b.col(J)
+                if w_ready and j == start:
+                    pass                           # w = A V[:, start] was applied ahead of time
+                elif self.spmv_events is not None:   # bench.py: device time of the sharded SpMV
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    op.apply(x, w, ws)
+                    e1.record()
+                    self.spmv_events.append((e0, e1))
+                else:
+                    op.apply(x, w, ws)
+                if not multi:
+                    dev.dgks_gs_device(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
+                    continue
+                dev.gs_project(b, J, w, ws)
+                self.comm.allreduce_sum_(ws.red(1, J + 1))
+                dev.gs_update_project(b, J, w, ws)
+                self.comm.allreduce_sum_(ws.red(2, J + 1))
+                dev.gs_update_norm(b, J, w, ws, eta)
+                if not lazy:
+                    self.comm.allreduce_sum_(ws.red(3, 1))
+                dev.gs_finish(b, J, w, hbase + 16 * j, self.max_dim, tol, ws, eta)
 
     def collectives_per_step(self):
         """Data-path collectives one Arnoldi step issues on the multi-rank path (0 on one GPU): the ghost

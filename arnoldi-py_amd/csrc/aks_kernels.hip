@@ -41,6 +41,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "arnoldi_hip.h"
 
 typedef double2 c128;
@@ -1018,6 +1020,36 @@ struct Probe {
     }
 };
 
+struct Comm {
+    ncclComm_t nccl = nullptr;
+    hipStream_t side = nullptr;          // carries the ghost exchange next to the diagonal-block SpMV
+    hipEvent_t packed = nullptr, arrived = nullptr;
+    int rank = 0, size = 1;
+};
+
+int nccl_fail(ncclResult_t r, const char *where) {
+    g_err = std::string(where) + ": " + ncclGetErrorString(r);
+    return AKS_ERR_HIP;
+}
+
+// one CSR block applied with whichever form its plan selects; vectors complex128 or (real) float64
+int apply_block(const aks_csr_block &B, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real) {
+    if (B.n_rows <= 0) return AKS_OK;
+    if (real) {
+        if (B.values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
+        return B.pb != nullptr
+                   ? aks_pb_spmv_real(B.pb, static_cast<const double *>(x), static_cast<double *>(y), accumulate, d_ws, stream)
+                   : aks_csr_spmv_real(B.n_rows, B.d_indptr, B.d_indices, static_cast<const double *>(B.d_values), B.d_tiles,
+                                       B.n_tiles, B.lanes_per_row, static_cast<const double *>(x),
+                                       static_cast<double *>(y), accumulate, d_ws, stream);
+    }
+    return B.pb != nullptr
+               ? aks_pb_spmv(B.pb, static_cast<const aks_c128 *>(x), static_cast<aks_c128 *>(y), accumulate, d_ws, stream)
+               : aks_csr_spmv(B.n_rows, B.d_indptr, B.d_indices, B.d_values, B.values_complex, B.d_tiles, B.n_tiles,
+                              B.lanes_per_row, static_cast<const aks_c128 *>(x), static_cast<aks_c128 *>(y), accumulate,
+                              d_ws, stream);
+}
+
 // ---- tile-binned SpMV: host-side plan and launcher
 struct PbPlan {
     aks_pb_sizes sz;
@@ -1467,72 +1499,158 @@ int aks_workspace_set_real(void *d_ws, int32_t real_packed, void *stream) {
     return AKS_OK;
 }
 
-int aks_arnoldi_expand_ex(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const void *d_values,
-                          int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row,
-                          const aks_pb_matrix *pb, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
-                          int32_t start_dim, int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
-                          int32_t max_dim, void *probe, void *stream, int32_t flags) {
+// ---- communicator: RCCL + a side stream for the ghost exchange ------------------------------
+int aks_comm_unique_id(void *id_out) {
+    static_assert(sizeof(ncclUniqueId) <= AKS_COMM_ID_BYTES, "AKS_COMM_ID_BYTES too small");
+    if (id_out == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return nccl_fail(r, "ncclGetUniqueId");
+    memset(id_out, 0, AKS_COMM_ID_BYTES);
+    memcpy(id_out, &id, sizeof id);
+    return AKS_OK;
+}
+
+int aks_comm_create(const void *id, int32_t rank, int32_t size, void **comm_out) {
+    if (id == nullptr || comm_out == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    if (size < 1 || rank < 0 || rank >= size) return fail(AKS_ERR_ARG, "need 0 <= rank < size");
+    Comm *c = new (std::nothrow) Comm();
+    if (c == nullptr) return fail(AKS_ERR_ARG, "out of host memory");
+    c->rank = rank;
+    c->size = size;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclResult_t r = ncclCommInitRank(&c->nccl, size, uid, rank);
+    if (r != ncclSuccess) { delete c; return nccl_fail(r, "ncclCommInitRank"); }
+    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->packed, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->arrived, hipEventDisableTiming);
+    if (e != hipSuccess) { (void)aks_comm_destroy(c); return hip_fail(e, "aks_comm_create"); }
+    *comm_out = c;
+    return AKS_OK;
+}
+
+int aks_comm_destroy(void *comm) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (c == nullptr) return AKS_OK;
+    if (c->packed) (void)hipEventDestroy(c->packed);
+    if (c->arrived) (void)hipEventDestroy(c->arrived);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->nccl) (void)ncclCommDestroy(c->nccl);
+    delete c;
+    return AKS_OK;
+}
+
+int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *stream) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (c == nullptr || d_buf == nullptr || count < 1) return fail(AKS_ERR_ARG, "bad argument");
+    ncclResult_t r = ncclAllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->nccl, static_cast<hipStream_t>(stream));
+    if (r != ncclSuccess) return nccl_fail(r, "ncclAllReduce");
+    return AKS_OK;
+}
+
+int aks_shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *d_ws, void *stream, int32_t flags) {
+    if (A == nullptr || d_x == nullptr || d_y == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    const bool real = (flags & AKS_EXPAND_REAL_PACKED) != 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Comm *c = static_cast<Comm *>(A->comm);
+    const bool exchange = c != nullptr && A->any_exchange != 0;
+    if (!exchange) return apply_block(A->diag, d_x, d_y, 0, d_ws, stream, real);
+    if (A->send_counts == nullptr || A->recv_counts == nullptr) return fail(AKS_ERR_ARG, "null exchange counts");
+    if ((A->n_send > 0 && (!A->d_send_idx || !A->d_sendbuf)) || (A->n_ghost > 0 && !A->d_ghostbuf))
+        return fail(AKS_ERR_ARG, "null exchange buffer");
+    int rc = AKS_OK;
+    if (A->n_send > 0)
+        rc = real ? aks_gather_f64(A->n_send, A->d_send_idx, static_cast<const double *>(d_x),
+                                   static_cast<double *>(A->d_sendbuf), stream)
+                  : aks_gather_c128(A->n_send, A->d_send_idx, static_cast<const aks_c128 *>(d_x),
+                                    static_cast<aks_c128 *>(A->d_sendbuf), stream);
+    if (rc != AKS_OK) return rc;
+    hipError_t e = hipEventRecord(c->packed, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->side, c->packed, 0);
+    if (e != hipSuccess) return hip_fail(e, "aks_shard_apply(events)");
+    {   // all-to-all of the packed entries: every pair of ranks exchanges its slice, one group
+        const size_t words = real ? 1 : 2;
+        const double *sb = static_cast<const double *>(A->d_sendbuf);
+        double *gb = static_cast<double *>(A->d_ghostbuf);
+        ncclResult_t r = ncclGroupStart();
+        int64_t so = 0, ro = 0;
+        for (int peer = 0; peer < c->size && r == ncclSuccess; ++peer) {
+            const int64_t ns = A->send_counts[peer], nr = A->recv_counts[peer];
+            if (ns < 0 || nr < 0 || so + ns > A->n_send || ro + nr > A->n_ghost) {
+                (void)ncclGroupEnd();
+                return fail(AKS_ERR_ARG, "exchange counts do not fit the buffers");
+            }
+            if (ns > 0) r = ncclSend(sb + so * words, (size_t)ns * words, ncclDouble, peer, c->nccl, c->side);
+            if (nr > 0 && r == ncclSuccess) r = ncclRecv(gb + ro * words, (size_t)nr * words, ncclDouble, peer, c->nccl, c->side);
+            so += ns;
+            ro += nr;
+        }
+        const ncclResult_t r2 = ncclGroupEnd();
+        if (r != ncclSuccess) return nccl_fail(r, "ncclSend/ncclRecv");
+        if (r2 != ncclSuccess) return nccl_fail(r2, "ncclGroupEnd");
+    }
+    e = hipEventRecord(c->arrived, c->side);
+    if (e != hipSuccess) return hip_fail(e, "hipEventRecord");
+    rc = apply_block(A->diag, d_x, d_y, 0, d_ws, stream, real);          // overlaps the exchange
+    if (rc != AKS_OK) return rc;
+    e = hipStreamWaitEvent(s, c->arrived, 0);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+    if (A->off.n_rows > 0) rc = apply_block(A->off, A->d_ghostbuf, d_y, 1, d_ws, stream, real);
+    return rc;
+}
+
+int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
+                       int32_t start_dim, int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
+                       int32_t max_dim, void *probe, void *stream, int32_t flags) {
     const bool first_w_ready = (flags & AKS_EXPAND_FROM_W) != 0, real = (flags & AKS_EXPAND_REAL_PACKED) != 0;
+    const bool lazy_third = (flags & AKS_EXPAND_LAZY_THIRD) != 0;
+    if (A == nullptr) return fail(AKS_ERR_ARG, "null operator");
     if (start_dim < 0 || end_dim > max_dim || start_dim > end_dim)
         return fail(AKS_ERR_ARG, "need 0 <= start_dim <= end_dim <= max_dim");
     if (d_V == nullptr || d_H == nullptr) return fail(AKS_ERR_ARG, "null pointer");
     if (ldh < max_dim) return fail(AKS_ERR_ARG, "ldh < max_dim");
-    if (pb != nullptr && (pb->n_rows != n_rows || pb->n_cols != n_rows))
-        return fail(AKS_ERR_ARG, "binned matrix shape does not match n_rows");
-    if (real && values_complex) return fail(AKS_ERR_ARG, "real-packed mode needs real matrix values");
+    const int64_t n_rows = A->diag.n_rows;
+    if (A->diag.n_cols != n_rows) return fail(AKS_ERR_ARG, "the diagonal block must be square");
+    if (real && (A->diag.values_complex || (A->off.n_rows > 0 && A->off.values_complex)))
+        return fail(AKS_ERR_ARG, "real-packed mode needs real matrix values");
     // real-packed: a column holds n_rows float64 = ceil(n_rows / 2) complex slots (an odd tail slot keeps Im = 0)
     const int64_t n_panel = real ? (n_rows + 1) / 2 : n_rows;
     if (ldv < n_panel) return fail(AKS_ERR_ARG, "ldv too small");
     Probe *pr = static_cast<Probe *>(probe);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    Comm *c = static_cast<Comm *>(A->comm);
+    Ws ws;
+    int rc = bind_ws(d_ws, ws_bytes, n_panel, max_dim, &ws);
+    if (rc != AKS_OK) return rc;
     for (int32_t j = start_dim; j < end_dim; ++j) {
+        const int32_t J = j + 1;
         aks_c128 *x = d_V + (int64_t)j * ldv;
-        aks_c128 *w = d_V + (int64_t)(j + 1) * ldv;
+        aks_c128 *w = d_V + (int64_t)J * ldv;
         hipEvent_t done = nullptr;
-        int rc = AKS_OK;
         if (!(first_w_ready && j == start_dim)) {
             done = pr ? pr->begin(AKS_PROBE_SPMV, s) : nullptr;
-            if (real)
-                rc = pb != nullptr
-                         ? aks_pb_spmv_real(pb, reinterpret_cast<const double *>(x), reinterpret_cast<double *>(w), 0,
-                                            d_ws, stream)
-                         : aks_csr_spmv_real(n_rows, d_indptr, d_indices, static_cast<const double *>(d_values),
-                                             d_tiles, n_tiles, lanes_per_row, reinterpret_cast<const double *>(x),
-                                             reinterpret_cast<double *>(w), 0, d_ws, stream);
-            else
-                rc = pb != nullptr
-                         ? aks_pb_spmv(pb, x, w, 0, d_ws, stream)
-                         : aks_csr_spmv(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
-                                        lanes_per_row, x, w, 0, d_ws, stream);
+            rc = aks_shard_apply(A, x, w, d_ws, stream, flags);
             if (done) (void)hipEventRecord(done, s);
             if (rc != AKS_OK) return rc;
         }
         done = pr ? pr->begin(AKS_PROBE_ORTHO, s) : nullptr;
-        rc = aks_dgks_gs(n_panel, j + 1, d_V, ldv, w, d_H + j, ldh, tol, eta, 1, d_ws, ws_bytes, max_dim, stream);
+        if (c == nullptr) {
+            rc = aks_dgks_gs(n_panel, J, d_V, ldv, w, d_H + j, ldh, tol, eta, 1, d_ws, ws_bytes, max_dim, stream);
+        } else {
+            // the stage kernels with the reductions summed over the ranks in between
+            rc = aks_gs_project(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream);
+            if (rc == AKS_OK) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red1), 2 * (J + 1), stream);
+            if (rc == AKS_OK) rc = aks_gs_update_project(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream);
+            if (rc == AKS_OK) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red2), 2 * (J + 1), stream);
+            if (rc == AKS_OK) rc = aks_gs_update_norm(n_panel, J, d_V, ldv, w, eta, d_ws, ws_bytes, max_dim, stream);
+            if (rc == AKS_OK && !lazy_third) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red3), 2, stream);
+            if (rc == AKS_OK) rc = aks_gs_finish(n_panel, J, w, d_H + j, ldh, tol, eta, 1, d_ws, ws_bytes, max_dim, stream);
+        }
         if (done) (void)hipEventRecord(done, s);
         if (rc != AKS_OK) return rc;
     }
     return AKS_OK;
-}
-
-int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const void *d_values,
-                       int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row,
-                       const aks_pb_matrix *pb, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
-                       int32_t start_dim, int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
-                       int32_t max_dim, void *probe, void *stream) {
-    return aks_arnoldi_expand_ex(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
-                                 lanes_per_row, pb, d_V, ldv, d_H, ldh, start_dim, end_dim, tol, eta, d_ws, ws_bytes,
-                                 max_dim, probe, stream, 0);
-}
-
-int aks_arnoldi_expand_from_w(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
-                              const void *d_values, int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles,
-                              int32_t lanes_per_row, const aks_pb_matrix *pb, aks_c128 *d_V, int64_t ldv,
-                              aks_c128 *d_H, int64_t ldh, int32_t start_dim, int32_t end_dim, double tol, double eta,
-                              void *d_ws, int64_t ws_bytes, int32_t max_dim, void *probe, void *stream) {
-    return aks_arnoldi_expand_ex(n_rows, d_indptr, d_indices, d_values, values_complex, d_tiles, n_tiles,
-                                 lanes_per_row, pb, d_V, ldv, d_H, ldh, start_dim, end_dim, tol, eta, d_ws, ws_bytes,
-                                 max_dim, probe, stream, AKS_EXPAND_FROM_W);
 }
 
 int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv, const aks_c128 *d_Qp,

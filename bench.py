@@ -296,9 +296,9 @@ def measure(args, comm, world, rank):
     else:
         solver = KrylovSchurSolver(op, nev, m, p, 1e-8, sort_key, comm=comm)
     ctx = solver.ctx
-    native = world == 1 and not args.chained and comm is None
-    if not native:
+    if args.chained:
         ctx.force_chained = True
+    native = op.c_driven and not ctx.force_chained     # one C call per expansion (one GPU, or RCCL from C)
     t_setup = time.perf_counter() - t_setup
 
     def sync():
@@ -373,7 +373,7 @@ def measure(args, comm, world, rank):
                  "second_pass_fraction": round(frac_second, 3), "traffic": None}
 
     exchange = None
-    if world > 1:
+    if world > 1 or (comm is not None and comm.active):
         w = 8 if real else 16
         exchange = {"ghost_bytes_received_per_spmv_rank0": int(op.n_ghost) * w,
                     "packed_bytes_sent_per_spmv_rank0": int(getattr(op, "n_send", 0)) * w,
@@ -454,7 +454,20 @@ def run_child(extra_argv, timeout_s):
 
 
 # ------------------------------------------------------------------------------------------- rank main
+def emit(line):
+    """The ONE line of this process on the real stdout (fd 1 is pointed at stderr while the rank runs, so that
+    banners of RCCL / the HIP runtime cannot get in front of it)."""
+    os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
+_REAL_STDOUT = 1
+
+
 def run_rank(args, argv):
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -496,10 +509,11 @@ def run_rank(args, argv):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         comm = Comm(force=True)
 
+    comm_forced = comm is not None and world == 1
     res = measure(args, comm, world, rank)
 
     if args.leg == "measure":                      # child process of a one-GPU run: report and leave
-        print(json.dumps(leg_summary(res)), flush=True)
+        emit(json.dumps(leg_summary(res)))
         return 0
 
     out = None
@@ -529,7 +543,9 @@ def run_rank(args, argv):
                              f"1 step = 1 Krylov-Schur restart ({m - p} Arnoldi steps + host Schur + truncation)"),
                 "n": n, "nnz_rank0": res["nnz_local"], "nev": nev, "max_dim": m, "p": p,
                 "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
-                "path": "aks_arnoldi_expand (C-chained)" if res["native"] else "python-chained stages + collectives",
+                "path": (("aks_arnoldi_expand: one C call per expansion"
+                          + (", RCCL all-reduces and ghost exchange issued from C" if res["exchange"] or comm_forced else ""))
+                         if res["native"] else "python-chained stages + torch.distributed collectives"),
                 "exchange": res["exchange"],
             },
             "initial_expand_ms": round(res["initial_ms"], 2),
@@ -601,7 +617,7 @@ def run_rank(args, argv):
                              "--cpu-budget-s", str(args.cpu_budget_s)], 900)
             out["cpu_baseline"] = leg
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     return 0
 
 

@@ -211,27 +211,73 @@ int aks_dgks_gs(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks
                 aks_c128 *d_Hcol, int64_t ldh, double tol, double eta, int32_t normalize,
                 void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream);
 
+/* ---- the operator of one rank: its rows of A, and how the x entries of other ranks reach it -------
+ * One GPU: `diag` is the whole matrix, `comm` is NULL and the remaining fields are unused.
+ * Row-sharded over several GPUs (one process per GPU): `diag` holds the columns this rank
+ * owns (local column ids), `off` the others with column ids = positions in the ghost buffer
+ * (off.n_rows == 0 if there are none).  Before each product the entries other ranks need are packed
+ * (d_send_idx -> d_sendbuf), exchanged (grouped ncclSend / ncclRecv on a side stream of the
+ * communicator) WHILE the diagonal block is applied, then the off-diagonal block accumulates
+ * y += A_off ghost.  send_counts / recv_counts (host arrays, one entry per rank, in vector entries)
+ * say how d_sendbuf / d_ghostbuf are cut; both buffers are ordered by peer rank. */
+typedef struct aks_csr_block {
+    int64_t n_rows, n_cols;             /* n_rows == 0: empty block                                */
+    const int32_t *d_indptr, *d_indices;
+    const void *d_values;               /* float64 or complex128                                   */
+    const int32_t *d_tiles;             /* aks_csr_plan_tiles                                      */
+    int64_t n_tiles;
+    int32_t values_complex, lanes_per_row;
+    const aks_pb_matrix *pb;            /* not NULL: apply the block with the tile-binned form     */
+} aks_csr_block;
+
+typedef struct aks_shard {
+    aks_csr_block diag, off;
+    void *comm;                         /* aks_comm_create handle; NULL = single GPU               */
+    const int32_t *d_send_idx;          /* n_send local row ids to pack                            */
+    void *d_sendbuf, *d_ghostbuf;       /* n_send / n_ghost vector entries (complex128, or float64
+                                           in real-packed mode)                                    */
+    int64_t n_send, n_ghost;
+    const int64_t *send_counts, *recv_counts;
+    int32_t any_exchange, pad_;         /* 0: no rank needs anything from any other                */
+} aks_shard;
+
+/* ---- communicator (RCCL over xGMI; one process per GPU) -------------------------------------------
+ * Rank 0 draws an id with aks_comm_unique_id (AKS_COMM_ID_BYTES bytes), the host layer hands it to every
+ * rank (any out-of-band channel: torch.distributed, MPI, a file), every rank calls aks_comm_create.
+ * The handle owns an ncclComm_t, a side stream for the ghost exchange and two events. */
+#define AKS_COMM_ID_BYTES 128
+int aks_comm_unique_id(void *id_out);
+int aks_comm_create(const void *id, int32_t rank, int32_t size, void **comm_out);
+int aks_comm_destroy(void *comm);
+/* In-place sum over the ranks of `count` doubles on `stream` (the Gram-Schmidt reductions). */
+int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *stream);
+
+/* y = A x for this rank's rows: pack, exchange overlapped with the diagonal block, off-diagonal block.
+ * flags: AKS_EXPAND_REAL_PACKED for float64 vectors.  A no-op on the device once the control block of
+ * d_ws (may be NULL) says `broken`. */
+int aks_shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *d_ws, void *stream,
+                    int32_t flags);
+
 /* ---- Arnoldi expansion: replaces arnoldi_decomposition (decomposition.py:13-68)
  * for j in [start_dim, end_dim):  V[:, j+1] = A V[:, j]; dgks_gs; normalise.
- * Single GPU, no host synchronisation; results (H columns, control block) are
- * read back by the caller afterwards.  If `pb` is not NULL the operator is applied with
- * aks_pb_spmv(pb, ...) and the CSR arguments are ignored. */
-int aks_arnoldi_expand(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
-                       const void *d_values, int32_t values_complex, const int32_t *d_tiles,
-                       int64_t n_tiles, int32_t lanes_per_row, const aks_pb_matrix *pb,
-                       aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh, int32_t start_dim,
-                       int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
-                       int32_t max_dim, void *probe, void *stream);
-
-/* The same, for a caller that applied the operator to V[:, start_dim] ahead of time (e.g. while the
- * host was busy with the restart's Schur step): V[:, start_dim+1] must already hold A V[:, start_dim];
- * the first step then starts at the orthogonalisation.  Identical results to aks_arnoldi_expand. */
-int aks_arnoldi_expand_from_w(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
-                              const void *d_values, int32_t values_complex, const int32_t *d_tiles,
-                              int64_t n_tiles, int32_t lanes_per_row, const aks_pb_matrix *pb,
-                              aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh, int32_t start_dim,
-                              int32_t end_dim, double tol, double eta, void *d_ws, int64_t ws_bytes,
-                              int32_t max_dim, void *probe, void *stream);
+ * ONE host call per expansion on every rank, no host synchronisation inside; results (H columns,
+ * control block) are read back by the caller afterwards.  With A->comm set, the reductions
+ * [V^H w; ||w||^2] of the Gram-Schmidt stages are all-reduced over the ranks on `stream` between the
+ * stage kernels: two per step, plus a third (the norm after the second DGKS pass) unless
+ * AKS_EXPAND_LAZY_THIRD is given.  With that flag a step whose DGKS test fires leaves a rank-local
+ * norm behind: the caller must look at the control block's second_passes afterwards and repeat the
+ * expansion without the flag if it moved (arnoldi_amd.engine does; matrices whose steps never need a
+ * second pass -- random graphs, Markov chains -- then run with two collectives per step).
+ * flags: AKS_EXPAND_FROM_W  V[:, start_dim+1] already holds A V[:, start_dim] (applied ahead of time,
+ *                           e.g. while the host did the restart's Schur step): the first step starts
+ *                           at the orthogonalisation; identical results;
+ *        AKS_EXPAND_REAL_PACKED  see "real-packed mode" below. */
+#define AKS_EXPAND_FROM_W 1
+#define AKS_EXPAND_REAL_PACKED 2
+#define AKS_EXPAND_LAZY_THIRD 4
+int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
+                       int32_t start_dim, int32_t end_dim, double tol, double eta, void *d_ws,
+                       int64_t ws_bytes, int32_t max_dim, void *probe, void *stream, int32_t flags);
 
 /* ---- real-packed mode (the reference's "real arithmetic" TODO, README.md:112-119) ----------------
  * For a real matrix and a real start vector the whole Krylov basis is real.  A real column of n_rows
@@ -253,17 +299,9 @@ int aks_pb_spmv_real(const aks_pb_matrix *A, const double *d_x, double *d_y, int
                      const void *d_ws, void *stream);
 int aks_gather_f64(int64_t count, const int32_t *d_idx, const double *d_src, double *d_dst, void *stream);
 
-/* General form of the expansion: flags = AKS_EXPAND_FROM_W (as aks_arnoldi_expand_from_w) and / or
- * AKS_EXPAND_REAL_PACKED (n_rows = matrix dimension; V columns are real-packed, ldv counts complex
- * slots >= ceil(n_rows/2); the workspace is laid out for ceil(n_rows/2) rows and set to real mode). */
-#define AKS_EXPAND_FROM_W 1
-#define AKS_EXPAND_REAL_PACKED 2
-int aks_arnoldi_expand_ex(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices,
-                          const void *d_values, int32_t values_complex, const int32_t *d_tiles,
-                          int64_t n_tiles, int32_t lanes_per_row, const aks_pb_matrix *pb, aks_c128 *d_V,
-                          int64_t ldv, aks_c128 *d_H, int64_t ldh, int32_t start_dim, int32_t end_dim,
-                          double tol, double eta, void *d_ws, int64_t ws_bytes, int32_t max_dim,
-                          void *probe, void *stream, int32_t flags);
+/* Real-packed expansion: aks_arnoldi_expand(..., flags | AKS_EXPAND_REAL_PACKED): diag.n_rows is the matrix
+ * dimension of this rank's rows; V columns are real-packed, ldv counts complex slots >= ceil(n_rows/2); the
+ * workspace is laid out for ceil(n_rows/2) rows and set to real mode. */
 
 /* ---- restart compression: replaces krylov_schur.py:78 and :81 --------------
  * V[:, :p] = V[:, :m] @ Qp   (in place: a wave reads all m columns of its 64 rows before it

@@ -4,7 +4,7 @@
  * src/arnoldi/decomposition.py:13-68), copies V and H back and checks the Arnoldi invariants
  *     V^H V = I      and      A V_m = V_{m+1} H
  * on the host, then compresses the basis with aks_truncate and re-checks orthonormality, and repeats the
- * factorisation in real-packed mode (aks_workspace_set_real + aks_arnoldi_expand_ex).
+ * factorisation in real-packed mode (aks_workspace_set_real + aks_arnoldi_expand with AKS_EXPAND_REAL_PACKED).
  *
  *   hipcc -x c abi_smoke.c -I../../include -L<dir of the .so> -larnoldi_hip -o abi_smoke
  * Exit code 0 = pass.  Used by tests/test_gpu_parity.py::test_c_abi_from_plain_c. */
@@ -74,8 +74,12 @@ int main(void) {
     CHECK_HIP(hipMemcpy(d_V, V, (size_t)n * 16, hipMemcpyHostToDevice));
 
     CHECK_AKS(aks_workspace_init(d_ws, lay.total_bytes, n, m, NULL));
-    CHECK_AKS(aks_arnoldi_expand(n, d_indptr, d_indices, d_values, 0, d_tiles, n_tiles, 0, NULL, d_V, ldv, d_H, m,
-                                 0, m, 1e-8, sqrt(0.5), d_ws, lay.total_bytes, m, NULL, NULL));
+    aks_shard A;                                    /* one GPU: the whole matrix is the diagonal block */
+    memset(&A, 0, sizeof A);
+    A.diag.n_rows = A.diag.n_cols = n;
+    A.diag.d_indptr = d_indptr; A.diag.d_indices = d_indices; A.diag.d_values = d_values;
+    A.diag.d_tiles = d_tiles; A.diag.n_tiles = n_tiles;
+    CHECK_AKS(aks_arnoldi_expand(&A, d_V, ldv, d_H, m, 0, m, 1e-8, sqrt(0.5), d_ws, lay.total_bytes, m, NULL, NULL, 0));
     CHECK_HIP(hipDeviceSynchronize());
 
     double complex *H = malloc((size_t)(m + 1) * m * sizeof *H);
@@ -140,9 +144,8 @@ int main(void) {
     CHECK_HIP(hipMemcpy(d_Vr, Vr, (size_t)n * 8, hipMemcpyHostToDevice));
     CHECK_AKS(aks_workspace_init(d_wsr, layr.total_bytes, n_panel, m, NULL));
     CHECK_AKS(aks_workspace_set_real(d_wsr, 1, NULL));
-    CHECK_AKS(aks_arnoldi_expand_ex(n, d_indptr, d_indices, d_values, 0, d_tiles, n_tiles, 0, NULL, d_Vr, ldp, d_Hr, m,
-                                    0, m, 1e-8, sqrt(0.5), d_wsr, layr.total_bytes, m, NULL, NULL,
-                                    AKS_EXPAND_REAL_PACKED));
+    CHECK_AKS(aks_arnoldi_expand(&A, d_Vr, ldp, d_Hr, m, 0, m, 1e-8, sqrt(0.5), d_wsr, layr.total_bytes, m, NULL, NULL,
+                                 AKS_EXPAND_REAL_PACKED));
     CHECK_HIP(hipDeviceSynchronize());
     CHECK_HIP(hipMemcpy(Vr, d_Vr, (size_t)(m + 1) * ldp * 16, hipMemcpyDeviceToHost));
     CHECK_HIP(hipMemcpy(H, d_Hr, (size_t)(m + 1) * m * 16, hipMemcpyDeviceToHost));

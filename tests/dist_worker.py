@@ -71,6 +71,9 @@ def main():
             "orth_err": float(np.abs(Q.conj().T @ Q - np.eye(nev)).max()),
             "n_ghost": int(getattr(stats["solver"].op, "n_ghost", -1)),
             "restarts": int(stats["restarts"]),
+            "lazy_redos": int(stats["solver"].ctx.lazy_redos),
+            "second_passes": int(stats["second_passes"]),
+            "collectives_per_step": int(stats["solver"].ctx.collectives_per_step()),
         }
 
     LR, LM = oracle.arg_largest_real, oracle.arg_largest_magnitude

@@ -228,31 +228,43 @@ class FakeHip:
         self.aks_gs_update_norm(n, J, V, ldv, w, eta, ws, ws_bytes, max_dim, stream)
         return self.aks_gs_finish(n, J, w, Hcol, ldh, tol, eta, normalize, ws, ws_bytes, max_dim, stream)
 
-    def aks_arnoldi_expand_from_w(self, *args):
-        return self.aks_arnoldi_expand_ex(*args, 1)
+    @staticmethod
+    def _deref(A):
+        return A._obj if hasattr(A, "_obj") else A.contents
 
-    def aks_arnoldi_expand(self, *args):
-        return self.aks_arnoldi_expand_ex(*args, 0)
+    def _apply_block(self, B, x, y, acc, ws, stream, real):
+        if B.n_rows <= 0:
+            return
+        pb = B.pb if bool(B.pb) else None
+        if real and pb is not None:
+            self.aks_pb_spmv_real(pb, x, y, acc, ws, stream)
+        elif real:
+            self.aks_csr_spmv_real(B.n_rows, B.d_indptr, B.d_indices, B.d_values, B.d_tiles, B.n_tiles,
+                                   B.lanes_per_row, x, y, acc, ws, stream)
+        elif pb is not None:
+            self.aks_pb_spmv(pb, x, y, acc, ws, stream)
+        else:
+            self.aks_csr_spmv(B.n_rows, B.d_indptr, B.d_indices, B.d_values, B.values_complex, B.d_tiles, B.n_tiles,
+                              B.lanes_per_row, x, y, acc, ws, stream)
 
-    def aks_arnoldi_expand_ex(self, n, indptr, indices, values, cplx, tiles, n_tiles, lpr, pb, V, ldv, H, ldh,
-                              start, end, tol, eta, ws, ws_bytes, max_dim, probe, stream, flags):
+    def aks_shard_apply(self, A, x, y, ws, stream, flags):
+        sh = self._deref(A)
+        assert not sh.comm, "the CPU stand-in has no RCCL: multi-rank tests chain the stages over gloo"
+        self._apply_block(sh.diag, x, y, 0, ws, stream, bool(flags & 2))
+        return 0
+
+    def aks_arnoldi_expand(self, A, V, ldv, H, ldh, start, end, tol, eta, ws, ws_bytes, max_dim, probe, stream, flags):
+        sh = self._deref(A)
         first_w_ready, real = bool(flags & 1), bool(flags & 2)
         self.calls.append(("expand_from_w" if first_w_ready else "expand") + ("_real" if real else ""))
+        n = int(sh.diag.n_rows)
         n_panel = (n + 1) // 2 if real else n
         assert not real or self._is_real_mode(ws)
         for j in range(start, end):
             x = _addr(V) + 16 * ldv * j
             w = _addr(V) + 16 * ldv * (j + 1)
-            if first_w_ready and j == start:
-                pass
-            elif real and pb is not None:
-                self.aks_pb_spmv_real(pb, x, w, 0, ws, stream)
-            elif real:
-                self.aks_csr_spmv_real(n, indptr, indices, values, tiles, n_tiles, lpr, x, w, 0, ws, stream)
-            elif pb is not None:
-                self.aks_pb_spmv(pb, x, w, 0, ws, stream)
-            else:
-                self.aks_csr_spmv(n, indptr, indices, values, cplx, tiles, n_tiles, lpr, x, w, 0, ws, stream)
+            if not (first_w_ready and j == start):
+                self.aks_shard_apply(A, x, w, ws, stream, flags)
             self.aks_dgks_gs(n_panel, j + 1, V, ldv, w, _addr(H) + 16 * j, ldh, tol, eta, 1, ws, ws_bytes, max_dim,
                              stream)
         return 0

@@ -1,5 +1,5 @@
-"""One-rank RCCL rehearsal (GPU box): the collectives of the multi-rank path are issued through
-torch.distributed's nccl backend (= RCCL) on a one-rank group, with the real HIP kernels, and the
+"""One-rank RCCL rehearsal (GPU box): the collectives of the multi-rank path are issued -- by the library's own
+communicator (aks_comm_*, the default) and through torch.distributed's nccl backend (= RCCL) -- on a one-rank group, with the real HIP kernels, and the
 solve is compared with the CPU oracle.  Multi-rank *logic* is covered by the gloo tests; this
 checks that the device tensors / views / split sizes we hand to RCCL are accepted and correct.
 
@@ -66,7 +66,82 @@ def main(out_path):
         "eig_err": float(np.abs(np.diag(T) - np.diag(To)).max()),
         "rel": float(rel.max()), "rel_oracle": float(rel_o.max()),
     }
+    ctx = stats["solver"].ctx
+    res["solve"].update(native_comm=bool(stats["solver"].op.native_comm), c_driven=bool(stats["solver"].op.c_driven),
+                        lazy_redos=int(ctx.lazy_redos), collectives_per_step=int(ctx.collectives_per_step()),
+                        second_passes=int(stats["second_passes"]))
+
+    # the same through torch.distributed's all-reduces chained from Python (AKS_DIST_PATH=python): same History
+    os.environ["AKS_DIST_PATH"] = "python"
+    comm_py = Comm(force=True)
+    np.random.seed(0)
+    st2 = {}
+    Q2, T2, hist2 = partial_schur(A, 5, sort_function=oracle.arg_largest_real, comm=comm_py, stats=st2, **kw)
+    res["python_path"] = {"native_comm": bool(st2["solver"].op.native_comm),
+                          "restarts_equal": bool(np.array_equal(hist2.restarts, hist.restarts)),
+                          "eig_err": float(np.abs(np.diag(T2) - np.diag(T)).max())}
+    del os.environ["AKS_DIST_PATH"]
+
+    # every step of the Laplacian needs the second DGKS pass: the first expansion (two all-reduces per step) is
+    # found out by the control block and repeated with three; History equal to the oracle's
+    L = matrices.laplace2d(30, 31)
+    np.random.seed(0)
+    st3 = {}
+    Q3, T3, hist3 = partial_schur(L, 10, max_dim=40, sort_function=oracle.arg_largest_magnitude, comm=comm, stats=st3)
+    np.random.seed(0)
+    Qo3, To3, histo3 = oracle.krylov_schur(L, 10, max_dim=40, sort_function=oracle.arg_largest_magnitude)
+    res["laplace"] = {"restarts_equal": bool(np.array_equal(hist3.restarts, histo3.restarts)),
+                      "eig_err": float(np.abs(np.diag(T3) - np.diag(To3)).max()),
+                      "lazy_redos": int(st3["solver"].ctx.lazy_redos),
+                      "collectives_per_step": int(st3["solver"].ctx.collectives_per_step())}
+
+    # aks_shard_apply's exchange on one GPU: this rank "sends" k packed entries to itself (grouped
+    # ncclSend / ncclRecv on the communicator's side stream) while the diagonal block runs, then the
+    # off-diagonal block accumulates  y += O ghost;  expected  y = D x + O x[send_idx]
+    import ctypes as C
+
+    import scipy.sparse as sp
+    from arnoldi_amd import _hip
+    from arnoldi_amd import device as dev
+
+    rng = np.random.default_rng(3)
+    n, k = 5000, 700
+    D = sp.random(n, n, density=2e-3, random_state=np.random.RandomState(1), format="csr")
+    O = sp.random(n, k, density=5e-3, random_state=np.random.RandomState(2), format="csr")
+    send_idx = np.sort(rng.choice(n, k, replace=False)).astype(np.int32)
+    for real in (False, True):
+        dD, dO = dev.DeviceCSR(D), dev.DeviceCSR(O)
+        sh = _hip.Shard()
+        dD.block(sh.diag)
+        dO.block(sh.off)
+        sh.comm = comm.native()
+        sh.any_exchange = 1
+        counts = (C.c_int64 * 1)(k)
+        sh.send_counts, sh.recv_counts = counts, counts
+        d_idx = torch.from_numpy(send_idx).cuda()
+        vdt = torch.float64 if real else torch.complex128
+        sendbuf, ghost = torch.zeros(k, dtype=vdt, device="cuda"), torch.zeros(k, dtype=vdt, device="cuda")
+        sh.d_send_idx, sh.n_send, sh.d_sendbuf = d_idx.data_ptr(), k, sendbuf.data_ptr()
+        sh.d_ghostbuf, sh.n_ghost = ghost.data_ptr(), k
+        xh = rng.standard_normal(n) + (0 if real else 1j * rng.standard_normal(n))
+        x = torch.from_numpy(np.ascontiguousarray(xh)).cuda()
+        y = torch.full((n,), 7.0, dtype=vdt, device="cuda")
+        for _ in range(3):                                  # repeated: the events / side stream are reused
+            rc = _hip.load().aks_shard_apply(C.byref(sh), dev._ptr(x), dev._ptr(y), C.c_void_p(0), dev._stream(),
+                                             _hip.EXPAND_REAL_PACKED if real else 0)
+            _hip.check(rc, "aks_shard_apply")
+        torch.cuda.synchronize()
+        ref = D @ xh + O @ xh[send_idx]
+        res["self_exchange_real" if real else "self_exchange"] = float(np.abs(y.cpu().numpy() - ref).max()
+                                                                       / max(np.abs(ref).max(), 1e-300))
+    # the library's own all-reduce entry point on a float64 view inside a byte buffer
+    view.copy_(torch.arange(42, dtype=torch.float64, device="cuda"))
+    _hip.check(_hip.load().aks_comm_allreduce_sum(comm.native(), dev._ptr(view), 42, dev._stream()), "allreduce")
+    torch.cuda.synchronize()
+    res["native_allreduce_ok"] = bool(torch.equal(view.cpu(), torch.arange(42, dtype=torch.float64)))
+
     comm.barrier()
+    comm.close()
     dist.destroy_process_group()
     json.dump(res, open(out_path, "w"))
 

@@ -395,6 +395,11 @@ def check_dist_verdicts(verdicts):
             assert c["rel_residual"] <= max(1.05 * c["rel_residual_oracle"], 1e-13), (name, c)
             assert c["orth_err"] < 1e-12, (name, c)
             assert c["device_residual_err"] < 1e-11, (name, c)
+            # third all-reduce only once a step has needed the second DGKS pass (then the expansion is redone)
+            assert c["lazy_redos"] == (1 if c["second_passes"] else 0), (name, c)
+            exch = 0 if name == "block_diag" else 1
+            assert c["collectives_per_step"] == exch + (3 if c["second_passes"] else 2), (name, c)
+        assert v["laplace2d"]["lazy_redos"] == 1 and v["block_diag"]["collectives_per_step"] in (2, 3)
         assert v["random_planted"]["n_ghost"] > 1000 and v["block_diag"]["n_ghost"] == 0
         assert 0 < v["laplace2d"]["n_ghost"] <= 60
     assert all(v == verdicts[0] or v["mark50"]["restarts"] == verdicts[0]["mark50"]["restarts"] for v in verdicts)
