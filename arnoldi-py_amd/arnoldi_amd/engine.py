@@ -390,6 +390,16 @@ class ArnoldiContext:
         Qd = torch.from_numpy(np.ascontiguousarray(Qp, dtype=C128)).to(self.basis.device)
         dev.truncate(self.basis, m, p, Qd)
 
+    def truncate_active(self, Zp, l, m, p):
+        """Restart compression behind ``l`` locked columns (krylov_schur_locking.py):
+        ``V[:, l:p] = V[:, l:m] @ Zp`` and ``V[:, p] = V[:, m]`` -- ``aks_truncate`` on the sub-basis that
+        starts at column ``l``; the locked columns are neither read nor written."""
+        b = self.basis
+        Zd = torch.from_numpy(np.ascontiguousarray(Zp, dtype=C128).reshape(m - l, p - l)).to(b.device)
+        rc = _hip.load().aks_truncate(b.n_rows, m - l, p - l, b.V.data_ptr() + 16 * b.ldv * l, b.ldv,
+                                      dev._ptr(Zd), dev._stream())
+        _hip.check(rc, "aks_truncate")
+
     # -- data movement --------------------------------------------------------------
     def set_start_vector(self, v_full):
         self.basis.set_col(0, v_full[self.op.r0: self.op.r1])

@@ -170,15 +170,57 @@ def sweep(A, out_csv, grid=None, whichs=("LM", "LR"), tol=1e-8, max_restarts=100
     return all_rows
 
 
+def _is_matlab_v73(name):
+    """MATLAB v7.3 files are HDF5 containers behind a 512-byte text header (``scipy.io.loadmat`` refuses
+    them); the large SuiteSparse matrices -- af_shell10 among them -- are distributed in this format."""
+    with open(name, "rb") as f:
+        return f.read(19) == b"MATLAB 7.3 MAT-file"
+
+
+def _load_mat_v73(name, h5py=None):
+    """``Problem.A`` (or the first sparse variable) of a MATLAB v7.3 file: a sparse matrix is an HDF5 group with
+    the CSC arrays ``data``, ``ir`` (row indices), ``jc`` (column pointers) and the attribute ``MATLAB_sparse``
+    (= number of rows).  Needs h5py."""
+    if h5py is None:
+        try:
+            import h5py
+        except ImportError as e:
+            raise ValueError(f"{name!r} is a MATLAB v7.3 (HDF5) file and h5py is not installed; "
+                             "convert it to MatrixMarket (.mtx) or SciPy .npz") from e
+
+    def sparse_groups(group, depth=0):
+        if "MATLAB_sparse" in getattr(group, "attrs", {}):
+            yield group
+        elif hasattr(group, "keys") and depth < 3:
+            keys = list(group.keys())
+            for key in sorted(keys, key=lambda k: (k != "Problem", k != "A", k)):   # Problem.A first
+                if not str(key).startswith("#"):
+                    yield from sparse_groups(group[key], depth + 1)
+
+    with h5py.File(name, "r") as f:
+        for g in sparse_groups(f):
+            n_rows = int(g.attrs["MATLAB_sparse"])
+            jc = np.asarray(g["jc"], dtype=np.int64)
+            ir = np.asarray(g["ir"], dtype=np.int64) if "ir" in g else np.zeros(0, np.int64)
+            data = np.asarray(g["data"]) if "data" in g else np.zeros(0)
+            if data.dtype.names:                                     # complex: compound (real, imag)
+                data = data[data.dtype.names[0]] + 1j * data[data.dtype.names[1]]
+            return sp.csc_matrix((data, ir, jc), shape=(n_rows, len(jc) - 1))
+    raise ValueError(f"No sparse matrix found in {name!r}")
+
+
 def load_matrix(path) -> sp.csr_matrix:
     """Square sparse matrix from a file, as canonical CSR.
 
     ``.mat``  SuiteSparse MATLAB layout: struct ``Problem`` with field ``A``
               (scripts/utils.py:102-116 of the reference); any top-level sparse variable otherwise;
+              MATLAB v7.3 (HDF5) files through h5py when it is installed, a clear error otherwise;
     ``.mtx`` / ``.mtx.gz``  MatrixMarket;   ``.npz``  ``scipy.sparse.save_npz``.
     """
     name = os.fspath(path)
-    if name.endswith(".mat"):
+    if name.endswith(".mat") and _is_matlab_v73(name):
+        A = _load_mat_v73(name)
+    elif name.endswith(".mat"):
         data = scipy.io.loadmat(name, squeeze_me=False)
         A = None
         prob = data.get("Problem")

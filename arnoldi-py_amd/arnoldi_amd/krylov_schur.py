@@ -117,7 +117,7 @@ class KrylovSchurSolver:
 
 def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts=100,
                   sort_function=None, p=None, v0=None, comm=None, device=None, gather=True,
-                  stats=None, on_breakdown="raise", arithmetic="complex"):
+                  stats=None, on_breakdown="raise", arithmetic="complex", locking=False):
     """Compute ``nev`` Schur vectors ``Q`` and the ``nev x nev`` upper-triangular ``T``
     with ``A Q ~= Q T`` by the Krylov-Schur algorithm.
 
@@ -138,6 +138,9 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
             "real": for a real matrix and a real start vector, iterate in real arithmetic on a
             real-packed basis (krylov_schur_real.py) -- half the memory traffic; same ``(Q, T)`` contract,
             restart counts may differ from the reference's.  "auto" picks "real" whenever it applies.
+    locking  False (default: the reference's iteration, identical restart history) or True: lock converged
+            Schur vectors and let the restart size grow with them (krylov_schur_locking.py; the
+            reference's TODO, README.md:116).  Same ``(Q, T)`` contract; restart counts differ.
     stats   optional dict that receives ``restarts``, ``matvecs`` (true operator
             applications), ``second_passes`` and the solver object.
 
@@ -173,6 +176,8 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
 
     if comm is None:
         comm = default_comm()
+    if arithmetic == "real" and locking:
+        raise ValueError("locking=True is implemented for arithmetic='complex'")
     if arithmetic == "real":
         from .krylov_schur_real import RealKrylovSchurSolver
 
@@ -183,6 +188,12 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
         if max_dim < nev + 2:      # room to keep the partner of a conjugate pair cut at nev
             raise ValueError("arithmetic='real' needs max_dim >= nev + 2")
         solver = RealKrylovSchurSolver(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)
+    elif locking:
+        from .krylov_schur_locking import LockingKrylovSchurSolver
+
+        if on_breakdown != "raise":
+            raise ValueError("on_breakdown='deflate' is not implemented together with locking=True")
+        solver = LockingKrylovSchurSolver(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)
     else:
         solver = KrylovSchurSolver(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)
 
@@ -204,7 +215,8 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
         stats.update(restarts=solver.restarts_run, matvecs=ctx.matvecs,
                      second_passes=int(ctx.last_ctrl.second_passes), solver=solver,
                      lookahead_applies=ctx.lookahead_applies, arithmetic=arithmetic,
-                     tol=float(tol), max_dim=int(max_dim), p=int(p))
+                     tol=float(tol), max_dim=int(max_dim), p=int(p),
+                     locked=int(getattr(solver, "locked", 0)), truncation_bytes=list(getattr(solver, "trunc_bytes", [])))
     if not converged:
         raise ValueError("Has not converged !")                      # krylov_schur.py:108-109
     return solver.result(gather)

@@ -711,6 +711,7 @@ constexpr int PB_D = 4;                      // rounds of products in flight per
 constexpr int PB_B = 8;                      // rounds whose descriptors one vector load fetches (PB_B * PB_K lanes)
 constexpr int PB_P1_THREADS = 1024, PB_P1_U = 4;
 constexpr int PB_STAGE = PB_RPR * AKS_PB_RUN_MAX;   // (level, row) words of one round, at most
+constexpr int PB_MAX_LEVELS = 8;                    // 3-bit level field next to the 13-bit row
 static_assert(PB_CW_BITS <= 13 && PB_RB_BITS <= 13, "lcol / lrow are 13-bit fields");
 static_assert(PB_B % PB_D == 0 && (PB_B & 1) == 0 && PB_B * PB_K <= 64, "descriptor block: even, multiple of the depth");
 static_assert(PB_W * 64 * 4 >= PB_STAGE, "one 8-byte load per lane must cover a round's words");
@@ -1381,30 +1382,47 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
     }
     // phase-2 schedule: runs, rounds, levels
     P->rb_run_ptr.resize(n_rb + 1);
-    std::vector<uint8_t> seen(PB_RB, 0);
+    std::vector<uint16_t> seen(PB_RB, 0);           // waves that add to a row in the current round (bit per wave)
     std::vector<int64_t> stamp(PB_RB, -1);
+    std::vector<aks_pb_run> raw;
     int64_t round_id = 0;
     for (int64_t rb = 0; rb < n_rb; ++rb) {
         P->rb_run_ptr[rb] = (int32_t)P->runs.size();
-        const size_t first = P->runs.size();
+        raw.clear();
         for (int64_t s = 0; s < n_ss; ++s) {
             const int32_t c = cnt[s * n_rb + rb], q0 = start[s * n_rb + rb];
-            for (int32_t o = 0; o < c; o += AKS_PB_RUN_MAX) {
-                aks_pb_run run = {(uint32_t)(q0 + o), (uint32_t)std::min<int32_t>(AKS_PB_RUN_MAX, c - o), 0u, 0u};
-                P->runs.push_back(run);
-            }
+            for (int32_t o = 0; o < c; o += AKS_PB_RUN_MAX)
+                raw.push_back(aks_pb_run{(uint32_t)(q0 + o), (uint32_t)std::min<int32_t>(AKS_PB_RUN_MAX, c - o), 0u, 0u});
         }
-        while ((P->runs.size() - first) % PB_RPR) P->runs.push_back(aks_pb_run{0u, 0u, 0u, 0u});
-        for (size_t rr = first; rr < P->runs.size(); rr += PB_RPR, ++round_id) {
-            // which waves touch each row in this round (slot j of the round belongs to wave j / PB_K)
-            for (int j = 0; j < PB_RPR; ++j) {
-                const aks_pb_run &run = P->runs[rr + j];
+        size_t next = 0;
+        while (next < raw.size()) {
+            // one round: consecutive runs into slots 0 .. PB_RPR - 1 (slot j belongs to wave j / PB_K).  A row may
+            // be hit from at most PB_MAX_LEVELS different waves in a round (its level field has 3 bits): a run
+            // that would exceed that closes the round early (the remaining slots stay empty).
+            const size_t rr = P->runs.size();
+            ++round_id;
+            int slot = 0;
+            while (slot < PB_RPR && next < raw.size()) {
+                const aks_pb_run &run = raw[next];
+                const uint16_t bit = (uint16_t)(1u << (slot / PB_K));
+                bool fits = true;
+                if (PB_W > PB_MAX_LEVELS && slot > 0)
+                    for (uint32_t i = 0; i < run.info && fits; ++i) {
+                        const int row = row13[run.start + i];
+                        const uint16_t have = stamp[row] == round_id ? seen[row] : (uint16_t)0;
+                        fits = __builtin_popcount(have | bit) <= PB_MAX_LEVELS;
+                    }
+                if (!fits) break;
                 for (uint32_t i = 0; i < run.info; ++i) {
                     const int row = row13[run.start + i];
                     if (stamp[row] != round_id) { stamp[row] = round_id; seen[row] = 0; }
-                    seen[row] |= (uint8_t)(1u << (j / PB_K));
+                    seen[row] |= bit;
                 }
+                P->runs.push_back(run);
+                ++slot;
+                ++next;
             }
+            while (P->runs.size() - rr < (size_t)PB_RPR) P->runs.push_back(aks_pb_run{0u, 0u, 0u, 0u});
             const uint32_t lbase = (uint32_t)P->lrow.size();
             uint32_t off = 0, levels = 1;
             for (int j = 0; j < PB_RPR; ++j) {
@@ -1413,7 +1431,7 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
                 for (uint32_t i = 0; i < len; ++i) {
                     const int row = row13[run.start + i];
                     // level = waves with a smaller index that add to this row in this round: entries of one
-                    // row then run in wave order, one barrier-separated level per wave (<= PB_W - 1 = 7)
+                    // row then run in wave order, one barrier-separated level per wave
                     const uint32_t lv = (uint32_t)__builtin_popcount(seen[row] & ((1u << w) - 1u));
                     P->lrow.push_back((uint16_t)(row | (lv << 13)));
                     levels = std::max(levels, lv + 1);

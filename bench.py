@@ -597,6 +597,7 @@ def run_rank(args, argv):
                 leg = run_child(["--rows", str(args.n), "--per-row", str(args.per_row), "--nev", str(args.nev),
                                  "--max-dim", str(args.max_dim), "--arithmetic", "real"] + base, 600)
                 if "error" not in leg:
+                    leg.update(value=leg["restarts_per_s"], unit="restarts/s")
                     leg.update(dtype="float64 (real-packed basis, real Schur form on the host)",
                                note="partial_schur(arithmetic='real'): same (Q, T) contract; restart size moves by "
                                     "one when it would cut a conjugate pair")

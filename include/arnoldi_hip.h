@@ -129,8 +129,12 @@ int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indic
 #ifndef AKS_PB_ROWBLOCK_BITS
 #define AKS_PB_ROWBLOCK_BITS 13  /* rows per phase-2 workgroup = 8192 (accumulators: 128 KiB) */
 #endif
+#ifndef AKS_PB_WAVES
 #define AKS_PB_WAVES 8           /* waves of a phase-2 workgroup                              */
+#endif
+#ifndef AKS_PB_RUNS_PER_WAVE
 #define AKS_PB_RUNS_PER_WAVE 4   /* runs a wave takes per round (round = 32 runs)             */
+#endif
 #define AKS_PB_RUN_MAX 64        /* entries per run (one lane each)                           */
 
 typedef struct aks_pb_run {      /* 16 bytes; n_runs of them, a multiple of 32 per row block  */

@@ -669,6 +669,42 @@ def test_stress_grid_case_under_graph_capture(amd, monkeypatch):
     np.testing.assert_allclose(np.diag(T), np.diag(To), rtol=1e-7, atol=1e-10)
 
 
+@pytest.mark.parametrize("case", ["mark50_lr", "laplace_lm", "planted_300k"])
+def test_locking_and_dynamic_p(amd, case):
+    """``partial_schur(..., locking=True)`` on the device (/root/reference/README.md:116): same
+    wanted eigenpairs and residual bound as the oracle of the reference's algorithm; the restart compression
+    (``aks_truncate`` on the sub-basis behind the locked columns) moves fewer bytes as values lock."""
+    from arnoldi_amd import matrices
+
+    if case == "mark50_lr":
+        A, nev, kw, sort_o = matrices.mark(50), 5, dict(max_dim=20, stopping_criterion=1e-8), oracle.arg_largest_real
+    elif case == "laplace_lm":
+        A, nev, kw, sort_o = matrices.laplace2d(30, 31), 10, dict(max_dim=40), oracle.arg_largest_magnitude
+    else:
+        A = matrices.random_csr(300_000, 5, 1234, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5))
+        nev, kw, sort_o = 5, dict(max_dim=20), oracle.arg_largest_magnitude
+    np.random.seed(0)
+    Qo, To, ho = oracle.krylov_schur(A, nev, sort_function=sort_o, max_restarts=2000, **kw)
+    np.random.seed(0)
+    st = {}
+    Q, T, h = amd.partial_schur(A, nev, sort_function=sort_o, locking=True, stats=st, max_restarts=2000, **kw)
+    tol = st["tol"]
+    assert st["locked"] == nev
+    np.testing.assert_allclose(np.sort_complex(np.diag(T)), np.sort_complex(np.diag(To)), rtol=50 * tol, atol=50 * tol)
+    np.testing.assert_allclose(Q.conj().T @ Q, np.eye(nev), atol=1e-11)
+    assert np.abs(np.tril(T, -1)).max() == 0
+    _, _, rel = oracle.eig_residuals(A, Q, T)
+    _, _, rel_o = oracle.eig_residuals(A, Qo, To)
+    assert rel.max() <= max(1.05 * rel_o.max(), 10 * tol), (rel.max(), rel_o.max())
+    assert 0 < st["restarts"] <= 2 * int(ho.restarts.max()) + 5
+    tb = st["truncation_bytes"]
+    n, m, p0 = A.shape[0], st["max_dim"], min(nev + 5, st["max_dim"] - 1)
+    assert tb[0] == 16 * n * (m + p0 + 2) and min(tb) < tb[0]
+    # device-side residuals of the locked partial Schur form agree with the host's
+    _, _, drel = st["solver"].true_residuals()
+    np.testing.assert_allclose(np.sort(drel), np.sort(rel), rtol=1e-6, atol=1e-12)
+
+
 def test_c_abi_from_plain_c():
     """tests/c_abi/abi_smoke.c -- a C program with hipMalloc'd buffers and no Python in the process --
     drives aks_arnoldi_expand + aks_truncate through include/arnoldi_hip.h and checks the Arnoldi
@@ -733,4 +769,11 @@ def test_bench_contract_line():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "restarts/s" and cb["sample"]
-    assert d["real_arithmetic"]["value"] > 0
+    assert cb["n"] == 300000 and cb["full_size"] is True            # the CPU baseline ran at the bench's own size
+    assert d["real_arithmetic"]["value"] > 0 and d["real_arithmetic"]["spmv_frac"] > 0
+    wl = {w["name"]: w for w in d["workloads"]}
+    assert set(wl) == {"markov", "laplace2d"}
+    for w in wl.values():                                           # north star: Markov / Laplace, fraction of the roofline
+        assert "error" not in w, w
+        assert w["restarts_per_s"] > 0 and 0 < w["spmv_frac"] < 1 and 0 < w["ortho_frac"] < 1
+    assert wl["laplace2d"]["second_pass_fraction"] == 1.0 and wl["markov"]["n"] > 9_000_000

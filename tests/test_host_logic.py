@@ -583,3 +583,45 @@ def test_real_arithmetic_errors(fake):
 
     rc.check_errors()
     rc.check_auto()
+
+
+# ---------------------------------------------------------------------------- locking + dynamic p
+@pytest.mark.parametrize("case", ["mark50_lr", "laplace_lm", "planted_lm"])
+def test_locking_gives_the_oracles_eigenpairs(fake, case):
+    """``partial_schur(..., locking=True)`` (the reference's TODO, README.md:116) against the oracle of the
+    reference's algorithm: same wanted eigenvalues, partial Schur relation and residual bound; locked vectors
+    leave the restart compression (fewer panel bytes per restart) and p grows with them."""
+    import arnoldi_amd
+    from arnoldi_amd import matrices
+
+    if case == "mark50_lr":
+        A, nev, kw, sort_o = matrices.mark(50), 5, dict(max_dim=20, stopping_criterion=1e-8), oracle.arg_largest_real
+    elif case == "laplace_lm":
+        A, nev, kw, sort_o = matrices.laplace2d(30, 31), 6, dict(max_dim=30), oracle.arg_largest_magnitude
+    else:
+        A = matrices.random_csr(6000, 5, 1234, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5))
+        nev, kw, sort_o = 5, dict(max_dim=20), oracle.arg_largest_magnitude
+    np.random.seed(0)
+    Qo, To, ho = oracle.krylov_schur(A, nev, sort_function=sort_o, max_restarts=2000, **kw)
+    np.random.seed(0)
+    st = {}
+    Q, T, h = arnoldi_amd.partial_schur(A, nev, sort_function=sort_o, locking=True, stats=st, max_restarts=2000, **kw)
+    tol = st["tol"]
+    assert st["locked"] == nev and Q.shape == (A.shape[0], nev)
+    np.testing.assert_allclose(np.sort_complex(np.diag(T)), np.sort_complex(np.diag(To)), rtol=50 * tol, atol=50 * tol)
+    assert np.abs(np.tril(T, -1)).max() == 0
+    np.testing.assert_allclose(Q.conj().T @ Q, np.eye(nev), atol=1e-11)
+    # A Q = Q T up to the deflated couplings (each < tol |theta|)
+    scale = np.abs(np.diag(T)).max()
+    assert np.linalg.norm(A @ Q - Q @ T, axis=0).max() < 5 * tol * scale * np.sqrt(nev)
+    _, _, rel = oracle.eig_residuals(A, Q, T)
+    _, _, rel_o = oracle.eig_residuals(A, Qo, To)
+    assert rel.max() <= max(1.05 * rel_o.max(), 10 * tol), (rel.max(), rel_o.max())
+    # restart count in the oracle's ballpark, every History entry set once
+    assert 0 < st["restarts"] <= 2 * int(ho.restarts.max()) + 5
+    assert np.all(h.restarts > 0) and np.all(np.diff(h.restarts) >= 0)
+    # the compression moved fewer bytes once values were locked: 16 n (m + p - 2 l + 2) with growing l
+    tb = st["truncation_bytes"]
+    n, m, p0 = A.shape[0], st["max_dim"], min(nev + 5, st["max_dim"] - 1)
+    assert tb[0] == 16 * n * (m + p0 + 2) and min(tb) < tb[0]
+    assert st["p"] >= p0
