@@ -30,6 +30,19 @@ def family(name):
     return fam
 
 
+def source_stamp():
+    """Same stamp as bench.py: sha256 over the kernel source and the ABI header of the build the counters
+    were collected on (bench.py refuses a summary whose stamp differs from the tree it runs in)."""
+    import hashlib
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for rel in ("arnoldi-py_amd/csrc/aks_kernels.hip", "include/arnoldi_hip.h"):
+        with open(os.path.join(repo, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def main(root):
     out = defaultdict(lambda: {"launches": 0})
     # durations
@@ -62,6 +75,8 @@ def main(root):
         h, m = d.get("TCC_HIT_sum_per_launch"), d.get("TCC_MISS_sum_per_launch")
         if h is not None and m is not None and h + m > 0:
             d["l2_hit_rate"] = round(h / (h + m), 4)
+    out = dict(out)
+    out["_source_stamp"] = source_stamp()
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 
 
