@@ -721,7 +721,7 @@ def test_c_abi_from_plain_c():
 
 def test_lookahead_is_bitwise_neutral(amd, monkeypatch):
     """AKS_LOOKAHEAD=1 (default: A V[:, m] queued behind the copy of H, consumed by
-    aks_arnoldi_expand_from_w) and =0 run the same kernels on the same operands: identical bits."""
+    aks_arnoldi_expand with AKS_EXPAND_FROM_W) and =0 run the same kernels on the same operands: identical bits."""
     from arnoldi_amd import matrices
 
     from arnoldi_amd.engine import CsrOperator

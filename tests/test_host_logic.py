@@ -531,7 +531,7 @@ def test_explicit_restarts_reference_tests_host_logic(fake):
 
 def test_lookahead_application_is_used_and_changes_nothing(fake, monkeypatch):
     """The Krylov-Schur driver queues A V[:, m] behind the copy of H (engine.ArnoldiContext.expand) and
-    starts the next expansion from it (aks_arnoldi_expand_from_w): same iterates as without."""
+    starts the next expansion from it (AKS_EXPAND_FROM_W): same iterates as without."""
     import arnoldi_amd
     from arnoldi_amd import matrices
     from arnoldi_amd.utils import arg_largest_real
