@@ -96,6 +96,26 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
     return r;
 }
 
+// Panel loads.  The Krylov basis (GBs) streams through every Gram-Schmidt kernel once and is far larger than any
+// cache: these loads are non-temporal.  Measured at n = 10M (profiles/ab_kernels.py, r02_b_ab_nt_panel.txt):
+// projection 0.571 -> 0.507 ms at J = 20 (6.6 TB/s), fused update + re-projection 0.647 -> 0.610 ms; 11-14 % at
+// J = 12..16.  AKS_NT_PANEL=0 / AKS_NT_TRUNC=0 rebuild the plain-load variants for A/B runs.
+#ifndef AKS_NT_PANEL
+#define AKS_NT_PANEL 1
+#endif
+#ifndef AKS_NT_TRUNC
+#define AKS_NT_TRUNC 0
+#endif
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ c128 ld_panel(const c128 *p) {
+#if AKS_NT_PANEL
+    const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p));
+    return make_double2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+
 // ---- many-value wave reduction ------------------------------------------------------------
 // Summing K per-lane values over the 64 lanes with K independent butterflies costs 6 K dependent
 // cross-lane moves (2 ds_bpermute each for a double).  Here every step HALVES the values a lane
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *_
         const c128 wv = w[i];
         c128 v[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = Vc[i + (int64_t)c * ldv];
+        for (int c = 0; c < NC; ++c) v[c] = ld_panel(&Vc[i + (int64_t)c * ldv]);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             ar[c] = fma(v[c].x, wv.x, fma(v[c].y, wv.y, ar[c]));
@@ -223,7 +243,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__
         c128 wv = w[i];
         c128 v[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = V[i + (int64_t)c * ldv];
+        for (int c = 0; c < NC; ++c) v[c] = ld_panel(&V[i + (int64_t)c * ldv]);
         double sr = 0.0, si = 0.0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -285,7 +305,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj_split(int64_t n, int J, c
         c128 wv = w[i];
         c128 v[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) v[q] = Vw[i + (int64_t)min(q, cnt - 1) * ldv];
+        for (int q = 0; q < NQ; ++q) v[q] = ld_panel(&Vw[i + (int64_t)min(q, cnt - 1) * ldv]);
         double sr = 0.0, si = 0.0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(BLOCK) void k_update(int64_t n, int J, const c128 *
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int cc = min(c + u, J - 1);  // padded columns re-read a valid one; their h is 0
-                v[u] = V[i + (int64_t)cc * ldv];
+                v[u] = ld_panel(&V[i + (int64_t)cc * ldv]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -455,6 +475,21 @@ __device__ __forceinline__ c128 cmul(c128 a, c128 x) {
     return make_double2(fma(a.x, x.x, -a.y * x.y), fma(a.x, x.y, a.y * x.x));
 }
 
+// Index / value streams of the CSR kernel are read once; x must stay cached.  AKS_NT_CSR=1: non-temporal stream loads.
+#ifndef AKS_NT_CSR
+#define AKS_NT_CSR 0
+#endif
+__device__ __forceinline__ int ld_stream(const int32_t *p) { return AKS_NT_CSR ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ double ld_stream(const double *p) { return AKS_NT_CSR ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ c128 ld_stream(const c128 *p) {
+#if AKS_NT_CSR
+    const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p));
+    return make_double2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+
 template <typename VT, bool ACC>
 __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *__restrict__ indptr,
                                                const int32_t *__restrict__ indices, const VT *__restrict__ vals,
@@ -477,8 +512,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *
 #pragma unroll
             for (int q = 0; q < NPT; ++q) {
                 const int k = min(k0 + q * 64 + lane, k1 - 1);
-                col[q] = indices[k];
-                a[q] = vals[k];
+                col[q] = ld_stream(&indices[k]);
+                a[q] = ld_stream(&vals[k]);
             }
 #pragma unroll
             for (int q = 0; q < NPT; ++q) xv[q] = x[col[q]];
@@ -648,7 +683,13 @@ __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p
             const int c = min(c0 + g, m - 1);            // padded K slots re-read a valid column; their Q rows are 0
             c128 v[NS];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) v[s] = V[rows[s] + (int64_t)c * ldv];
+            for (int s = 0; s < NS; ++s) {
+#if AKS_NT_TRUNC
+                v[s] = ld_panel(&V[rows[s] + (int64_t)c * ldv]);
+#else
+                v[s] = V[rows[s] + (int64_t)c * ldv];
+#endif
+            }
             const c128 *qrow = qs + (c0 + g) * PP;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -723,6 +764,19 @@ __device__ __forceinline__ void store_stream(c128 v, c128 *p) {      // written 
 }
 __device__ __forceinline__ void store_stream(double v, double *p) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ double cmul(double a, double x) { return a * x; }
+#ifndef AKS_NT_PB
+#define AKS_NT_PB 0              // A/B knob: non-temporal loads of the streams the binned kernels read once
+#endif
+__device__ __forceinline__ double ld_once(const double *p) { return AKS_NT_PB ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ c128 ld_once(const c128 *p) {
+#if AKS_NT_PB
+    const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+    return make_double2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ int ld_once(const uint16_t *p) { return AKS_NT_PB ? (int)__builtin_nontemporal_load(p) : (int)*p; }
 
 // Phase 1: prod[k] = val[k] * x[slab * 8192 + lcol[k]] for the sub-slab's entries; x slice in LDS.
 // VT: value type (double | c128), XT: vector entry type (c128 | double for real-packed vectors).
@@ -747,8 +801,8 @@ __global__ __launch_bounds__(PB_P1_THREADS) void k_pb_phase1(int64_t n_cols, con
 #pragma unroll
         for (int u = 0; u < PB_P1_U; ++u) {
             const int k = min(base + u * PB_P1_THREADS + (int)threadIdx.x, k1 - 1);
-            a[u] = val[k];
-            c[u] = lcol[k];
+            a[u] = ld_once(&val[k]);
+            c[u] = ld_once(&lcol[k]);
         }
 #pragma unroll
         for (int u = 0; u < PB_P1_U; ++u) {
@@ -862,7 +916,7 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
                 const unsigned start = __builtin_amdgcn_readlane(dv.x, j * PB_K + k);
                 const unsigned inf = __builtin_amdgcn_readlane(dv.y, j * PB_K + k);
                 info[d][k] = inf;
-                p[d][k] = prod[start + min((unsigned)lane, max(inf & 255u, 1u) - 1u)];
+                p[d][k] = ld_once(&prod[start + min((unsigned)lane, max(inf & 255u, 1u) - 1u)]);
             }
         }
     }

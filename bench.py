@@ -583,6 +583,7 @@ def run_rank(args, argv):
 
     if comm is not None:
         comm.barrier()
+        comm.close()                      # the library's own RCCL communicator, if one was made
         dist.destroy_process_group()
 
     # ---- extra legs (one GPU only): child processes, after this process has released the GPU memory

@@ -8,7 +8,7 @@ rounds, libs, bargs = int(sys.argv[1]), sys.argv[2:sep], sys.argv[sep + 1:]
 res = {l: [] for l in libs}
 for _ in range(rounds):
     for l in libs:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-real-leg"] + bargs,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-real-leg", "--no-workloads"] + bargs,
                            capture_output=True, text=True, env=dict(os.environ, AKS_LIB_PATH=os.path.abspath(l)))
         if r.returncode:
             print(r.stderr[-1500:]); sys.exit(1)
