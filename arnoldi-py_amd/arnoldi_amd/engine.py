@@ -412,11 +412,7 @@ class ArnoldiContext:
         loc = self.local_columns(j0, j1)
         if self.comm is None or self.comm.size == 1:
             return np.asfortranarray(loc)
-        import torch.distributed as dist
-
-        parts = [None] * self.comm.size
-        dist.all_gather_object(parts, np.ascontiguousarray(loc), group=self.comm.group)
-        return np.asfortranarray(np.concatenate(parts, axis=0))
+        return np.asfortranarray(self.comm.allgather_rows(loc))
 
     # -- verification on the device -----------------------------------------
     def true_residuals(self, T):
@@ -427,9 +423,40 @@ class ArnoldiContext:
         ``vecs = Q S``, ``residual_norms`` does the rest."""
         k = T.shape[0]
         vals, S = np.linalg.eig(T)
+        if self.real:
+            res = self._residual_norms_real(k, S, vals)
+            return vals, res, res / np.abs(vals)
         vecs = self.combine(0, k, S)                              # aks_combine: vecs = Q S, out of place
         res = self.residual_norms(vecs, vals)
         return vals, res, res / np.abs(vals)
+
+    def _residual_norms_real(self, k, S, vals):
+        """Real-packed basis (``Q`` real, eigenvectors ``u = Q S`` complex): with ``u = ur + i ui``,
+        ``ur = Q Re S`` and ``ui = Q Im S`` are two real combinations (``aks_combine`` with real coefficients),
+        ``A u`` is two real operator applications, and
+        ``Re r = A ur - (lr ur - li ui)``, ``Im r = A ui - (li ur + lr ui)`` are J = 2 fused updates of the
+        real-packed stage kernels on the panel ``[ur, ui]`` whose norm outputs add up to ``||A u - l u||^2``.
+        Nothing of length n leaves the device."""
+        b, ws, lib = self.basis, self.ws, _hip.load()
+        self._clear_ctrl()
+        S = np.asarray(S, dtype=C128).reshape(k, -1)
+        out = np.zeros(len(vals))
+        y = self._scratch_col()
+        args = (dev._ptr(ws.buf), ws.nbytes, ws.max_dim, dev._stream())
+        red1, red2 = ws.red(1, 2), ws.red(2, 3)
+        for i, lam in enumerate(np.asarray(vals, dtype=C128)):
+            pair = self.combine(0, k, np.stack([S[:, i].real, S[:, i].imag], axis=1).astype(C128))   # [ur, ui]
+            total = 0.0
+            for col, coef in ((0, (lam.real, -lam.imag)), (1, (lam.imag, lam.real))):
+                self.op.apply(pair.col(col), y, ws)
+                red1.copy_(torch.tensor([coef[0], 0.0, coef[1], 0.0], dtype=torch.float64, device=b.device))
+                _hip.check(lib.aks_gs_update_project(b.n_rows, 2, dev._ptr(pair.V), pair.ldv, dev._ptr(y), *args),
+                           "aks_gs_update_project")
+                if self._multi():
+                    self.comm.allreduce_sum_(red2)
+                total += float(red2[4].item())
+            out[i] = np.sqrt(total)
+        return out
 
     # -- building blocks of the explicit-restart solvers (SURVEY 8(f) rank 3) ---------------------
     # All of them work on columns of the resident basis; nothing of length n moves to the host.
@@ -501,7 +528,8 @@ class ArnoldiContext:
         ``aks_gs_update_project`` with J = 1 and coefficient values[i], whose norm output is
         ``||A u_i - values[i] u_i||^2``."""
         if self.real:
-            raise NotImplementedError("device-side residuals need the complex basis (eigenvectors are complex)")
+            raise NotImplementedError("real-packed basis: use true_residuals() (eigenvectors are complex pairs of "
+                                      "real-packed columns)")
         b, ws, lib = self.basis, self.ws, _hip.load()
         self._clear_ctrl()
         values = np.atleast_1d(np.asarray(values, dtype=C128))
@@ -529,11 +557,7 @@ class ArnoldiContext:
         loc = block.get_cols()
         if self.comm is None or self.comm.size == 1:
             return np.asfortranarray(loc)
-        import torch.distributed as dist
-
-        parts = [None] * self.comm.size
-        dist.all_gather_object(parts, np.ascontiguousarray(loc), group=self.comm.group)
-        return np.asfortranarray(np.concatenate(parts, axis=0))
+        return np.asfortranarray(self.comm.allgather_rows(loc))
 
 
 def default_comm():

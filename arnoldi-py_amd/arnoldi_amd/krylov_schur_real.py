@@ -152,6 +152,13 @@ class RealKrylovSchurSolver:
                                  consume_lookahead=True)
         return self.m
 
+    def true_residuals(self):
+        """Eigenvalues of the converged real partial Schur form with ``||A v - l v||`` and ``||A v - l v|| / |l|``
+        evaluated on the device (real-packed kernels; no n-vector leaves the GPU).  All ``nev_now`` values: the
+        partner of a pair cut at ``nev`` is included."""
+        k = self.nev_now
+        return self.ctx.true_residuals(self.H[:k, :k])
+
     def result(self, gather=True):
         """``(Q, T, history)`` in the reference's form: the real partial Schur pair (``nev`` columns, one
         more if that completes a conjugate pair) is rotated to complex upper-triangular form on the host

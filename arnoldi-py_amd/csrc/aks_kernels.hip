@@ -471,6 +471,7 @@ constexpr int TILE = AKS_SPMV_TILE_NNZ;  // non-zeros per wave tile
 constexpr int NPT = TILE / 64;           // per lane
 
 __device__ __forceinline__ c128 cmul(double a, c128 x) { return make_double2(a * x.x, a * x.y); }
+__device__ __forceinline__ double cmul(double a, double x) { return a * x; }
 __device__ __forceinline__ c128 cmul(c128 a, c128 x) {
     return make_double2(fma(a.x, x.x, -a.y * x.y), fma(a.x, x.y, a.y * x.x));
 }
@@ -490,14 +491,23 @@ __device__ __forceinline__ c128 ld_stream(const c128 *p) {
 #endif
 }
 
-template <typename VT, bool ACC>
+// XT: vector entry type -- c128, or double for real vectors (real-packed mode: 8-byte gathers, one LDS plane).
+__device__ __forceinline__ double xt_re(c128 v) { return v.x; }
+__device__ __forceinline__ double xt_im(c128 v) { return v.y; }
+__device__ __forceinline__ double xt_re(double v) { return v; }
+__device__ __forceinline__ double xt_im(double) { return 0.0; }
+__device__ __forceinline__ void xt_make(double re, double im, c128 *out) { *out = make_double2(re, im); }
+__device__ __forceinline__ void xt_make(double re, double, double *out) { *out = re; }
+
+template <typename VT, typename XT, bool ACC>
 __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *__restrict__ indptr,
                                                const int32_t *__restrict__ indices, const VT *__restrict__ vals,
                                                const int32_t *__restrict__ tiles, int lpr,
-                                               const c128 *__restrict__ x, c128 *__restrict__ y,
+                                               const XT *__restrict__ x, XT *__restrict__ y,
                                                const aks_ctrl *__restrict__ ctrl) {
     if (ctrl != nullptr && ctrl->broken) return;
-    __shared__ double pr[WAVES][TILE], pi[WAVES][TILE];
+    constexpr bool CPLX = sizeof(XT) == sizeof(c128);
+    __shared__ double pr[WAVES][TILE], pi[CPLX ? WAVES : 1][CPLX ? TILE : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = (int64_t)blockIdx.x * WAVES + wave;
     if (t >= n_tiles) return;  // waves are independent: no block-level barrier below
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *
         if (nnz > 0) {
             int col[NPT];
             VT a[NPT];
-            c128 xv[NPT];
+            XT xv[NPT];
 #pragma unroll
             for (int q = 0; q < NPT; ++q) {
                 const int k = min(k0 + q * 64 + lane, k1 - 1);
@@ -521,9 +531,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *
             for (int q = 0; q < NPT; ++q) {
                 const int s = q * 64 + lane;
                 if (s < nnz) {
-                    const c128 p = cmul(a[q], xv[q]);
-                    pr[wave][s] = p.x;
-                    pi[wave][s] = p.y;
+                    const XT p = cmul(a[q], xv[q]);
+                    pr[wave][s] = xt_re(p);
+                    if (CPLX) pi[wave][s] = xt_im(p);
                 }
             }
         }
@@ -540,98 +550,40 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *
                 const int a0 = indptr[r] - k0, a1 = indptr[r + 1] - k0;
                 for (int s = a0 + sub; s < a1; s += lpr) {
                     sr += pr[wave][s];
-                    si += pi[wave][s];
+                    if (CPLX) si += pi[wave][s];
                 }
             }
             for (int off = lpr >> 1; off > 0; off >>= 1) {
                 sr += __shfl_xor(sr, off, 64);
-                si += __shfl_xor(si, off, 64);
+                if (CPLX) si += __shfl_xor(si, off, 64);
             }
             if (r < r1 && sub == 0) {
                 if (ACC) {
-                    const c128 old = y[r];
-                    sr += old.x;
-                    si += old.y;
+                    const XT old = y[r];
+                    sr += xt_re(old);
+                    si += xt_im(old);
                 }
-                y[r] = make_double2(sr, si);
+                xt_make(sr, si, &y[r]);
             }
         }
     } else {
         // one long row per tile: the wave strides over it
         double sr = 0.0, si = 0.0;
         for (int k = k0 + lane; k < k1; k += 64) {
-            const c128 p = cmul(vals[k], x[indices[k]]);
-            sr += p.x;
-            si += p.y;
+            const XT p = cmul(vals[k], x[indices[k]]);
+            sr += xt_re(p);
+            si += xt_im(p);
         }
         sr = wave_sum(sr);
-        si = wave_sum(si);
+        if (CPLX) si = wave_sum(si);
         if (lane == 0) {
             if (ACC) {
-                const c128 old = y[r0];
-                sr += old.x;
-                si += old.y;
+                const XT old = y[r0];
+                sr += xt_re(old);
+                si += xt_im(old);
             }
-            y[r0] = make_double2(sr, si);
+            xt_make(sr, si, &y[r0]);
         }
-    }
-}
-
-// Real vectors (real-packed mode): x, y are float64 arrays, values float64.  Same tiling as k_spmv;
-// gathers are 8 bytes, one LDS plane.
-template <bool ACC>
-__global__ __launch_bounds__(BLOCK) void k_spmv_real(int64_t n_tiles, const int32_t *__restrict__ indptr,
-                                                    const int32_t *__restrict__ indices,
-                                                    const double *__restrict__ vals,
-                                                    const int32_t *__restrict__ tiles, int lpr,
-                                                    const double *__restrict__ x, double *__restrict__ y,
-                                                    const aks_ctrl *__restrict__ ctrl) {
-    if (ctrl != nullptr && ctrl->broken) return;
-    __shared__ double pr[WAVES][TILE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t t = (int64_t)blockIdx.x * WAVES + wave;
-    if (t >= n_tiles) return;
-    const int r0 = tiles[t], r1 = tiles[t + 1];
-    const int k0 = indptr[r0], k1 = indptr[r1];
-    const int nnz = k1 - k0;
-    if (nnz <= TILE) {
-        if (nnz > 0) {
-            int col[NPT];
-            double a[NPT], xv[NPT];
-#pragma unroll
-            for (int q = 0; q < NPT; ++q) {
-                const int k = min(k0 + q * 64 + lane, k1 - 1);
-                col[q] = indices[k];
-                a[q] = vals[k];
-            }
-#pragma unroll
-            for (int q = 0; q < NPT; ++q) xv[q] = x[col[q]];
-#pragma unroll
-            for (int q = 0; q < NPT; ++q) {
-                const int s = q * 64 + lane;
-                if (s < nnz) pr[wave][s] = a[q] * xv[q];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int rows_per_pass = 64 / lpr;
-        const int sub = lane % lpr;
-        for (int rb = r0; rb < r1; rb += rows_per_pass) {
-            const int r = rb + lane / lpr;
-            double sr = 0.0;
-            if (r < r1) {
-                const int a0 = indptr[r] - k0, a1 = indptr[r + 1] - k0;
-                for (int s = a0 + sub; s < a1; s += lpr) sr += pr[wave][s];
-            }
-            for (int off = lpr >> 1; off > 0; off >>= 1) sr += __shfl_xor(sr, off, 64);
-            if (r < r1 && sub == 0) y[r] = ACC ? y[r] + sr : sr;
-        }
-    } else {
-        double sr = 0.0;
-        for (int k = k0 + lane; k < k1; k += 64) sr = fma(vals[k], x[indices[k]], sr);
-        sr = wave_sum(sr);
-        if (lane == 0) y[r0] = ACC ? y[r0] + sr : sr;
     }
 }
 
@@ -736,8 +688,9 @@ __global__ __launch_bounds__(BLOCK) void k_scale(int64_t n, c128 *__restrict__ w
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) w[i] = cmul(alpha, w[i]);
 }
 
+template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_gather(int64_t count, const int32_t *__restrict__ idx,
-                                                 const c128 *__restrict__ src, c128 *__restrict__ dst) {
+                                                 const T *__restrict__ src, T *__restrict__ dst) {
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) dst[i] = src[idx[i]];
 }
@@ -763,7 +716,6 @@ __device__ __forceinline__ void store_stream(c128 v, c128 *p) {      // written 
     __builtin_nontemporal_store(t, reinterpret_cast<v2d *>(p));
 }
 __device__ __forceinline__ void store_stream(double v, double *p) { __builtin_nontemporal_store(v, p); }
-__device__ __forceinline__ double cmul(double a, double x) { return a * x; }
 #ifndef AKS_NT_PB
 #define AKS_NT_PB 0              // A/B knob: non-temporal loads of the streams the binned kernels read once
 #endif
@@ -928,12 +880,6 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
             y[row0 + i] = v;
         }
     }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_gather_f64(int64_t count, const int32_t *__restrict__ idx,
-                                                     const double *__restrict__ src, double *__restrict__ dst) {
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) dst[i] = src[idx[i]];
 }
 
 // ------------------------------------------------------------------ host-side plumbing
@@ -1242,15 +1188,15 @@ int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indic
     if (values_complex) {
         const c128 *v = static_cast<const c128 *>(d_values);
         if (accumulate)
-            hipLaunchKernelGGL((k_spmv<c128, true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
+            hipLaunchKernelGGL((k_spmv<c128, c128, true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
         else
-            hipLaunchKernelGGL((k_spmv<c128, false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
+            hipLaunchKernelGGL((k_spmv<c128, c128, false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
     } else {
         const double *v = static_cast<const double *>(d_values);
         if (accumulate)
-            hipLaunchKernelGGL((k_spmv<double, true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
+            hipLaunchKernelGGL((k_spmv<double, c128, true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
         else
-            hipLaunchKernelGGL((k_spmv<double, false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
+            hipLaunchKernelGGL((k_spmv<double, c128, false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
     }
     AKS_CHECK_LAUNCH("k_spmv");
     return AKS_OK;
@@ -1269,10 +1215,10 @@ int aks_csr_spmv_real(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((n_tiles + WAVES - 1) / WAVES));
     if (accumulate)
-        hipLaunchKernelGGL((k_spmv_real<true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, d_values, d_tiles, lpr, d_x, d_y, ctrl);
+        hipLaunchKernelGGL((k_spmv<double, double, true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, d_values, d_tiles, lpr, d_x, d_y, ctrl);
     else
-        hipLaunchKernelGGL((k_spmv_real<false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, d_values, d_tiles, lpr, d_x, d_y, ctrl);
-    AKS_CHECK_LAUNCH("k_spmv_real");
+        hipLaunchKernelGGL((k_spmv<double, double, false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, d_values, d_tiles, lpr, d_x, d_y, ctrl);
+    AKS_CHECK_LAUNCH("k_spmv (real vectors)");
     return AKS_OK;
 }
 
@@ -1846,7 +1792,7 @@ int aks_gather_c128(int64_t count, const int32_t *d_idx, const aks_c128 *d_src, 
     if (count < 0 || !d_idx || !d_src || !d_dst) return fail(AKS_ERR_ARG, "bad argument");
     const int64_t want = (count + BLOCK - 1) / BLOCK;
     const dim3 grid((unsigned)(want < 4096 ? want : 4096));
-    hipLaunchKernelGGL(k_gather, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), count, d_idx,
+    hipLaunchKernelGGL(k_gather<c128>, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), count, d_idx,
                        reinterpret_cast<const c128 *>(d_src), reinterpret_cast<c128 *>(d_dst));
     AKS_CHECK_LAUNCH("k_gather");
     return AKS_OK;
@@ -1857,7 +1803,7 @@ int aks_gather_f64(int64_t count, const int32_t *d_idx, const double *d_src, dou
     if (count < 0 || !d_idx || !d_src || !d_dst) return fail(AKS_ERR_ARG, "bad argument");
     const int64_t want = (count + BLOCK - 1) / BLOCK;
     const dim3 grid((unsigned)(want < 4096 ? want : 4096));
-    hipLaunchKernelGGL(k_gather_f64, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), count, d_idx, d_src,
+    hipLaunchKernelGGL(k_gather<double>, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), count, d_idx, d_src,
                        d_dst);
     AKS_CHECK_LAUNCH("k_gather_f64");
     return AKS_OK;

@@ -46,6 +46,16 @@ def check_case(A, nev, seed, **kw):
     assert rel.max() <= max(1.05 * rel_o.max(), 10 * float(st["tol"])), (rel, rel_o)
     scale = np.abs(np.diag(T)).max()
     assert np.linalg.norm(A @ Q - Q @ T, axis=0).max() <= 50 * float(st["tol"]) * scale
+    # residuals of the real partial Schur form evaluated on the device (real-packed kernels: two real operator
+    # applications + two J = 2 fused updates per eigenvector) against the same quantity on the host
+    solver = st["solver"]
+    k = solver.nev_now
+    dvals, dres, drel = solver.true_residuals()
+    Qr = solver.ctx.gather_columns(0, k)
+    hv, hS = np.linalg.eig(solver.H[:k, :k])
+    hres = np.linalg.norm(A @ (Qr @ hS) - (Qr @ hS) * hv, axis=0)
+    np.testing.assert_allclose(dvals, hv, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(dres, hres, rtol=1e-6, atol=1e-13 * max(scale, 1.0))
     # restart counts are close to the complex iteration's (not necessarily equal)
     assert abs(int(st["restarts"]) - int(histo.restarts.max())) <= max(3, int(0.3 * histo.restarts.max()))
     return st
