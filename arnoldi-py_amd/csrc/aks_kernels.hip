@@ -99,12 +99,15 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
 // Panel loads.  The Krylov basis (GBs) streams through every Gram-Schmidt kernel once and is far larger than any
 // cache: these loads are non-temporal.  Measured at n = 10M (profiles/ab_kernels.py, r02_b_ab_nt_panel.txt):
 // projection 0.571 -> 0.507 ms at J = 20 (6.6 TB/s), fused update + re-projection 0.647 -> 0.610 ms; 11-14 % at
-// J = 12..16.  AKS_NT_PANEL=0 / AKS_NT_TRUNC=0 rebuild the plain-load variants for A/B runs.
+// J = 12..16.  AKS_NT_PANEL=0 / AKS_NT_TRUNC=0 / AKS_NT_TRUNC_STORE=0 rebuild the plain variants for A/B runs.
 #ifndef AKS_NT_PANEL
 #define AKS_NT_PANEL 1
 #endif
-#ifndef AKS_NT_TRUNC
-#define AKS_NT_TRUNC 0
+#ifndef AKS_NT_TRUNC             // restart compression: panel loads and the stores of the compressed columns, both
+#define AKS_NT_TRUNC 1            // streamed once: 1.005 -> 0.956 ms at m = 20, p = 10, n = 10M with 128 rows per wave
+#endif                           // (profiles/r02_c_ab_truncate.txt; with 64 rows per wave the load hint alone was neutral)
+#ifndef AKS_NT_TRUNC_STORE
+#define AKS_NT_TRUNC_STORE 1
 #endif
 typedef double v2d_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ c128 ld_panel(const c128 *p) {
@@ -665,7 +668,14 @@ __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p
                     for (int r = 0; r < 4; ++r) {
                         const int jj = mt * 16 + g + 4 * r;      // real output column held in register r
                         const int j = jj >> 1;
-                        if (j < p) reinterpret_cast<double *>(O + row + (int64_t)j * ldo)[jj & 1] = acc[s][mt][r];
+                        if (j < p) {
+                            double *dst = reinterpret_cast<double *>(O + row + (int64_t)j * ldo) + (jj & 1);
+#if AKS_NT_TRUNC_STORE
+                            __builtin_nontemporal_store(acc[s][mt][r], dst);
+#else
+                            *dst = acc[s][mt][r];
+#endif
+                        }
                     }
                 }
             }
@@ -992,7 +1002,9 @@ void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c12
 template <int MT>
 int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_t ldv, const c128 *Qp, c128 *O,
                          int64_t ldo, int copy_last) {
-    constexpr int NS = MT <= 9 ? 4 : 2;      // keeps NS * MT * 8 accumulator registers below the spill point
+    // rows per wave = 16 NS: 128 for p <= 16 (more loads in flight per K-step: 1.041 -> 1.011 ms at m = 20, p = 10,
+    // n = 10M; the read/write mix of this kernel streams at ~5.4 TB/s = 0.95 ms), fewer as the accumulators grow
+    constexpr int NS = MT <= 2 ? 8 : (MT <= 9 ? 4 : 2);      // keeps NS * MT * 8 accumulator registers below the spill point
     const size_t smem = (size_t)((m + 3) & ~3) * MT * 8 * sizeof(c128);
     if (smem > 160 * 1024) return fail(AKS_ERR_UNSUPPORTED, "Qp does not fit the 160 KiB LDS");
     static size_t smem_allowed = 48 * 1024;   // per instantiation (one process drives one GPU): raise once
