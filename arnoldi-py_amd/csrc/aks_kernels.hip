@@ -4,16 +4,16 @@
 // the design goal is "every byte of V / CSR crosses HBM once per stage, in 16-byte
 // per-lane, 1-KiB per-wave coalesced loads, with enough of them in flight".
 //
-//   k_spmv          CSR-stream SpMV: one 64-lane wave per tile of <= 256 non-zeros;
-//                   indices/values are read coalesced, x is gathered (16 B/lane),
-//                   products are staged in LDS and rows are summed from LDS by
+//   k_spmv<VT,XT>   CSR-stream SpMV: one 64-lane wave per tile of <= 256 non-zeros;
+//                   indices/values are read coalesced, x is gathered (16 B/lane; 8 B for real
+//                   vectors), products are staged in LDS and rows are summed from LDS by
 //                   1..64 lanes per row.                (reference: decomposition.py:58)
-//   k_proj<NC>      tall-skinny  V[:, c0:c0+NC]^H w  with one lane per row and NC
-//                   complex accumulators per lane (exact NC: no masked loads), plus
-//                   ||w||^2.                            (ortho.py:92-94, 102)
 //   k_pb_phase1/2   the same operator for matrices without column locality: products are formed
 //                   sub-slab by sub-slab (8192 x entries staged in LDS) and written sequentially,
 //                   then summed per 8192-row block in LDS (levels + barriers keep the order fixed).
+//   k_proj<NC>      tall-skinny  V[:, c0:c0+NC]^H w  with one lane per row and NC
+//                   complex accumulators per lane (exact NC: no masked loads), plus
+//                   ||w||^2.                            (ortho.py:92-94, 102)
 //   k_update_proj<NC>  w -= V h fused with the re-projection V^H w and ||w||^2: the
 //                   row's NC panel entries stay in registers between the two uses,
 //                   so the panel is read once instead of twice.   (ortho.py:96-98,102)
@@ -25,10 +25,15 @@
 //   k_finish        H column, beta, breakdown test, w /= beta.
 //                                                       (ortho.py:95,103,107; decomposition.py:61-66)
 //   k_truncate_mfma<MT,NS>  V[:, :p] = V[:, :m] Qp in place on v_mfma_f64_16x16x4_f64 (one wave owns
-//                   64 rows), V[:, p] = V[:, m].        (krylov_schur.py:78,81)
+//                   16 NS rows), V[:, p] = V[:, m].     (krylov_schur.py:78,81)
+//   host side       aks_shard_apply / aks_arnoldi_expand chain these per Arnoldi step; with an RCCL
+//                   communicator (aks_comm_*) they also issue the ghost exchange of the SpMV and the
+//                   all-reduces between the Gram-Schmidt stages: one C call per expansion on every rank.
 //
-// Reductions are two-stage (per-block partials, then one fixed-order sum) and the only atomics
-// are LDS adds issued by a single wave in program order: results are bitwise reproducible.
+// Reductions are two-stage (per-block partials, then one fixed-order sum); the only atomics are LDS
+// adds whose order is fixed by construction (one wave in program order, or level by level behind
+// workgroup barriers in k_pb_phase2): results are bitwise reproducible.  Panel streams that are
+// read once (the Krylov basis in the Gram-Schmidt and compression kernels) use non-temporal loads.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
