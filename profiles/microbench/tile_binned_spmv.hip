@@ -653,6 +653,9 @@ __global__ __launch_bounds__(256) void k_stream_p2(int64_t nnz, const c128 *__re
     }
     if (s == 1.2345e300) out[blockIdx.x] = s;     // never true: keeps the loads
 }
+__global__ void k_permute(int64_t n, const uint32_t *perm, const c128 *in, c128 *out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[perm[i]];
+}
 __global__ void k_fill_x(int64_t n, c128 *x) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         x[i] = make_double2(std::sin(0.001 * (double)(i % 100003)) + 0.5, std::cos(0.003 * (double)(i % 70001)));
@@ -783,17 +786,40 @@ int main(int argc, char **argv) {
         }
 
         if (W == 8) {
-            auto runL = [&](auto kern, int Wl, int Kl, const char *name, bool strict = false) {
+            auto runL = [&](auto kern, int Wl, int Kl, const char *name, bool strict = false, bool contig = false) {
                 PlanL L;
                 auto t1 = std::chrono::steady_clock::now();
                 make_plan_L(P, Wl, Kl, L, strict);
                 const double ps = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+                const c128 *prod_in = prod;
+                c128 *prod2 = nullptr;
+                if (contig) {
+                    // HYPOTHETICAL layout for the experiment: the runs of a row block back to back (what phase 2 would
+                    // read if phase 1 scattered its runs into row-block-major order): is phase 2 bound by the 528-byte
+                    // granularity of its reads?
+                    std::vector<uint32_t> perm(P.nnz_pad, 0);
+                    std::vector<uint16_t> lv2(P.nnz_pad, 0);
+                    uint32_t pos = 0;
+                    for (size_t r = 0; r < L.desc.size(); ++r) {
+                        const uint32_t st = L.desc[r].x, len = L.desc[r].y & 255u;
+                        for (uint32_t i = 0; i < len; ++i) { perm[pos + i] = st + i; lv2[pos + i] = L.lrow_lv[st + i]; }
+                        L.desc[r].x = pos;
+                        pos += len;
+                    }
+                    L.lrow_lv = lv2;
+                    uint32_t *d_perm = upload(perm);
+                    CK(hipMalloc(&prod2, P.nnz_pad * sizeof(c128)));
+                    hipLaunchKernelGGL(k_permute, dim3(4096), dim3(256), 0, 0, P.nnz_pad, d_perm, prod, prod2);
+                    CK(hipDeviceSynchronize());
+                    CK(hipFree(d_perm));
+                    prod_in = prod2;
+                }
                 uint2 *d_desc = upload(L.desc);
                 int32_t *d_rp = upload(L.rb_run_ptr);
                 uint16_t *d_lv = upload(L.lrow_lv);
                 set_lds(reinterpret_cast<const void *>(kern), lds2);
                 CK(hipMemset(y, 0xff, n * sizeof(c128)));
-                auto launch = [&] { hipLaunchKernelGGL(kern, dim3(rbx * 8), dim3(Wl * 64), lds2, 0, n, P.n_rb, rbx, d_rp, d_desc, d_lv, prod, y); };
+                auto launch = [&] { hipLaunchKernelGGL(kern, dim3(rbx * 8), dim3(Wl * 64), lds2, 0, n, P.n_rb, rbx, d_rp, d_desc, d_lv, prod_in, y); };
                 const double ms = time_ms(launch);
                 CK(hipMemcpy(h_y.data(), y, n * sizeof(c128), hipMemcpyDeviceToHost));
                 std::vector<c128> first(h_y);
@@ -807,9 +833,12 @@ int main(int argc, char **argv) {
                        bytes / ms / 1e9, err, same ? "yes" : "NO", L.mean_phases, ps);
                 best2 = std::min(best2, ms);
                 CK(hipFree(d_desc)); CK(hipFree(d_rp)); CK(hipFree(d_lv));
+                if (prod2) CK(hipFree(prod2));
             };
             runL(k_phase2V<8, 4, 2, false>, 8, 4, "atomics, vector desc, 8 waves x 4 runs, depth 2");
             if (prof) return 0;
+            runL(k_phase2V<8, 4, 2, false>, 8, 4, "same kernel, runs of a row block CONTIGUOUS", false, true);
+            runL(k_phase2V<8, 4, 4, false>, 8, 4, "depth 4, runs of a row block CONTIGUOUS", false, true);
             runL(k_phase2L<8, 4, 3>, 8, 4, "atomics, s_load desc, 8 waves x 4 runs, depth 3");
             runL(k_phase2V<8, 4, 4, false>, 8, 4, "atomics, vector desc, 8 waves x 4 runs, depth 4");
             runL(k_phase2V<8, 2, 4, false>, 8, 2, "atomics, vector desc, 8 waves x 2 runs, depth 4");
