@@ -228,7 +228,11 @@ class ArnoldiContext:
         self.probe = None   # optional _hip.Probe (bench.py): device time of SpMV / ortho launches
         self.spmv_events = None  # optional list (bench.py, Python-chained path): torch event pairs
         self.force_chained = False  # run the Python-chained stage path even on one GPU (tests, bench)
-        self.use_graph = os.environ.get("AKS_GRAPH", "0") == "1"   # hipGraph replay of re-expansions (opt-in)
+        # hipGraph replay of re-expansions: AKS_GRAPH=1 always, =0 never; default "auto" = for shards of at most
+        # 4M rows, whose kernels last 20-150 us, so that the restart rate follows the host's launch latency (same box,
+        # 2-D Laplace n = 1M: 50 / 119 restarts/s eager in a cold / warm process, 125 replayed in both)
+        mode = os.environ.get("AKS_GRAPH", "auto")
+        self.use_graph = mode == "1" or (mode == "auto" and getattr(op, "n_local", 1 << 62) <= 4_000_000)
         self._graphs = {}
         # look-ahead operator application (see expand): off with AKS_LOOKAHEAD=0
         self.allow_lookahead = os.environ.get("AKS_LOOKAHEAD", "1") != "0"
@@ -326,7 +330,7 @@ class ArnoldiContext:
         # relative to the kernels).  Not used while a probe records per-kernel events, nor with
         # collectives in the sequence.
         key = (start, end, float(tol), float(eta), w_ready)
-        if self.use_graph and self.probe is None and start > 0 and not op.native_comm:
+        if self.use_graph and self.probe is None and start > 0 and not op.native_comm and b.V.is_cuda:
             g = self._graphs.get(key)
             if g is None:
                 g = torch.cuda.CUDAGraph()

@@ -587,7 +587,7 @@ def test_graph_replay_gives_identical_results(amd, monkeypatch):
 
     A = mark(50)
     out = []
-    for flag in ("0", "1"):
+    for flag in ("0", "1"):                            # (default "auto" = replay for shards of <= 4M rows)
         monkeypatch.setenv("AKS_GRAPH", flag)
         np.random.seed(0)
         st = {}
