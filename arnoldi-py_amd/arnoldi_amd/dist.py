@@ -9,8 +9,12 @@ The reference has no distributed code; this is the layout SURVEY 8(e) fixes:
     of the x entries other shards need before each SpMV (all-to-all of packed
     "ghost" entries; the local (diagonal-block) SpMV runs while it is in flight).
 
-Everything in this file is host logic (numpy planning + torch.distributed calls);
-it never touches matrix values on the CPU after the plan is built.
+Everything in this file is host logic (numpy planning + set-up exchanges over torch.distributed);
+it never touches matrix values on the CPU after the plan is built.  On the data path of an RCCL
+group the collectives are issued by libarnoldi_hip.so itself (``Comm.native()`` hands it a
+communicator, ``aks_shard_apply`` / ``aks_arnoldi_expand`` do the rest); the torch.distributed
+data-path calls below serve gloo groups (CPU tests, several test ranks on one GPU) and
+AKS_DIST_PATH=python.
 """
 from __future__ import annotations
 

@@ -8,10 +8,12 @@ workspace, and exposes the two O(n) seams of the reference's driver:
   * ``truncate(Qp, m, p)``          == V[:, :p] = V[:, :m] @ Qp ; V[:, p] = V[:, m]
                                                    (src/arnoldi/krylov_schur.py:78,81)
 
-With one rank and a CSR operator the whole expansion is one C call
-(``aks_arnoldi_expand``) that enqueues every kernel with no host round trip; with
-several ranks the same stage kernels are chained from Python with an RCCL
-all-reduce of the (J+1)-vector between stages.
+With a CSR operator the whole expansion is one C call (``aks_arnoldi_expand`` on the
+operator's ``aks_shard``) that enqueues every kernel with no host round trip -- on one GPU,
+and on every rank of a row-sharded solve over RCCL, where the same call also issues the
+ghost exchange of each SpMV and the all-reduces of the (J+1)-vector between the
+Gram-Schmidt stages on the library's own communicator.  Only opaque host operators and
+non-RCCL process groups (gloo: CPU tests) chain the stage kernels from Python.
 """
 from __future__ import annotations
 
