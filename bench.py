@@ -16,8 +16,9 @@ The line printed by rank 0 also carries
   roofline        live HIP-event timing of the SpMV launches inside the timed region,
                   algorithmic bytes (12 nnz + 36 n + 4) / average launch time vs 8 TB/s;
   roofline_ortho  the same for the Gram-Schmidt launches of the timed region;
-  workloads       (N = 1) the structured matrices the north star names -- Markov n = 10M and the
-                  2-D Laplacian of BASELINE config 2 -- through the same measurement, a few restarts each;
+  workloads       (N = 1) the other matrices of BASELINE.json -- Markov n = 10M (config 1 scaled), the 2-D Laplacian
+                  of config 2, the banded stand-in for config 3 and the 3-D Laplacian of config 4 (on one GPU) --
+                  through the same measurement, a few restarts each;
   real_arithmetic (N = 1) the same default workload with partial_schur(arithmetic="real");
   cpu_baseline    (N = 1) the CPU oracle (NumPy/SciPy restatement of the reference, validated against
                   the reference's golden outputs) timed on this host at the full problem size.
@@ -628,7 +629,11 @@ def run_rank(args, argv):
                 legs = []
                 for name, extra in (("markov", ["--workload", "markov", "--rows", "10000000"]),
                                     ("laplace2d", ["--workload", "laplace2d", "--rows", "1000000", "--nev", "10",
-                                                   "--max-dim", "40"])):
+                                                   "--max-dim", "40"]),                       # BASELINE config 2
+                                    ("banded", ["--workload", "banded", "--rows", "1500000", "--per-row", "35",
+                                                "--nev", "20", "--max-dim", "41"]),           # config 3 stand-in
+                                    ("laplace3d", ["--workload", "laplace3d", "--rows", "16000000", "--nev", "10",
+                                                   "--max-dim", "40"])):                      # config 4 on ONE GPU
                     leg = run_child(extra + base, 600)
                     leg["name"] = name
                     legs.append(leg)
