@@ -67,7 +67,7 @@ COMM_ID_BYTES = 128     # AKS_COMM_ID_BYTES
 class PbRun(C.Structure):
     """Mirror of ``aks_pb_run`` (16 bytes)."""
 
-    _fields_ = [("start", C.c_uint32), ("info", C.c_uint32), ("lbase", C.c_uint32), ("lcount", C.c_uint32)]
+    _fields_ = [("start0", C.c_uint32), ("start1", C.c_uint32), ("start2", C.c_uint32), ("info", C.c_uint32)]
 
 
 class PbSizes(C.Structure):

@@ -272,7 +272,11 @@ class BinnedCSR:
         self.slab_begin, self.slab_end, self.rb_run_ptr = up(slab_begin), up(slab_end), up(rb_run_ptr)
         self.prod = torch.zeros(int(sz.nnz_pad), dtype=torch.complex128, device=device)
         self.n_slabs, self.n_rowblocks = int(sz.n_slabs), int(sz.n_rowblocks)
-        self.levels_per_round = float(((runs[::_hip.PB_RUNS_PER_ROUND, 1] >> 8) & 255).mean()) if len(runs) else 0.0
+        rpr = _hip.PB_RUNS_PER_ROUND
+        info = runs[:-rpr, 3]                                   # (the last round is the planner's empty one)
+        self.levels_per_round = float(((info[::rpr] >> 21) & 15).mean()) if len(info) else 0.0
+        filled = np.count_nonzero((info >> 14) & 127)
+        self.lanes_per_load = nnz / filled if filled else 0.0   # of 64
         d = _hip.PbMatrix()
         d.n_rows, d.n_cols, d.nnz, d.nnz_pad = n_rows, n_cols, nnz, int(sz.nnz_pad)
         d.n_runs, d.n_lrow = int(sz.n_runs), int(sz.n_lrow)
@@ -284,10 +288,11 @@ class BinnedCSR:
 
     def moved_bytes(self, real=False):
         """Bytes the two phases stream per SpMV (excluding x and y): value + 2-byte column read and the
-        product written in phase 1; product + 2-byte (level, row) word + run descriptors read in phase 2."""
+        product written in phase 1; product + the (level, row) words (64 per wave-load) + wave-load
+        descriptors read in phase 2."""
         d = self.desc
         v, pr = (16 if d.values_complex else 8), (8 if real else 16)
-        return (v + 2 + pr) * int(d.nnz_pad) + (pr + 2) * int(d.nnz) + 16 * int(d.n_runs)
+        return (v + 2 + pr) * int(d.nnz_pad) + pr * int(d.nnz) + 2 * int(d.n_lrow) + 16 * int(d.n_runs)
 
 
 class Workspace:

@@ -716,14 +716,15 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int64_t count, const int32_t *
 constexpr int PB_CW_BITS = AKS_PB_SLAB_BITS, PB_CW = 1 << PB_CW_BITS;       // columns per sub-slab
 constexpr int PB_RB_BITS = AKS_PB_ROWBLOCK_BITS, PB_RB = 1 << PB_RB_BITS;   // rows per row block
 constexpr int PB_W = AKS_PB_WAVES, PB_K = AKS_PB_RUNS_PER_WAVE, PB_RPR = PB_W * PB_K;
-constexpr int PB_D = 4;                      // rounds of products in flight per wave (the words of a round are needed one step earlier)
+constexpr int PB_D = 4;                      // pipeline stages per wave: a round is loaded PB_D - 1 steps before its adds
 constexpr int PB_B = 8;                      // rounds whose descriptors one vector load fetches (PB_B * PB_K lanes)
 constexpr int PB_P1_THREADS = 1024, PB_P1_U = 4;
-constexpr int PB_STAGE = PB_RPR * AKS_PB_RUN_MAX;   // (level, row) words of one round, at most
-constexpr int PB_MAX_LEVELS = 8;                    // 3-bit level field next to the 13-bit row
+constexpr int PB_RW = AKS_PB_ROUND_WORDS;    // (level, row) words of one round: [wave][lane][k]
+constexpr int PB_MAX_LEVELS = 8;             // 3-bit level field next to the 13-bit row
 static_assert(PB_CW_BITS <= 13 && PB_RB_BITS <= 13, "lcol / lrow are 13-bit fields");
-static_assert(PB_B % PB_D == 0 && (PB_B & 1) == 0 && PB_B * PB_K <= 64, "descriptor block: even, multiple of the depth");
-static_assert(PB_W * 64 * 4 >= PB_STAGE, "one 8-byte load per lane must cover a round's words");
+static_assert(PB_B % PB_D == 0 && PB_B * PB_K <= 64, "descriptor block: a multiple of the depth, one lane per slot");
+static_assert(PB_K == 4 && AKS_PB_RUN_MAX == 64, "a lane's words of a round are one 8-byte load");
+static_assert(PB_W <= PB_MAX_LEVELS, "a level counts waves");
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_stream(c128 v, c128 *p) {      // written once, read by another kernel
@@ -790,6 +791,8 @@ __device__ __forceinline__ void pb_acc_add(double *acc, int row, c128 p) {
 __device__ __forceinline__ void pb_acc_add(double *acc, int row, double p) { unsafeAtomicAdd(&acc[row], p); }
 __device__ __forceinline__ c128 pb_acc_get(const double *acc, int i, c128) { return make_double2(acc[i], acc[PB_RB + i]); }
 __device__ __forceinline__ double pb_acc_get(const double *acc, int i, double) { return acc[i]; }
+__device__ __forceinline__ void pb_acc_clear(double *acc, int i, c128) { acc[i] = 0.0; acc[PB_RB + i] = 0.0; }
+__device__ __forceinline__ void pb_acc_clear(double *acc, int i, double) { acc[i] = 0.0; }
 __device__ __forceinline__ c128 pb_sum(c128 a, c128 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double pb_sum(double a, double b) { return a + b; }
 template <typename XT> __device__ __forceinline__ XT pb_zero();
@@ -797,12 +800,14 @@ template <> __device__ __forceinline__ c128 pb_zero<c128>() { return make_double
 template <> __device__ __forceinline__ double pb_zero<double>() { return 0.0; }
 
 // Phase 2: one workgroup per row block.  Software pipeline per wave, one step per round:
-//   descriptors (a block of 16 rounds per vector load, one block ahead, broadcast with v_readlane)
-//   -> products + the round's (level, row) words (PB_D rounds ahead, unconditional loads so that the
-//      compiler's s_waitcnt counts stay exact) -> words through LDS (written one step before use)
+//   descriptors (a block of PB_B rounds per vector load, one block ahead, broadcast with v_readlane)
+//   -> products (a lane picks its piece of the wave-load) + the lane's four (level, row) words, PB_D - 1
+//      steps ahead, unconditional loads so that the compiler's s_waitcnt counts stay exact
 //   -> LDS adds level by level, workgroup barrier after each level.
+// The kernel is bound by the LDS atomics (profiles/microbench/pb_abi_bench.txt: cycle sums per round), which
+// is why a wave-load is filled to 64 lanes from up to three pieces instead of taking one tile.
 template <typename XT, bool ACC>
-__global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_rb, int rb_per_xcd,
+__global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_rb, int n_chunks, int chunks_per_xcd,
                                                         const int32_t *__restrict__ rb_run_ptr,
                                                         const uint4 *__restrict__ runs,
                                                         const uint16_t *__restrict__ lrow,
@@ -812,87 +817,115 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
     constexpr int T = PB_W * 64, NACC = PB_RB * (int)(sizeof(XT) / sizeof(double));
     double *acc = reinterpret_cast<double *>(pb_smem);                      // re plane [, im plane]
-    uint16_t *stage = reinterpret_cast<uint16_t *>(acc + NACC);            // 2 buffers of PB_STAGE words
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // consecutive row blocks on one XCD (blockIdx % 8, observed placement; speed only): their runs are
-    // neighbours in memory, so the lines two of them share are fetched once into that XCD's L2
-    if ((int)(blockIdx.x >> 3) >= rb_per_xcd) return;
-    const int rb = (blockIdx.x & 7) * rb_per_xcd + (blockIdx.x >> 3);
-    if (rb >= n_rb) return;
+    // One workgroup per CHUNK of consecutive row blocks (about one chunk per CU): the pipeline below runs
+    // across the row-block boundaries, so only the first round of a chunk waits for memory with nothing
+    // else in flight.  Chunks hold (nearly) equal numbers of rounds; consecutive chunks sit on one XCD
+    // (blockIdx % 8, observed placement; speed only): the lines two neighbours share are fetched once.
+    if ((int)(blockIdx.x >> 3) >= chunks_per_xcd) return;
+    const int chunk = (blockIdx.x & 7) * chunks_per_xcd + (blockIdx.x >> 3);
+    if (chunk >= n_chunks) return;
+    const int total_rounds = rb_run_ptr[n_rb] / PB_RPR;
+    auto first_rb_at = [&](int round) {          // first row block whose rounds start at or after `round`
+        int lo = 0, hi = n_rb;                   // (every row block owns at least one round: strictly increasing)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (rb_run_ptr[mid] / PB_RPR < round) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const int rb_lo = first_rb_at((int)((int64_t)total_rounds * chunk / n_chunks));
+    const int rb_hi = first_rb_at((int)((int64_t)total_rounds * (chunk + 1) / n_chunks));
+    if (rb_lo >= rb_hi) return;
     for (int i = threadIdx.x; i < NACC; i += T) acc[i] = 0.0;
-    const int R0 = rb_run_ptr[rb];
-    const int n_rounds = (rb_run_ptr[rb + 1] - R0) / PB_RPR;
+    const int R0 = rb_run_ptr[rb_lo];
+    const int n_rounds = (rb_run_ptr[rb_hi] - R0) / PB_RPR;
+    int rb = rb_lo;                              // row block of the round whose adds are next
     const uint4 *my_runs = runs + R0 + wave * PB_K;
+    const uint2 *my_words = reinterpret_cast<const uint2 *>(lrow + (size_t)(R0 / PB_RPR) * PB_RW) + wave * 64 + lane;
     auto load_block = [&](int first_round) {
         const int l = lane & (PB_B * PB_K - 1);
         const int round = first_round + l / PB_K;
-        uint4 v = my_runs[(size_t)min(round, max(n_rounds - 1, 0)) * PB_RPR + l % PB_K];
-        if (round >= n_rounds) v = make_uint4(0u, 0u, 0u, 0u);
+        uint4 v = my_runs[(size_t)max(min(round, n_rounds - 1), 0) * PB_RPR + l % PB_K];
+        if (round < 0 || round >= n_rounds) v = make_uint4(0u, 0u, 0u, 0u);
         return v;
     };
     XT p[PB_D][PB_K];
-    unsigned info[PB_D][PB_K], lcount[PB_D];
+    unsigned info[PB_D][PB_K];
     uint2 words[PB_D];
 #pragma unroll
     for (int d = 0; d < PB_D; ++d) {
-        lcount[d] = 0u;
         words[d] = make_uint2(0u, 0u);
 #pragma unroll
         for (int k = 0; k < PB_K; ++k) { info[d][k] = 0u; p[d][k] = pb_zero<XT>(); }
     }
-    uint4 dv, dvn = load_block(0);
+    // Step t adds round t - PB_D (stage t % PB_D) and, between the adds of that round's first level and
+    // the barrier behind them, issues the loads of round t - 1 into the stage that step t - 1 freed.
+    // The descriptor block of steps i0 .. i0 + PB_B - 1 therefore holds rounds i0 - 1 .. i0 + PB_B - 2.
+    uint4 dv, dvn = load_block(-1);
     pb_lds_barrier();
-    // Whole blocks of PB_B steps, with NO branch around any load: steps past the last round work on
-    // all-zero descriptors (no adds; their loads re-read entry 0).  A guard here would make the
-    // compiler's s_waitcnt placement fall back to vmcnt(0) and serialise the prefetch.
+    // A descriptor block is made to land inside straight-line code (here and at step PB_B - 2 of a block),
+    // where the compiler counts the loads issued since exactly; met across the loop's back edge, its wait
+    // would cover (nearly) everything in flight.
+    asm volatile("" : "+v"(dvn.x), "+v"(dvn.y), "+v"(dvn.z), "+v"(dvn.w));
+    // Whole blocks of PB_B steps, with NO branch around any load: steps outside the rounds work on
+    // all-zero descriptors (no adds; their loads re-read entry 0 / the chunk's first words).  A guard here
+    // would make the compiler's s_waitcnt placement fall back to vmcnt(0) and serialise the prefetch.
     const int n_steps = n_rounds + PB_D;
     for (int i0 = 0; i0 < n_steps; i0 += PB_B) {
         dv = dvn;
-        dvn = load_block(i0 + PB_B);
+        dvn = load_block(i0 + PB_B - 1);
 #pragma unroll
         for (int j = 0; j < PB_B; ++j) {
             constexpr int D = PB_D;
-            const int d = j % D, dn = (j + 1) % D;
-            // stage d holds round C = i0 + j - D, stage dn round C + 1; (level, row) words of round X live
-            // in staging buffer X & 1 (i0 is a multiple of the even PB_B, so parities follow j)
-            uint16_t *buf_c = stage + ((j + D) & 1) * PB_STAGE, *buf_n = stage + ((j + D + 1) & 1) * PB_STAGE;
-            const int w4 = (wave * 64 + lane) * 4;
-            if (w4 < (int)lcount[dn]) *reinterpret_cast<uint2 *>(buf_n + w4) = words[dn];   // for the next step
-            unsigned m[PB_K];
+            const int d = j % D, dp = (j + D - 1) % D;
+            unsigned m[PB_K];                   // this lane's word per wave-load; inactive lanes match no level
 #pragma unroll
             for (int k = 0; k < PB_K; ++k) {
-                const int len = (int)(info[d][k] & 255u);
-                m[k] = lane < len ? (unsigned)buf_c[(info[d][k] >> 16) + lane] : 0xffffu;
+                const unsigned w = k < 2 ? words[d].x : words[d].y;
+                m[k] = lane < (int)((info[d][k] >> 14) & 127u) ? ((k & 1) ? w >> 16 : w & 0xffffu) : 0xffffffffu;
             }
-            const int nph = max((int)((info[d][0] >> 8) & 255u), 1);
-            for (int ph = 0; ph < nph; ++ph) {
+            const int nph = max((int)((info[d][0] >> 21) & 15u), 1);
+            const bool last_of_rb = ((info[d][0] >> 25) & 1u) != 0u;
+#pragma unroll
+            for (int k = 0; k < PB_K; ++k)
+                if ((int)(m[k] >> 13) == 0) pb_acc_add(acc, (int)(m[k] & (PB_RB - 1)), p[d][k]);
+            // issue round i0 + j - 1 into stage dp
+            const int rnd = min(max(i0 + j - 1, 0), max(n_rounds - 1, 0));
+            words[dp] = my_words[(size_t)rnd * (PB_RW / 4)];
+#pragma unroll
+            for (int k = 0; k < PB_K; ++k) {
+                const unsigned s0 = __builtin_amdgcn_readlane(dv.x, j * PB_K + k);
+                const unsigned s1 = __builtin_amdgcn_readlane(dv.y, j * PB_K + k);
+                const unsigned s2 = __builtin_amdgcn_readlane(dv.z, j * PB_K + k);
+                const unsigned inf = __builtin_amdgcn_readlane(dv.w, j * PB_K + k);
+                info[dp][k] = inf;
+                const unsigned lc = min((unsigned)lane, max((inf >> 14) & 127u, 1u) - 1u);
+                const unsigned base = lc < (inf & 127u) ? s0 : (lc < ((inf >> 7) & 127u) ? s1 : s2);
+                p[dp][k] = ld_once(&prod[base + lc]);
+            }
+            if (j == PB_B - 2) asm volatile("" : "+v"(dvn.x), "+v"(dvn.y), "+v"(dvn.z), "+v"(dvn.w));
+            pb_lds_barrier();
+            for (int ph = 1; ph < nph; ++ph) {
 #pragma unroll
                 for (int k = 0; k < PB_K; ++k)
-                    if (lane < (int)(info[d][k] & 255u) && (int)(m[k] >> 13) == ph)
-                        pb_acc_add(acc, (int)(m[k] & (PB_RB - 1)), p[d][k]);
+                    if ((int)(m[k] >> 13) == ph) pb_acc_add(acc, (int)(m[k] & (PB_RB - 1)), p[d][k]);
                 pb_lds_barrier();
             }
-            // issue round i0 + j into stage d: its words first (they are needed one step before its products)
-            const unsigned lb = __builtin_amdgcn_readlane(dv.z, j * PB_K);
-            lcount[d] = __builtin_amdgcn_readlane(dv.w, j * PB_K);
-            const unsigned wmax = (max(lcount[d], 1u) - 1u) & ~3u;     // last 4-word group of the block
-            words[d] = *reinterpret_cast<const uint2 *>(lrow + lb + min((unsigned)w4, wmax));
-#pragma unroll
-            for (int k = 0; k < PB_K; ++k) {
-                const unsigned start = __builtin_amdgcn_readlane(dv.x, j * PB_K + k);
-                const unsigned inf = __builtin_amdgcn_readlane(dv.y, j * PB_K + k);
-                info[d][k] = inf;
-                p[d][k] = ld_once(&prod[start + min((unsigned)lane, max(inf & 255u, 1u) - 1u)]);
+            if (last_of_rb) {                    // the row block is complete: write it out, clear the accumulators
+                const int64_t row0 = (int64_t)rb << PB_RB_BITS;
+                for (int i = threadIdx.x; i < PB_RB; i += T) {
+                    XT v = pb_acc_get(acc, i, XT());
+                    pb_acc_clear(acc, i, XT());
+                    if (row0 + i < n_rows) {
+                        if (ACC) v = pb_sum(v, y[row0 + i]);
+                        y[row0 + i] = v;
+                    }
+                }
+                ++rb;
+                pb_lds_barrier();
             }
-        }
-    }
-    const int64_t row0 = (int64_t)rb << PB_RB_BITS;
-    for (int i = threadIdx.x; i < PB_RB; i += T) {
-        if (row0 + i < n_rows) {
-            XT v = pb_acc_get(acc, i, XT());
-            if (ACC) v = pb_sum(v, y[row0 + i]);
-            y[row0 + i] = v;
         }
     }
 }
@@ -1080,8 +1113,9 @@ struct PbPlan {
 
 int check_pb(const aks_pb_matrix *A, const void *x, const void *y) {
     if (A == nullptr || x == nullptr || y == nullptr) return fail(AKS_ERR_ARG, "null pointer");
-    if (A->n_rows <= 0 || A->n_cols <= 0 || A->nnz < 0 || A->nnz_pad < 8 || A->n_runs < 1 || A->n_lrow < 8)
-        return fail(AKS_ERR_ARG, "bad sizes");
+    if (A->n_rows <= 0 || A->n_cols <= 0 || A->nnz < 0 || A->nnz_pad < 8 || A->n_runs < PB_RPR ||
+        A->n_runs % PB_RPR != 0 || A->n_lrow != A->n_runs * AKS_PB_RUN_MAX)
+        return fail(AKS_ERR_ARG, "bad sizes (n_runs: whole rounds, the last one empty; n_lrow = 64 n_runs)");
     if (A->n_slabs != (int32_t)((A->n_cols + PB_CW - 1) >> PB_CW_BITS) ||
         A->n_rowblocks != (int32_t)((A->n_rows + PB_RB - 1) >> PB_RB_BITS))
         return fail(AKS_ERR_ARG, "n_slabs / n_rowblocks do not match the shape");
@@ -1109,7 +1143,7 @@ template <typename VT, typename XT>
 int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const aks_ctrl *ctrl, hipStream_t s) {
     XT *prod = reinterpret_cast<XT *>(A->d_prod);       // real vectors use the first 8 nnz_pad bytes
     const size_t lds1 = (size_t)PB_CW * sizeof(XT);
-    const size_t lds2 = (size_t)PB_RB * sizeof(XT) + 2 * PB_STAGE * sizeof(uint16_t);
+    const size_t lds2 = (size_t)PB_RB * sizeof(XT);
     static bool ok1 = false, ok2a = false, ok2b = false;
     int rc = allow_lds(k_pb_phase1<VT, XT>, lds1, &ok1);
     if (rc == AKS_OK) rc = allow_lds(k_pb_phase2<XT, true>, lds2, &ok2a);
@@ -1118,14 +1152,23 @@ int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const 
     if (A->nnz > 0)
         hipLaunchKernelGGL((k_pb_phase1<VT, XT>), dim3((unsigned)A->n_slabs), dim3(PB_P1_THREADS), lds1, s, A->n_cols,
                            A->d_slab_begin, A->d_slab_end, static_cast<const VT *>(A->d_val), A->d_lcol, x, prod, ctrl);
-    const int rbx = (A->n_rowblocks + 7) / 8;
+    // about one chunk of row blocks per CU (k_pb_phase2), in multiples of 8 for the XCD mapping
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(AKS_ERR_HIP, "hipGetDeviceProperties");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int n_chunks = (int)std::min<int64_t>(A->n_rowblocks, n_cu);
+    const int cpx = (n_chunks + 7) / 8;
     const uint4 *runs = reinterpret_cast<const uint4 *>(A->d_runs);
     if (accumulate)
-        hipLaunchKernelGGL((k_pb_phase2<XT, true>), dim3((unsigned)(rbx * 8)), dim3(PB_W * 64), lds2, s, A->n_rows,
-                           A->n_rowblocks, rbx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
+        hipLaunchKernelGGL((k_pb_phase2<XT, true>), dim3((unsigned)(cpx * 8)), dim3(PB_W * 64), lds2, s, A->n_rows,
+                           A->n_rowblocks, n_chunks, cpx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
     else
-        hipLaunchKernelGGL((k_pb_phase2<XT, false>), dim3((unsigned)(rbx * 8)), dim3(PB_W * 64), lds2, s, A->n_rows,
-                           A->n_rowblocks, rbx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
+        hipLaunchKernelGGL((k_pb_phase2<XT, false>), dim3((unsigned)(cpx * 8)), dim3(PB_W * 64), lds2, s, A->n_rows,
+                           A->n_rowblocks, n_chunks, cpx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
     AKS_CHECK_LAUNCH("aks_pb_spmv");
     return AKS_OK;
 }
@@ -1397,81 +1440,88 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
             }
         }
     }
-    // phase-2 schedule: runs, rounds, levels
+    // phase-2 schedule: wave-loads (up to 64 entries from up to AKS_PB_PIECES contiguous pieces), rounds, levels
+    struct Piece { uint32_t start, len; };
+    struct Load { Piece pc[AKS_PB_PIECES]; int n_pc; uint32_t total; };
+    auto entry_of = [](const Load &L, uint32_t lane) {       // phase-1 position of a lane's entry
+        for (int i = 0; i < L.n_pc; ++i) {
+            if (lane < L.pc[i].len) return L.pc[i].start + lane;
+            lane -= L.pc[i].len;
+        }
+        return 0u;
+    };
     P->rb_run_ptr.resize(n_rb + 1);
-    std::vector<uint16_t> seen(PB_RB, 0);           // waves that add to a row in the current round (bit per wave)
+    // per row of the block: the last entry of the current round that adds to it
     std::vector<int64_t> stamp(PB_RB, -1);
-    std::vector<aks_pb_run> raw;
+    std::vector<uint8_t> last_wave(PB_RB, 0), last_level(PB_RB, 0);
+    std::vector<Load> loads;
     int64_t round_id = 0;
     for (int64_t rb = 0; rb < n_rb; ++rb) {
         P->rb_run_ptr[rb] = (int32_t)P->runs.size();
-        raw.clear();
+        loads.clear();
+        Load cur{};
+        auto close = [&] { if (cur.total > 0) loads.push_back(cur); cur = Load{}; };
         for (int64_t s = 0; s < n_ss; ++s) {
-            const int32_t c = cnt[s * n_rb + rb], q0 = start[s * n_rb + rb];
-            for (int32_t o = 0; o < c; o += AKS_PB_RUN_MAX)
-                raw.push_back(aks_pb_run{(uint32_t)(q0 + o), (uint32_t)std::min<int32_t>(AKS_PB_RUN_MAX, c - o), 0u, 0u});
+            int32_t c = cnt[s * n_rb + rb], q = start[s * n_rb + rb];
+            while (c > 0) {
+                if (cur.n_pc == AKS_PB_PIECES || cur.total == AKS_PB_RUN_MAX) close();
+                const int32_t take = std::min<int32_t>(c, AKS_PB_RUN_MAX - (int32_t)cur.total);
+                cur.pc[cur.n_pc++] = Piece{(uint32_t)q, (uint32_t)take};
+                cur.total += (uint32_t)take;
+                q += take;
+                c -= take;
+            }
         }
+        close();
         size_t next = 0;
-        while (next < raw.size()) {
-            // one round: consecutive runs into slots 0 .. PB_RPR - 1 (slot j belongs to wave j / PB_K).  A row may
-            // be hit from at most PB_MAX_LEVELS different waves in a round (its level field has 3 bits): a run
-            // that would exceed that closes the round early (the remaining slots stay empty).
-            const size_t rr = P->runs.size();
+        while (next < loads.size()) {
+            // one round: consecutive wave-loads into slots 0 .. PB_RPR - 1 (slot j belongs to wave j / PB_K, its
+            // k-th load).  Level of an entry = number of lower-index waves that add to its row in this round:
+            // entries of one row then run in wave order, one barrier-separated level per wave; inside a wave they
+            // run in program order (a wave's LDS operations complete in order; lanes of one ds_add that hit the
+            // same address are serialised by the LDS in a fixed order).  With PB_W = 8 waves a level fits 3 bits.
+            const size_t rr = P->runs.size(), wr = P->lrow.size();
             ++round_id;
-            int slot = 0;
-            while (slot < PB_RPR && next < raw.size()) {
-                const aks_pb_run &run = raw[next];
-                const uint16_t bit = (uint16_t)(1u << (slot / PB_K));
-                bool fits = true;
-                if (PB_W > PB_MAX_LEVELS && slot > 0)
-                    for (uint32_t i = 0; i < run.info && fits; ++i) {
-                        const int row = row13[run.start + i];
-                        const uint16_t have = stamp[row] == round_id ? seen[row] : (uint16_t)0;
-                        fits = __builtin_popcount(have | bit) <= PB_MAX_LEVELS;
-                    }
-                if (!fits) break;
-                for (uint32_t i = 0; i < run.info; ++i) {
-                    const int row = row13[run.start + i];
-                    if (stamp[row] != round_id) { stamp[row] = round_id; seen[row] = 0; }
-                    seen[row] |= bit;
+            P->runs.resize(rr + PB_RPR, aks_pb_run{0u, 0u, 0u, 0u});
+            P->lrow.resize(wr + PB_RW, (uint16_t)0);
+            uint32_t levels = 1;
+            for (int slot = 0; slot < PB_RPR && next < loads.size(); ++slot, ++next) {
+                const Load &L = loads[next];
+                const int w = slot / PB_K;
+                aks_pb_run &run = P->runs[rr + slot];
+                const uint32_t l0 = L.pc[0].len, l01 = l0 + (L.n_pc > 1 ? L.pc[1].len : 0u);
+                run.start0 = L.pc[0].start;
+                run.start1 = L.n_pc > 1 ? L.pc[1].start - l0 : 0u;
+                run.start2 = L.n_pc > 2 ? L.pc[2].start - l01 : 0u;
+                run.info = l0 | (l01 << 7) | (L.total << 14);
+                for (uint32_t l = 0; l < L.total; ++l) {
+                    const int row = row13[entry_of(L, l)];
+                    uint32_t lv = 0;
+                    if (stamp[row] == round_id) lv = last_wave[row] == w ? last_level[row] : last_level[row] + 1u;
+                    stamp[row] = round_id;
+                    last_wave[row] = (uint8_t)w;
+                    last_level[row] = (uint8_t)lv;
+                    P->lrow[wr + (size_t)w * (PB_K * AKS_PB_RUN_MAX) + (size_t)l * PB_K + (slot % PB_K)] = (uint16_t)(row | (lv << 13));
+                    levels = std::max(levels, lv + 1u);
                 }
-                P->runs.push_back(run);
-                ++slot;
-                ++next;
             }
-            while (P->runs.size() - rr < (size_t)PB_RPR) P->runs.push_back(aks_pb_run{0u, 0u, 0u, 0u});
-            const uint32_t lbase = (uint32_t)P->lrow.size();
-            uint32_t off = 0, levels = 1;
-            for (int j = 0; j < PB_RPR; ++j) {
-                aks_pb_run &run = P->runs[rr + j];
-                const uint32_t len = run.info, w = (uint32_t)(j / PB_K);
-                for (uint32_t i = 0; i < len; ++i) {
-                    const int row = row13[run.start + i];
-                    // level = waves with a smaller index that add to this row in this round: entries of one
-                    // row then run in wave order, one barrier-separated level per wave
-                    const uint32_t lv = (uint32_t)__builtin_popcount(seen[row] & ((1u << w) - 1u));
-                    P->lrow.push_back((uint16_t)(row | (lv << 13)));
-                    levels = std::max(levels, lv + 1);
-                }
-                run.info = len | (off << 16);
-                off += len;
-            }
-            while (P->lrow.size() & 3) P->lrow.push_back(0);
-            for (int j = 0; j < PB_RPR; ++j) {
-                aks_pb_run &run = P->runs[rr + j];
-                run.info |= levels << 8;
-                run.lbase = lbase;
-                run.lcount = off;
-            }
+            for (int j = 0; j < PB_RPR; ++j) P->runs[rr + j].info |= levels << 21;
         }
+        if ((size_t)P->rb_run_ptr[rb] == P->runs.size()) {      // a row block without entries still owns one round
+            P->runs.resize(P->runs.size() + PB_RPR, aks_pb_run{0u, 0u, 0u, 1u << 21});
+            P->lrow.resize(P->lrow.size() + PB_RW, (uint16_t)0);
+        }
+        for (int j = 0; j < PB_RPR; ++j) P->runs[P->runs.size() - PB_RPR + j].info |= 1u << 25;   // last round of the block
     }
     P->rb_run_ptr[n_rb] = (int32_t)P->runs.size();
-    if (P->runs.size() >= (size_t)INT32_MAX || P->lrow.size() >= (size_t)UINT32_MAX - 8) {
+    // one all-empty round behind the last row block: what the kernels' clamped prefetches of a row block
+    // without rounds read
+    P->runs.resize(P->runs.size() + PB_RPR, aks_pb_run{0u, 0u, 0u, 0u});
+    P->lrow.resize(P->lrow.size() + PB_RW, (uint16_t)0);
+    if (P->runs.size() >= (size_t)INT32_MAX / 2 || P->lrow.size() >= (size_t)UINT32_MAX - 8) {
         fail(AKS_ERR_UNSUPPORTED, "binned form: schedule too large");
         return nullptr;
     }
-    while (P->lrow.size() < 8) P->lrow.push_back(0);           // padding rounds read lrow[0 .. 3]
-    if (P->runs.empty()) P->runs.push_back(aks_pb_run{0u, 0u, 0u, 0u});
     P->sz.nnz_pad = nnz_pad;
     P->sz.n_runs = (int64_t)P->runs.size();
     P->sz.n_lrow = (int64_t)P->lrow.size();

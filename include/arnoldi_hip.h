@@ -113,14 +113,18 @@ int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indic
  *            are staged in LDS, the sub-slab's non-zeros -- ordered by (row block, row) -- are
  *            streamed (value, 13-bit local column) and val * x[col] is written SEQUENTIALLY;
  *   phase 2  one workgroup (8 waves) per ROW BLOCK of 2^13 rows with the block's 8192 complex
- *            accumulators in LDS.  The block's products are RUNS (the <= 64 entries of one
- *            (sub-slab, row block) tile, contiguous in phase-1 order); a wave-load takes one run.
- *            32 consecutive runs (4 per wave) form a ROUND.  Two entries of one round that hit the
- *            same row from different waves get different LEVELS; the round's LDS adds are issued
- *            level by level with a workgroup barrier after each, and rounds follow each other in
- *            order, so every row receives its addends in one fixed order: results are bitwise
- *            reproducible.  The per-entry (level, row) words of a round are one contiguous block
- *            (fetched with one 8-byte load per lane and handed out through LDS).
+ *            accumulators in LDS.  The block's products -- the (sub-slab, row block) tiles, each
+ *            contiguous in phase-1 order, taken sub-slab by sub-slab -- are cut into WAVE-LOADS of
+ *            up to 64 entries: one lane each, gathered from up to THREE contiguous pieces (the tail
+ *            of one tile, a whole tile, the head of the next), so that the LDS adds and the product
+ *            loads run with (nearly) full waves whatever the tile size.  32 consecutive wave-loads
+ *            (4 per wave) form a ROUND.  Two entries of one round that hit the same row from
+ *            different waves get different LEVELS (level = number of lower-index waves adding to that
+ *            row); the round's LDS adds are issued level by level with a workgroup barrier after each,
+ *            a wave's own adds complete in program order, and rounds follow each other in order, so
+ *            every row receives its addends in one fixed order: results are bitwise reproducible.  The
+ *            (level, row) words of a round are a fixed block of 2048, laid out [wave][lane][k]:
+ *            a lane fetches its four words with one 8-byte load.
  * aks_pb_plan_* are pure host functions that build the arrays from a canonical CSR matrix
  * (int32 indices); the caller uploads them and fills aks_pb_matrix with device pointers.     */
 #ifndef AKS_PB_SLAB_BITS         /* (overridable at build time for tuning experiments)        */
@@ -133,31 +137,35 @@ int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indic
 #define AKS_PB_WAVES 8           /* waves of a phase-2 workgroup                              */
 #endif
 #ifndef AKS_PB_RUNS_PER_WAVE
-#define AKS_PB_RUNS_PER_WAVE 4   /* runs a wave takes per round (round = 32 runs)             */
+#define AKS_PB_RUNS_PER_WAVE 4   /* wave-loads a wave takes per round (round = 32 of them)    */
 #endif
-#define AKS_PB_RUN_MAX 64        /* entries per run (one lane each)                           */
+#define AKS_PB_RUN_MAX 64        /* entries per wave-load (one lane each)                     */
+#define AKS_PB_PIECES 3          /* contiguous pieces a wave-load gathers from                */
+#define AKS_PB_ROUND_WORDS (AKS_PB_WAVES * AKS_PB_RUNS_PER_WAVE * AKS_PB_RUN_MAX)   /* 2048  */
 
-typedef struct aks_pb_run {      /* 16 bytes; n_runs of them, a multiple of 32 per row block  */
-    uint32_t start;              /* first entry of the run in phase-1 order                   */
-    uint32_t info;               /* bits 0-7 entries (0 = padding run), 8-15 levels of the
-                                    run's round (>= 1), 16-31 offset of the run's words in
-                                    the round's block of d_lrow                               */
-    uint32_t lbase;              /* first word of the round's block in d_lrow (multiple of 4) */
-    uint32_t lcount;             /* words in the round's block                                */
+typedef struct aks_pb_run {      /* one wave-load, 16 bytes; n_runs of them, a multiple of 32 per row block.
+                                    Lane l < total reads entry (l < l0 ? start0 : l < l01 ? start1 : start2) + l
+                                    of the phase-1 order (start1 / start2 are stored minus the lanes before
+                                    their piece, modulo 2^32).                                                 */
+    uint32_t start0, start1, start2;
+    uint32_t info;               /* bits 0-6 l0, 7-13 l01 = l0 + l1, 14-20 total (0 = padding slot),
+                                    21-24 levels of the wave-load's round (>= 1), 25 set on the slots of a
+                                    row block's LAST round (every row block owns at least one round)           */
 } aks_pb_run;
 
 typedef struct aks_pb_matrix {
     int64_t n_rows, n_cols, nnz;
     int64_t nnz_pad;                /* phase-1 slots: every sub-slab starts on a multiple of 8 */
-    int64_t n_runs, n_lrow;         /* lengths of d_runs / d_lrow                              */
+    int64_t n_runs, n_lrow;         /* lengths of d_runs / d_lrow (n_lrow = 64 n_runs)         */
     int32_t n_slabs, n_rowblocks, values_complex, pad_;
     const void *d_val;              /* nnz_pad values (f64 or c128), phase-1 order, pads = 0   */
     const uint16_t *d_lcol;         /* nnz_pad: column - sub-slab * 8192                       */
     const int32_t *d_slab_begin;    /* n_slabs: first phase-1 slot of each sub-slab            */
     const int32_t *d_slab_end;      /* n_slabs: one past its last entry                        */
-    const aks_pb_run *d_runs;       /* n_runs run descriptors, row block by row block          */
-    const int32_t *d_rb_run_ptr;    /* n_rowblocks + 1: first run of each row block            */
-    const uint16_t *d_lrow;         /* n_lrow: level << 13 | row - rowblock * 8192, round by round */
+    const aks_pb_run *d_runs;       /* n_runs wave-load descriptors, row block by row block    */
+    const int32_t *d_rb_run_ptr;    /* n_rowblocks + 1: first wave-load of each row block      */
+    const uint16_t *d_lrow;         /* n_lrow = n_runs * 64: level << 13 | row - rowblock * 8192;
+                                       round r (= slots 32 r ..) owns words 2048 r + wave * 256 + lane * 4 + k */
     aks_c128 *d_prod;               /* nnz_pad complex128 scratch (the products)               */
 } aks_pb_matrix;
 

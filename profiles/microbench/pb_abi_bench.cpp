@@ -58,12 +58,13 @@ int main(int argc, char **argv) {
     std::vector<aks_pb_run> runs(sz.n_runs);
     AK(aks_pb_plan_export(plan, val.data(), lcol.data(), sb.data(), se.data(), runs.data(), rbp.data(), lrow.data()));
     aks_pb_plan_destroy(plan);
-    printf("plan: %.2f s, nnz_pad %lld, %lld runs, %lld (level,row) words, %d sub-slabs x %d row blocks\n",
+    printf("plan: %.2f s, nnz_pad %lld, %lld wave-loads, %lld (level,row) words, %d sub-slabs x %d row blocks\n",
            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), (long long)sz.nnz_pad,
            (long long)sz.n_runs, (long long)sz.n_lrow, sz.n_slabs, sz.n_rowblocks);
-    double mean_levels = 0;
-    for (int64_t r = 0; r < sz.n_runs; r += 32) mean_levels += (runs[r].info >> 8) & 255;
-    printf("mean levels per round %.2f\n", mean_levels / (sz.n_runs / 32));
+    double mean_levels = 0, filled = 0;
+    for (int64_t r = 0; r + 32 < sz.n_runs; r += 32) mean_levels += (runs[r].info >> 21) & 15;
+    for (int64_t r = 0; r < sz.n_runs; ++r) filled += ((runs[r].info >> 14) & 127) != 0;
+    printf("mean levels per round %.2f, mean lanes per wave-load %.1f\n", mean_levels / (sz.n_runs / 32 - 1), nnz / filled);
 
     aks_pb_matrix A;
     memset(&A, 0, sizeof A);

@@ -82,7 +82,7 @@ class FakeHip:
 
     def _pb_replay(self, A, x, y, acc, vec_dtype):
         """The two phases of the tile-binned form, replayed with NumPy on the planned arrays: phase 1 walks
-        the sub-slab ranges, phase 2 the run descriptors and their (level, row) words."""
+        the sub-slab ranges, phase 2 the wave-load descriptors and their (level, row) words."""
         d = A._obj if hasattr(A, "_obj") else A.contents
         nnz, n_rows, n_cols, npad = int(d.nnz), int(d.n_rows), int(d.n_cols), int(d.nnz_pad)
         yv = _view(y, vec_dtype, n_rows)
@@ -102,18 +102,24 @@ class FakeHip:
             runs = _view(d.d_runs, np.uint32, 4 * int(d.n_runs)).reshape(-1, 4).astype(np.int64)
             rbp = _view(d.d_rb_run_ptr, np.int32, d.n_rowblocks + 1).astype(np.int64)
             lrow = _view(d.d_lrow, np.uint16, int(d.n_lrow)).astype(np.int64)
-            assert rbp[0] == 0 and rbp[-1] == len(runs) and np.all(np.diff(rbp) % 32 == 0)
-            lens, levels, loff = runs[:, 1] & 255, (runs[:, 1] >> 8) & 255, runs[:, 1] >> 16
-            assert lens.max() <= 64 and int(lens.sum()) == nnz and np.all(levels[lens > 0] >= 1)
-            assert np.all(runs[:, 2] % 4 == 0) and np.all(loff + lens <= runs[:, 3])
+            assert rbp[0] == 0 and rbp[-1] == len(runs) - 32 and np.all(np.diff(rbp) % 32 == 0)   # + one empty round
+            assert int(d.n_lrow) == 64 * len(runs)
+            info = runs[:, 3]
+            l0, l01, total, levels = info & 127, (info >> 7) & 127, (info >> 14) & 127, (info >> 21) & 15
+            assert total.max() <= 64 and int(total.sum()) == nnz and np.all(l0 <= l01) and np.all(l01 <= total)
+            assert np.all(levels[total > 0] >= 1) and np.all(total[rbp[-1]:] == 0)
             rb_of_run = np.repeat(np.arange(d.n_rowblocks, dtype=np.int64), np.diff(rbp))
-            rep = np.repeat(np.arange(len(runs)), lens)
-            within = np.arange(nnz) - np.repeat(np.cumsum(lens) - lens, lens)
-            words = lrow[runs[rep, 2] + loff[rep] + within]
+            rep = np.repeat(np.arange(len(runs)), total)                            # wave-load of every lane
+            lane = np.arange(nnz) - np.repeat(np.cumsum(total) - total, total)
+            base = np.where(lane < l0[rep], runs[rep, 0], np.where(lane < l01[rep], runs[rep, 1], runs[rep, 2]))
+            entry = (base + lane) & 0xFFFFFFFF
+            assert np.array_equal(np.sort(entry), k)                                # every product exactly once
+            slot = rep % 32
+            words = lrow[(rep // 32) * 2048 + (slot // 4) * 256 + lane * 4 + slot % 4]
             assert np.all((words >> 13) < levels[rep])                               # every level gets its barrier
             rows = (rb_of_run[rep] << 13) + (words & 8191)
             assert rows.max() < n_rows
-            np.add.at(out, rows, prod[runs[rep, 0] + within])                       # phase 2
+            np.add.at(out, rows, prod[entry])                                       # phase 2
         yv[:] = yv + out if acc else out
 
     def aks_pb_spmv_real(self, A, x, y, acc, ws, stream):

@@ -442,26 +442,33 @@ def test_binned_plan_represents_the_matrix(fake, shape, complex_vals):
     d = b.desc
     assert d.n_slabs == -(-n_cols // 8192) and d.n_rowblocks == -(-n_rows // 8192) and d.nnz == A.nnz
     runs = b.runs.numpy().view(np.uint32).astype(np.int64)
-    lens, levels, loff = runs[:, 1] & 255, (runs[:, 1] >> 8) & 255, runs[:, 1] >> 16
-    assert int(lens.sum()) == A.nnz and lens.max() <= 64 and levels.max() <= 8
-    # a round = 32 consecutive runs, 4 per wave: within a round, entries of one row that sit in runs of
-    # DIFFERENT waves carry different levels (their adds are separated by a barrier), ordered by wave
-    lrow = b.lrow.numpy().view(np.uint16).astype(np.int64)
+    info = runs[:, 3]
+    l0, l01, total, levels = info & 127, (info >> 7) & 127, (info >> 14) & 127, (info >> 21) & 15
+    assert int(total.sum()) == A.nnz and total.max() <= 64 and levels.max() <= 8
+    assert np.all(l0 <= l01) and np.all(l01 <= total)
     RPR = _hip.PB_RUNS_PER_ROUND
+    assert len(runs) % RPR == 0 and np.all(total[-RPR:] == 0)          # whole rounds, the last one empty
+    assert b.lanes_per_load > 32 or A.nnz < 64 * len(runs) // 4        # wave-loads are filled from several tiles
+    # a round = 32 consecutive wave-loads, 4 per wave.  Walking a round in (wave, load, lane) order, the level of
+    # an entry is that of the previous entry of its row if that one sits in the SAME wave (a wave's LDS
+    # operations complete in order), one more otherwise (a barrier separates the two adds)
+    lrow = b.lrow.numpy().view(np.uint16).astype(np.int64)
+    assert len(lrow) == 64 * len(runs)
     for r0 in range(0, len(runs), RPR):
-        rr = runs[r0:r0 + RPR]
-        assert len(set(rr[:, 2].tolist())) == 1 and len(set((rr[:, 1] >> 8 & 255).tolist())) == 1
-        seen = {}
-        for j, (start, info, lbase, lcount) in enumerate(rr):
-            w = j // (RPR // 8)
-            for word in lrow[lbase + (info >> 16): lbase + (info >> 16) + (info & 255)]:
-                seen.setdefault(int(word & 8191), []).append((w, int(word >> 13)))
-        for row, hits in seen.items():
-            per_wave = {}
-            for w, lv in hits:
-                assert per_wave.setdefault(w, lv) == lv            # one level per (row, wave)
-            lv_by_wave = [per_wave[w] for w in sorted(per_wave)]
-            assert lv_by_wave == list(range(len(lv_by_wave)))      # levels 0, 1, 2 ... in wave order
+        assert len(set(levels[r0:r0 + RPR].tolist())) == 1
+        last = {}
+        for j in range(RPR):
+            w, k = divmod(j, RPR // 8)
+            for lane in range(int(total[r0 + j])):
+                word = int(lrow[(r0 // RPR) * 2048 + w * 256 + lane * 4 + k])
+                row, lv = word & 8191, word >> 13
+                assert lv < levels[r0]
+                if row in last:
+                    pw, pj, plv = last[row]
+                    assert lv == (plv if pw == w else plv + 1)
+                else:
+                    assert lv == 0
+                last[row] = (w, j, lv)
         if r0 > 40 * RPR:
             break
     x = torch.from_numpy((rng.standard_normal(n_cols) + 1j * rng.standard_normal(n_cols)).astype(C128))
