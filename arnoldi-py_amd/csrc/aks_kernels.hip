@@ -721,6 +721,9 @@ constexpr int PB_B = 8;                      // rounds whose descriptors one vec
 constexpr int PB_P1_THREADS = 1024, PB_P1_U = 4;
 constexpr int PB_RW = AKS_PB_ROUND_WORDS;    // (level, row) words of one round: [wave][lane][k]
 constexpr int PB_MAX_LEVELS = 8;             // 3-bit level field next to the 13-bit row
+#ifndef AKS_PB_TICKS
+#define AKS_PB_TICKS 0           // diagnostic build: wave 0 of every phase-2 workgroup leaves s_memtime sums per pipeline
+#endif                           // section in the first doubles of the product scratch (pb_abi_bench prints them)
 static_assert(PB_CW_BITS <= 13 && PB_RB_BITS <= 13, "lcol / lrow are 13-bit fields");
 static_assert(PB_B % PB_D == 0 && PB_B * PB_K <= 64, "descriptor block: a multiple of the depth, one lane per slot");
 static_assert(PB_K == 4 && AKS_PB_RUN_MAX == 64, "a lane's words of a round are one 8-byte load");
@@ -819,29 +822,24 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
     double *acc = reinterpret_cast<double *>(pb_smem);                      // re plane [, im plane]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // One workgroup per CHUNK of consecutive row blocks (about one chunk per CU): the pipeline below runs
-    // across the row-block boundaries, so only the first round of a chunk waits for memory with nothing
-    // else in flight.  Chunks hold (nearly) equal numbers of rounds; consecutive chunks sit on one XCD
-    // (blockIdx % 8, observed placement; speed only): the lines two neighbours share are fetched once.
+    // One workgroup per CHUNK of row blocks (one chunk per CU of an MI355X): the pipeline below runs across
+    // the row-block boundaries, so only the first round of a chunk waits for memory with nothing else in
+    // flight.  Chunks are interleaved -- chunk c takes row blocks c, c + n_chunks, ... -- and consecutive
+    // chunks sit on one XCD (blockIdx % 8, observed placement; speed only): neighbouring row blocks are
+    // then worked on at about the same time by neighbouring CUs, and the 128-byte lines in which the
+    // products of two of them meet are fetched into that XCD's L2 once.
     if ((int)(blockIdx.x >> 3) >= chunks_per_xcd) return;
     const int chunk = (blockIdx.x & 7) * chunks_per_xcd + (blockIdx.x >> 3);
     if (chunk >= n_chunks) return;
-    const int total_rounds = rb_run_ptr[n_rb] / PB_RPR;
-    auto first_rb_at = [&](int round) {          // first row block whose rounds start at or after `round`
-        int lo = 0, hi = n_rb;                   // (every row block owns at least one round: strictly increasing)
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (rb_run_ptr[mid] / PB_RPR < round) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-    };
-    const int rb_lo = first_rb_at((int)((int64_t)total_rounds * chunk / n_chunks));
-    const int rb_hi = first_rb_at((int)((int64_t)total_rounds * (chunk + 1) / n_chunks));
-    if (rb_lo >= rb_hi) return;
+    // chunk c owns the row blocks c, c + n_chunks, c + 2 n_chunks, ...; the planner stores the row blocks in
+    // that order (aks_pb_matrix.d_rb_run_ptr is indexed by position), so a chunk's rounds are contiguous
+    const int q = n_rb / n_chunks, r = n_rb % n_chunks;
+    const int pos_lo = chunk * q + min(chunk, r), pos_hi = pos_lo + q + (chunk < r ? 1 : 0);
+    if (pos_lo >= pos_hi) return;
     for (int i = threadIdx.x; i < NACC; i += T) acc[i] = 0.0;
-    const int R0 = rb_run_ptr[rb_lo];
-    const int n_rounds = (rb_run_ptr[rb_hi] - R0) / PB_RPR;
-    int rb = rb_lo;                              // row block of the round whose adds are next
+    const int R0 = rb_run_ptr[pos_lo];
+    const int n_rounds = (rb_run_ptr[pos_hi] - R0) / PB_RPR;
+    int rb = chunk;                              // row block of the round whose adds are next
     const uint4 *my_runs = runs + R0 + wave * PB_K;
     const uint2 *my_words = reinterpret_cast<const uint2 *>(lrow + (size_t)(R0 / PB_RPR) * PB_RW) + wave * 64 + lane;
     auto load_block = [&](int first_round) {
@@ -860,11 +858,15 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
 #pragma unroll
         for (int k = 0; k < PB_K; ++k) { info[d][k] = 0u; p[d][k] = pb_zero<XT>(); }
     }
-    // Step t adds round t - PB_D (stage t % PB_D) and, between the adds of that round's first level and
-    // the barrier behind them, issues the loads of round t - 1 into the stage that step t - 1 freed.
+    // Step t issues the loads of round t - 1 into the stage that step t - 1 freed and adds round t - PB_D
+    // (stage t % PB_D).  (Measured: loads before, between or after the first-level adds -- no difference; with
+    // 64-lane wave-loads and shared boundary lines the kernel runs at the rate of its memory traffic.)
     // The descriptor block of steps i0 .. i0 + PB_B - 1 therefore holds rounds i0 - 1 .. i0 + PB_B - 2.
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tk = 0, tk0 = 0;
+#define PB_TICK(i) do { if (AKS_PB_TICKS) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tsum[i] += now_ - tk; tk = now_; } } while (0)
     uint4 dv, dvn = load_block(-1);
     pb_lds_barrier();
+    if (AKS_PB_TICKS) tk0 = tk = __builtin_amdgcn_s_memtime();
     // A descriptor block is made to land inside straight-line code (here and at step PB_B - 2 of a block),
     // where the compiler counts the loads issued since exactly; met across the loop's back edge, its wait
     // would cover (nearly) everything in flight.
@@ -880,22 +882,9 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
         for (int j = 0; j < PB_B; ++j) {
             constexpr int D = PB_D;
             const int d = j % D, dp = (j + D - 1) % D;
-            unsigned m[PB_K];                   // this lane's word per wave-load; inactive lanes match no level
-#pragma unroll
-            for (int k = 0; k < PB_K; ++k) {
-                const unsigned w = k < 2 ? words[d].x : words[d].y;
-                m[k] = lane < (int)((info[d][k] >> 14) & 127u) ? ((k & 1) ? w >> 16 : w & 0xffffu) : 0xffffffffu;
-            }
-            const int nph = max((int)((info[d][0] >> 21) & 15u), 1);
-            const bool last_of_rb = ((info[d][0] >> 25) & 1u) != 0u;
-#pragma unroll
-            for (int k = 0; k < PB_K; ++k)
-                if ((int)(m[k] >> 13) == 0) pb_acc_add(acc, (int)(m[k] & (PB_RB - 1)), p[d][k]);
-            // issue round i0 + j - 1 into stage dp
+            // Round i0 + j - 1 is loaded into stage dp while round i0 + j - PB_D (stage d) is added.
             const int rnd = min(max(i0 + j - 1, 0), max(n_rounds - 1, 0));
-            words[dp] = my_words[(size_t)rnd * (PB_RW / 4)];
-#pragma unroll
-            for (int k = 0; k < PB_K; ++k) {
+            auto issue_load = [&](int k) {
                 const unsigned s0 = __builtin_amdgcn_readlane(dv.x, j * PB_K + k);
                 const unsigned s1 = __builtin_amdgcn_readlane(dv.y, j * PB_K + k);
                 const unsigned s2 = __builtin_amdgcn_readlane(dv.z, j * PB_K + k);
@@ -904,9 +893,27 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
                 const unsigned lc = min((unsigned)lane, max((inf >> 14) & 127u, 1u) - 1u);
                 const unsigned base = lc < (inf & 127u) ? s0 : (lc < ((inf >> 7) & 127u) ? s1 : s2);
                 p[dp][k] = ld_once(&prod[base + lc]);
+            };
+            unsigned m[PB_K];                   // this lane's word per wave-load; inactive lanes match no level
+#pragma unroll
+            for (int k = 0; k < PB_K; ++k) {
+                const unsigned w = k < 2 ? words[d].x : words[d].y;
+                m[k] = lane < (int)((info[d][k] >> 14) & 127u) ? ((k & 1) ? w >> 16 : w & 0xffffu) : 0xffffffffu;
             }
+            const int nph = max((int)((info[d][0] >> 21) & 15u), 1);
+            const bool last_of_rb = ((info[d][0] >> 25) & 1u) != 0u;
+            auto add_slot = [&](int k) {
+                if ((int)(m[k] >> 13) == 0) pb_acc_add(acc, (int)(m[k] & (PB_RB - 1)), p[d][k]);
+            };
+            words[dp] = my_words[(size_t)rnd * (PB_RW / 4)];
+#pragma unroll
+            for (int k = 0; k < PB_K; ++k) issue_load(k);
+#pragma unroll
+            for (int k = 0; k < PB_K; ++k) add_slot(k);
             if (j == PB_B - 2) asm volatile("" : "+v"(dvn.x), "+v"(dvn.y), "+v"(dvn.z), "+v"(dvn.w));
+            PB_TICK(0);
             pb_lds_barrier();
+            PB_TICK(1);
             for (int ph = 1; ph < nph; ++ph) {
 #pragma unroll
                 for (int k = 0; k < PB_K; ++k)
@@ -923,11 +930,19 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
                         y[row0 + i] = v;
                     }
                 }
-                ++rb;
+                rb += n_chunks;
                 pb_lds_barrier();
             }
+            PB_TICK(2);
         }
     }
+    if (AKS_PB_TICKS && threadIdx.x == 0) {
+        double *dbg = reinterpret_cast<double *>(const_cast<XT *>(prod)) + (size_t)chunk * 8;
+        for (int i = 0; i < 6; ++i) dbg[i] = (double)tsum[i];
+        dbg[6] = (double)(tk - tk0);
+        dbg[7] = (double)n_rounds;
+    }
+#undef PB_TICK
 }
 
 // ------------------------------------------------------------------ host-side plumbing
@@ -1152,15 +1167,7 @@ int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const 
     if (A->nnz > 0)
         hipLaunchKernelGGL((k_pb_phase1<VT, XT>), dim3((unsigned)A->n_slabs), dim3(PB_P1_THREADS), lds1, s, A->n_cols,
                            A->d_slab_begin, A->d_slab_end, static_cast<const VT *>(A->d_val), A->d_lcol, x, prod, ctrl);
-    // about one chunk of row blocks per CU (k_pb_phase2), in multiples of 8 for the XCD mapping
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(AKS_ERR_HIP, "hipGetDeviceProperties");
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const int n_chunks = (int)std::min<int64_t>(A->n_rowblocks, n_cu);
+    const int n_chunks = (int)std::min<int64_t>(A->n_rowblocks, AKS_PB_CHUNKS);   // as the planner ordered them
     const int cpx = (n_chunks + 7) / 8;
     const uint4 *runs = reinterpret_cast<const uint4 *>(A->d_runs);
     if (accumulate)
@@ -1456,8 +1463,14 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
     std::vector<uint8_t> last_wave(PB_RB, 0), last_level(PB_RB, 0);
     std::vector<Load> loads;
     int64_t round_id = 0;
-    for (int64_t rb = 0; rb < n_rb; ++rb) {
-        P->rb_run_ptr[rb] = (int32_t)P->runs.size();
+    // row blocks are stored chunk by chunk, chunk c = row blocks c, c + n_chunks, ... (see k_pb_phase2)
+    const int64_t n_chunks = std::min<int64_t>(n_rb, AKS_PB_CHUNKS);
+    std::vector<int64_t> rb_at;
+    for (int64_t c = 0; c < n_chunks; ++c)
+        for (int64_t rb = c; rb < n_rb; rb += n_chunks) rb_at.push_back(rb);
+    for (int64_t pos = 0; pos < n_rb; ++pos) {
+        const int64_t rb = rb_at[pos];
+        P->rb_run_ptr[pos] = (int32_t)P->runs.size();
         loads.clear();
         Load cur{};
         auto close = [&] { if (cur.total > 0) loads.push_back(cur); cur = Load{}; };
@@ -1507,7 +1520,7 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
             }
             for (int j = 0; j < PB_RPR; ++j) P->runs[rr + j].info |= levels << 21;
         }
-        if ((size_t)P->rb_run_ptr[rb] == P->runs.size()) {      // a row block without entries still owns one round
+        if ((size_t)P->rb_run_ptr[pos] == P->runs.size()) {     // a row block without entries still owns one round
             P->runs.resize(P->runs.size() + PB_RPR, aks_pb_run{0u, 0u, 0u, 1u << 21});
             P->lrow.resize(P->lrow.size() + PB_RW, (uint16_t)0);
         }

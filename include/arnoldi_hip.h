@@ -140,6 +140,11 @@ int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indic
 #define AKS_PB_RUNS_PER_WAVE 4   /* wave-loads a wave takes per round (round = 32 of them)    */
 #endif
 #define AKS_PB_RUN_MAX 64        /* entries per wave-load (one lane each)                     */
+#define AKS_PB_CHUNKS 256        /* phase-2 workgroups (CUs of an MI355X).  With n_chunks = min(n_rowblocks, 256),
+                                    chunk c owns the row blocks c, c + n_chunks, c + 2 n_chunks, ...; d_runs /
+                                    d_lrow / d_rb_run_ptr hold the row blocks in THAT order: position p of
+                                    d_rb_run_ptr is the k-th row block of chunk c, where the first
+                                    n_rowblocks % n_chunks chunks own one row block more than the others     */
 #define AKS_PB_PIECES 3          /* contiguous pieces a wave-load gathers from                */
 #define AKS_PB_ROUND_WORDS (AKS_PB_WAVES * AKS_PB_RUNS_PER_WAVE * AKS_PB_RUN_MAX)   /* 2048  */
 
@@ -163,7 +168,7 @@ typedef struct aks_pb_matrix {
     const int32_t *d_slab_begin;    /* n_slabs: first phase-1 slot of each sub-slab            */
     const int32_t *d_slab_end;      /* n_slabs: one past its last entry                        */
     const aks_pb_run *d_runs;       /* n_runs wave-load descriptors, row block by row block    */
-    const int32_t *d_rb_run_ptr;    /* n_rowblocks + 1: first wave-load of each row block      */
+    const int32_t *d_rb_run_ptr;    /* n_rowblocks + 1: first wave-load per row-block POSITION  */
     const uint16_t *d_lrow;         /* n_lrow = n_runs * 64: level << 13 | row - rowblock * 8192;
                                        round r (= slots 32 r ..) owns words 2048 r + wave * 256 + lane * 4 + k */
     aks_c128 *d_prod;               /* nnz_pad complex128 scratch (the products)               */

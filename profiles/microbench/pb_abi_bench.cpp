@@ -119,6 +119,16 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < w * n; ++i) { err = std::max(err, std::fabs(h1[i] - h2[i])); ref = std::max(ref, std::fabs(h1[i])); }
     printf("max |binned - csr| = %.3e (max |y| %.3f); second binned run bitwise equal: %s\n", err, ref,
            memcmp(h2.data(), h3.data(), w * n * 8) == 0 ? "yes" : "NO");
+    if (getenv("PB_TICKS")) {   // library built with -DAKS_PB_TICKS=1: per-workgroup s_memtime sums sit in the scratch
+        const int n_wg = std::min(256, sz.n_rowblocks);
+        std::vector<double> dbg(8 * (size_t)n_wg);
+        CK(hipMemcpy(dbg.data(), A.d_prod, dbg.size() * 8, hipMemcpyDeviceToHost));
+        double t[8] = {0};
+        for (int b = 0; b < n_wg; ++b) for (int i = 0; i < 8; ++i) t[i] += dbg[8 * (size_t)b + i];
+        printf("phase 2, wave 0, s_memtime ticks per round: issue loads + first-level adds %.0f | their barrier (adds of all waves done) %.0f | "
+               "other levels + write-out %.0f | total %.0f (%.1f rounds per workgroup)\n",
+               t[0] / t[7], t[1] / t[7], t[2] / t[7], t[6] / t[7], t[7] / n_wg);
+    }
     // accumulate form
     pb(y2, 1);
     CK(hipMemcpy(h3.data(), y2, w * n * 8, hipMemcpyDeviceToHost));

@@ -108,7 +108,9 @@ class FakeHip:
             l0, l01, total, levels = info & 127, (info >> 7) & 127, (info >> 14) & 127, (info >> 21) & 15
             assert total.max() <= 64 and int(total.sum()) == nnz and np.all(l0 <= l01) and np.all(l01 <= total)
             assert np.all(levels[total > 0] >= 1) and np.all(total[rbp[-1]:] == 0)
-            rb_of_run = np.repeat(np.arange(d.n_rowblocks, dtype=np.int64), np.diff(rbp))
+            n_chunks = min(int(d.n_rowblocks), 256)                                  # AKS_PB_CHUNKS: chunk-interleaved order
+            rb_at = np.concatenate([np.arange(c, d.n_rowblocks, n_chunks) for c in range(n_chunks)]).astype(np.int64)
+            rb_of_run = np.repeat(rb_at, np.diff(rbp))
             rep = np.repeat(np.arange(len(runs)), total)                            # wave-load of every lane
             lane = np.arange(nnz) - np.repeat(np.cumsum(total) - total, total)
             base = np.where(lane < l0[rep], runs[rep, 0], np.where(lane < l01[rep], runs[rep, 1], runs[rep, 2]))

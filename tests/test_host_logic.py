@@ -418,7 +418,8 @@ def test_row_sharded_solve_two_ranks_gloo(tmp_path):
 
 # ---------------------------------------------------------------------------- tile-binned SpMV form
 @pytest.mark.parametrize("shape,complex_vals", [((5000, 5000), False), ((3000, 200_000), True), ((70_000, 900), False),
-                                                ((20_000, 20_000), False)])
+                                                ((20_000, 20_000), False),
+                                                ((2_130_000, 30_000), False)])     # 261 row blocks: > AKS_PB_CHUNKS
 def test_binned_plan_represents_the_matrix(fake, shape, complex_vals):
     """aks_pb_plan_create / aks_pb_plan_export are host code: replaying the two phases on the planned
     arrays (tests/fake_hip.py) must reproduce A @ x, including empty rows, a long row, several
@@ -430,7 +431,7 @@ def test_binned_plan_represents_the_matrix(fake, shape, complex_vals):
 
     rng = np.random.default_rng(shape[0])
     n_rows, n_cols = shape
-    nnz = 6 * n_rows
+    nnz = 6 * n_rows if n_rows < 1_000_000 else n_rows
     rows = rng.integers(0, n_rows, nnz)
     rows[rows % 7 == 0] = 1                       # empty rows + one long row (many runs, every level)
     cols = rng.integers(0, n_cols, nnz)
