@@ -716,7 +716,10 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int64_t count, const int32_t *
 constexpr int PB_CW_BITS = AKS_PB_SLAB_BITS, PB_CW = 1 << PB_CW_BITS;       // columns per sub-slab
 constexpr int PB_RB_BITS = AKS_PB_ROWBLOCK_BITS, PB_RB = 1 << PB_RB_BITS;   // rows per row block
 constexpr int PB_W = AKS_PB_WAVES, PB_K = AKS_PB_RUNS_PER_WAVE, PB_RPR = PB_W * PB_K;
-constexpr int PB_D = 4;                      // pipeline stages per wave: a round is loaded PB_D - 1 steps before its adds
+#ifndef AKS_PB_DEPTH
+#define AKS_PB_DEPTH 4
+#endif
+constexpr int PB_D = AKS_PB_DEPTH;                      // pipeline stages per wave: a round is loaded PB_D - 1 steps before its adds
 constexpr int PB_B = 8;                      // rounds whose descriptors one vector load fetches (PB_B * PB_K lanes)
 constexpr int PB_P1_THREADS = 1024, PB_P1_U = 4;
 constexpr int PB_RW = AKS_PB_ROUND_WORDS;    // (level, row) words of one round: [wave][lane][k]
@@ -726,7 +729,8 @@ constexpr int PB_MAX_LEVELS = 8;             // 3-bit level field next to the 13
 #endif                           // section in the first doubles of the product scratch (pb_abi_bench prints them)
 static_assert(PB_CW_BITS <= 13 && PB_RB_BITS <= 13, "lcol / lrow are 13-bit fields");
 static_assert(PB_B % PB_D == 0 && PB_B * PB_K <= 64, "descriptor block: a multiple of the depth, one lane per slot");
-static_assert(PB_K == 4 && AKS_PB_RUN_MAX == 64, "a lane's words of a round are one 8-byte load");
+static_assert((PB_K == 4 || PB_K == 8) && AKS_PB_RUN_MAX == 64, "a lane's words of a round are one 8- or 16-byte load");
+struct alignas(PB_K * 2) PbWords { unsigned v[PB_K / 2]; };     // a lane's PB_K (level, row) words of one round
 static_assert(PB_W <= PB_MAX_LEVELS, "a level counts waves");
 
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -841,7 +845,7 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
     const int n_rounds = (rb_run_ptr[pos_hi] - R0) / PB_RPR;
     int rb = chunk;                              // row block of the round whose adds are next
     const uint4 *my_runs = runs + R0 + wave * PB_K;
-    const uint2 *my_words = reinterpret_cast<const uint2 *>(lrow + (size_t)(R0 / PB_RPR) * PB_RW) + wave * 64 + lane;
+    const PbWords *my_words = reinterpret_cast<const PbWords *>(lrow + (size_t)(R0 / PB_RPR) * PB_RW) + wave * 64 + lane;
     auto load_block = [&](int first_round) {
         const int l = lane & (PB_B * PB_K - 1);
         const int round = first_round + l / PB_K;
@@ -851,10 +855,10 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
     };
     XT p[PB_D][PB_K];
     unsigned info[PB_D][PB_K];
-    uint2 words[PB_D];
+    PbWords words[PB_D];
 #pragma unroll
     for (int d = 0; d < PB_D; ++d) {
-        words[d] = make_uint2(0u, 0u);
+        words[d] = PbWords{};
 #pragma unroll
         for (int k = 0; k < PB_K; ++k) { info[d][k] = 0u; p[d][k] = pb_zero<XT>(); }
     }
@@ -897,7 +901,7 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
             unsigned m[PB_K];                   // this lane's word per wave-load; inactive lanes match no level
 #pragma unroll
             for (int k = 0; k < PB_K; ++k) {
-                const unsigned w = k < 2 ? words[d].x : words[d].y;
+                const unsigned w = words[d].v[k / 2];
                 m[k] = lane < (int)((info[d][k] >> 14) & 127u) ? ((k & 1) ? w >> 16 : w & 0xffffu) : 0xffffffffu;
             }
             const int nph = max((int)((info[d][0] >> 21) & 15u), 1);
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(PB_W * 64) void k_pb_phase2(int64_t n_rows, int n_r
             auto add_slot = [&](int k) {
                 if ((int)(m[k] >> 13) == 0) pb_acc_add(acc, (int)(m[k] & (PB_RB - 1)), p[d][k]);
             };
-            words[dp] = my_words[(size_t)rnd * (PB_RW / 4)];
+            words[dp] = my_words[(size_t)rnd * (PB_W * 64)];
 #pragma unroll
             for (int k = 0; k < PB_K; ++k) issue_load(k);
 #pragma unroll

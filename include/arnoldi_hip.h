@@ -137,7 +137,8 @@ int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indic
 #define AKS_PB_WAVES 8           /* waves of a phase-2 workgroup                              */
 #endif
 #ifndef AKS_PB_RUNS_PER_WAVE
-#define AKS_PB_RUNS_PER_WAVE 4   /* wave-loads a wave takes per round (round = 32 of them)    */
+#define AKS_PB_RUNS_PER_WAVE 4   /* wave-loads a wave takes per round (round = 32 of them; 8 builds too, for
+                                    experiments through the C ABI only: measured slower) */
 #endif
 #define AKS_PB_RUN_MAX 64        /* entries per wave-load (one lane each)                     */
 #define AKS_PB_CHUNKS 256        /* phase-2 workgroups (CUs of an MI355X).  With n_chunks = min(n_rowblocks, 256),

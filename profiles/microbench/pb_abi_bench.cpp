@@ -61,10 +61,13 @@ int main(int argc, char **argv) {
     printf("plan: %.2f s, nnz_pad %lld, %lld wave-loads, %lld (level,row) words, %d sub-slabs x %d row blocks\n",
            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), (long long)sz.nnz_pad,
            (long long)sz.n_runs, (long long)sz.n_lrow, sz.n_slabs, sz.n_rowblocks);
+    int32_t slab_bits, rb_bits, rpr;
+    AK(aks_pb_params(&slab_bits, &rb_bits, &rpr));
     double mean_levels = 0, filled = 0;
-    for (int64_t r = 0; r + 32 < sz.n_runs; r += 32) mean_levels += (runs[r].info >> 21) & 15;
+    for (int64_t r = 0; r + rpr < sz.n_runs; r += rpr) mean_levels += (runs[r].info >> 21) & 15;
     for (int64_t r = 0; r < sz.n_runs; ++r) filled += ((runs[r].info >> 14) & 127) != 0;
-    printf("mean levels per round %.2f, mean lanes per wave-load %.1f\n", mean_levels / (sz.n_runs / 32 - 1), nnz / filled);
+    printf("%d wave-loads per round, mean levels per round %.2f, mean lanes per wave-load %.1f\n", rpr,
+           mean_levels / (sz.n_runs / rpr - 1), nnz / filled);
 
     aks_pb_matrix A;
     memset(&A, 0, sizeof A);

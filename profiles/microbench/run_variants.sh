@@ -9,7 +9,7 @@ for v in "$@"; do
   name=$(echo "$v" | tr '/' '_')
   export LD_LIBRARY_PATH=$R/$v:/opt/rocm/lib
   timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/var_$name -o t -- $R/profiles/microbench/pb_abi_bench > $R/gpurun_out/var_$name.txt 2>&1 || echo "(bench rc $?)"
-  echo "== $v"; grep "tile-binned\|levels" $R/gpurun_out/var_$name.txt
+  echo "== $v"; grep "tile-binned\|levels\|max |" $R/gpurun_out/var_$name.txt
   python3 - "$R/gpurun_out/var_$name/t_kernel_stats.csv" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
