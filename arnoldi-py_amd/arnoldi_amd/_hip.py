@@ -86,13 +86,23 @@ class PbMatrix(C.Structure):
         ("d_rb_run_ptr", _P), ("d_lrow", _P), ("d_prod", _P),
     ]
 
+
+class SellMatrix(C.Structure):
+    """Mirror of ``aks_sell_matrix`` (device pointers of the sliced SpMV form)."""
+
+    _fields_ = [
+        ("n_rows", _I64), ("n_cols", _I64), ("nnz", _I64), ("nnz_pad", _I64), ("n_slices", _I64),
+        ("values_complex", _I32), ("pad_", _I32), ("d_slice_ptr", _P), ("d_col", _P), ("d_val", _P),
+    ]
+
+
 class CsrBlock(C.Structure):
-    """Mirror of ``aks_csr_block``: one CSR block with its SpMV plan (either form)."""
+    """Mirror of ``aks_csr_block``: one CSR block with its SpMV plan (any of the three forms)."""
 
     _fields_ = [
         ("n_rows", _I64), ("n_cols", _I64), ("d_indptr", _P), ("d_indices", _P), ("d_values", _P),
         ("d_tiles", _P), ("n_tiles", _I64), ("values_complex", _I32), ("lanes_per_row", _I32),
-        ("pb", C.POINTER(PbMatrix)),
+        ("pb", C.POINTER(PbMatrix)), ("sell", C.POINTER(SellMatrix)),
     ]
 
 
@@ -124,6 +134,9 @@ SIGNATURES = {
     "aks_pb_plan_export": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "aks_pb_plan_destroy": (None, [_P]),
     "aks_pb_spmv": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),
+    "aks_sell_plan_size": (_I64, [_P, _I64]),
+    "aks_sell_plan_fill": (C.c_int, [_P, _P, _P, _I32, _I64, _P, _P, _P]),
+    "aks_sell_spmv": (C.c_int, [C.POINTER(SellMatrix), _P, _P, _I32, _P, _P]),
     "aks_arnoldi_expand": (C.c_int, [C.POINTER(Shard), _P, _I64, _P, _I64, _I32, _I32, _F64, _F64, _P, _I64, _I32, _P, _P,
                                      _I32]),
     "aks_shard_apply": (C.c_int, [C.POINTER(Shard), _P, _P, _P, _P, _I32]),
@@ -134,6 +147,7 @@ SIGNATURES = {
     "aks_workspace_set_real": (C.c_int, [_P, _I32, _P]),
     "aks_csr_spmv_real": (C.c_int, [_I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _P]),
     "aks_pb_spmv_real": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),
+    "aks_sell_spmv_real": (C.c_int, [C.POINTER(SellMatrix), _P, _P, _I32, _P, _P]),
     "aks_gather_f64": (C.c_int, [_I64, _P, _P, _P, _P]),
     "aks_truncate": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P]),
     "aks_combine": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P, _I64, _P]),

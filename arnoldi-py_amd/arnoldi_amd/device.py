@@ -122,7 +122,16 @@ class DeviceCSR:
 
         self._host = M            # kept until the SpMV form has been chosen (autotune)
         self.binned = None        # BinnedCSR once built
-        self.use_binned = False   # which form spmv() / aks_arnoldi_expand use
+        self.sliced = None        # SlicedCSR once built
+        self.form = "csr"         # which form spmv() / aks_arnoldi_expand use: "csr" | "binned" | "sliced"
+
+    @property
+    def use_binned(self):
+        return self.form == "binned"
+
+    @use_binned.setter
+    def use_binned(self, flag):
+        self.form = "binned" if flag else "csr"
 
     def block(self, out=None):
         """Fill (and return) an ``aks_csr_block`` for this matrix with the SpMV form in use."""
@@ -131,7 +140,8 @@ class DeviceCSR:
         b.d_indptr, b.d_indices, b.d_values = self.indptr.data_ptr(), self.indices.data_ptr(), self.values.data_ptr()
         b.d_tiles, b.n_tiles = self.tiles.data_ptr(), self.n_tiles
         b.values_complex, b.lanes_per_row = self.values_complex, self.lanes_per_row
-        b.pb = C.pointer(self.binned.desc) if self.use_binned else None
+        b.pb = C.pointer(self.binned.desc) if self.form == "binned" else None
+        b.sell = C.pointer(self.sliced.desc) if self.form == "sliced" else None
         return b
 
     def algorithmic_bytes(self, real=False):
@@ -163,27 +173,49 @@ class DeviceCSR:
             self.binned = BinnedCSR(self._host, self.device)
         return self.binned
 
+    SLICED_MAX_PADDING = 1.25      # the sliced form is tried while its padded size stays below this x nnz
+
+    def sliced_padding(self):
+        """Padded size of the sliced form relative to nnz (1.0 = every row of a slice equally long)."""
+        if self._host is None or self.nnz == 0:
+            return float("inf")
+        indptr = np.ascontiguousarray(self._host.indptr, dtype=np.int32)
+        return int(_hip.check(_hip.load().aks_sell_plan_size(indptr.ctypes.data, self.n_rows), "aks_sell_plan_size")) / self.nnz
+
+    def build_sliced(self):
+        if self.sliced is None:
+            if self._host is None:
+                raise _hip.HipLibraryError("host copy of the matrix already released")
+            self.sliced = SlicedCSR(self._host, self.device)
+        return self.sliced
+
     def autotune(self, min_nnz=2_000_000, reps=3, force=None, real=False):
-        """Pick the CSR-stream or the tile-binned SpMV by timing both on this device.
-        Only matrices that are large and scattered enough to miss L2 are candidates.
-        ``force`` = "csr" | "binned" skips the measurement.  Frees the host copy.
+        """Pick the SpMV form by timing the candidates on this device: the CSR-stream kernel always; the
+        tile-binned form for matrices that are large and scattered enough to miss L2; the sliced form for
+        matrices with column locality whose rows are of similar length (padding <= 1.25 x nnz).
+        ``force`` = "csr" | "binned" | "sliced" skips the measurement.  Frees the host copy.
         ``real``: time the real-vector kernels (real-packed mode)."""
         choice = force
         if choice is None:
-            candidate = self.nnz >= min_nnz and self.n_cols * 16 > (4 << 20) and self.scatter_ratio() > 0.5
-            if not candidate:
-                choice = "csr"
-        if choice is None:
-            try:
-                self.build_binned()
-            except _hip.HipLibraryError:      # too many tiles / non-zeros for the binned form
+            forms = ["csr"]
+            scattered = self.nnz >= min_nnz // 4 and self.scatter_ratio() > 0.5      # gathers without locality
+            if scattered and self.nnz >= min_nnz and self.n_cols * 16 > (4 << 20):
+                try:
+                    self.build_binned()
+                    forms.append("binned")
+                except _hip.HipLibraryError:      # too many tiles / non-zeros for the binned form
+                    pass
+            if not scattered and self.nnz >= min_nnz // 4 and self.sliced_padding() <= self.SLICED_MAX_PADDING:
+                self.build_sliced()
+                forms.append("sliced")
+            if len(forms) == 1:
                 choice = "csr"
         if choice is None:
             x = torch.zeros(self.n_cols, dtype=torch.complex128, device=self.device)
             y = torch.empty(self.n_rows, dtype=torch.complex128, device=self.device)
             times = {}
-            for form in ("csr", "binned"):
-                self.use_binned = form == "binned"
+            for form in forms:
+                self.form = form
                 self.spmv(x, y, real=real)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -193,12 +225,19 @@ class DeviceCSR:
                 torch.cuda.synchronize()
                 times[form] = e0.elapsed_time(e1) / reps
             self.tune_ms = times
-            choice = "binned" if times["binned"] < 0.9 * times["csr"] else "csr"
+            choice = "csr"
+            best = min((f for f in forms if f != "csr"), key=times.get)
+            if times[best] < (0.9 if best == "binned" else 0.95) * times["csr"]:
+                choice = best
         if choice == "binned":
             self.build_binned()
-        else:
+        elif choice == "sliced":
+            self.build_sliced()
+        if choice != "binned":
             self.binned = None
-        self.use_binned = choice == "binned"
+        if choice != "sliced":
+            self.sliced = None
+        self.form = choice
         self._host = None
         return choice
 
@@ -211,27 +250,50 @@ class DeviceCSR:
                 assert t.dtype == torch.complex128 or (real and t.dtype == torch.float64)
                 assert have >= need and t.is_contiguous()
         wsp = _ptr(ws.buf) if ws is not None else C.c_void_p(0)
+        lib = _hip.load()
         if real:
             assert not self.values_complex, "real vectors need real matrix values"
-            if self.use_binned:
-                rc = _hip.load().aks_pb_spmv_real(C.byref(self.binned.desc), _ptr(x), _ptr(y), int(accumulate),
-                                                  wsp, _stream())
-            else:
-                rc = _hip.load().aks_csr_spmv_real(
-                    self.n_rows, _ptr(self.indptr), _ptr(self.indices), _ptr(self.values), _ptr(self.tiles),
-                    self.n_tiles, self.lanes_per_row, _ptr(x), _ptr(y), int(accumulate), wsp, _stream())
-            _hip.check(rc, "aks_*_spmv_real")
-            return
-        if self.use_binned:
-            rc = _hip.load().aks_pb_spmv(C.byref(self.binned.desc), _ptr(x), _ptr(y), int(accumulate),
-                                         _ptr(ws.buf) if ws is not None else C.c_void_p(0), _stream())
-            _hip.check(rc, "aks_pb_spmv")
-            return
-        rc = _hip.load().aks_csr_spmv(
-            self.n_rows, _ptr(self.indptr), _ptr(self.indices), _ptr(self.values), self.values_complex,
-            _ptr(self.tiles), self.n_tiles, self.lanes_per_row, _ptr(x), _ptr(y), int(accumulate),
-            _ptr(ws.buf) if ws is not None else C.c_void_p(0), _stream())
-        _hip.check(rc, "aks_csr_spmv")
+        sfx = "_real" if real else ""
+        if self.form == "binned":
+            rc = getattr(lib, "aks_pb_spmv" + sfx)(C.byref(self.binned.desc), _ptr(x), _ptr(y), int(accumulate), wsp, _stream())
+        elif self.form == "sliced":
+            rc = getattr(lib, "aks_sell_spmv" + sfx)(C.byref(self.sliced.desc), _ptr(x), _ptr(y), int(accumulate), wsp, _stream())
+        elif real:
+            rc = lib.aks_csr_spmv_real(self.n_rows, _ptr(self.indptr), _ptr(self.indices), _ptr(self.values),
+                                       _ptr(self.tiles), self.n_tiles, self.lanes_per_row, _ptr(x), _ptr(y),
+                                       int(accumulate), wsp, _stream())
+        else:
+            rc = lib.aks_csr_spmv(self.n_rows, _ptr(self.indptr), _ptr(self.indices), _ptr(self.values),
+                                  self.values_complex, _ptr(self.tiles), self.n_tiles, self.lanes_per_row, _ptr(x),
+                                  _ptr(y), int(accumulate), wsp, _stream())
+        _hip.check(rc, "aks_*_spmv" + sfx)
+
+
+class SlicedCSR:
+    """Sliced form of a CSR block (``aks_sell_matrix``): slices of 64 rows stored entry-major, planned on the
+    host by ``aks_sell_plan_size`` / ``aks_sell_plan_fill`` and uploaded."""
+
+    def __init__(self, M, device):
+        lib = _hip.load()
+        n_rows, n_cols = M.shape
+        indptr = np.ascontiguousarray(M.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(M.indices, dtype=np.int32)
+        values = np.ascontiguousarray(M.data)
+        cplx = int(values.dtype == C128)
+        nnz_pad = int(_hip.check(lib.aks_sell_plan_size(indptr.ctypes.data, n_rows), "aks_sell_plan_size"))
+        n_slices = (n_rows + 63) // 64
+        slice_ptr = np.empty(n_slices + 1, np.int64)
+        col = np.empty(max(nnz_pad, 1), np.int32)
+        val = np.empty(max(nnz_pad, 1), values.dtype)
+        _hip.check(lib.aks_sell_plan_fill(indptr.ctypes.data, indices.ctypes.data, values.ctypes.data, cplx, n_rows,
+                                          slice_ptr.ctypes.data, col.ctypes.data, val.ctypes.data), "aks_sell_plan_fill")
+        self.slice_ptr, self.col, self.val = (torch.from_numpy(a).to(device) for a in (slice_ptr, col, val))
+        self.padding = nnz_pad / max(int(M.nnz), 1)
+        d = _hip.SellMatrix()
+        d.n_rows, d.n_cols, d.nnz, d.nnz_pad, d.n_slices = n_rows, n_cols, int(M.nnz), nnz_pad, n_slices
+        d.values_complex, d.pad_ = cplx, 0
+        d.d_slice_ptr, d.d_col, d.d_val = self.slice_ptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr()
+        self.desc = d
 
 
 class BinnedCSR:

@@ -35,8 +35,9 @@ class CsrOperator:
 
     def __init__(self, A=None, *, local_rows=None, offsets=None, comm=None, device=None, spmv_form=None,
                  real=False):
-        """``spmv_form``: None/"auto" (time the CSR-stream and the slab-binned kernels on large
-        scattered matrices and keep the faster), "csr" or "binned".  Environment override:
+        """``spmv_form``: None/"auto" (time the CSR-stream kernel against the tile-binned form on large
+        scattered matrices and against the sliced form on matrices with rows of similar length, keep the
+        fastest), "csr", "binned" or "sliced".  Environment override:
         AKS_SPMV_FORM.  ``real``: the operator works on real vectors (real-packed Krylov basis):
         real-vector SpMV kernels, float64 ghost exchange."""
         form = os.environ.get("AKS_SPMV_FORM", spmv_form or "auto")

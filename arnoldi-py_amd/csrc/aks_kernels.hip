@@ -506,6 +506,8 @@ __device__ __forceinline__ double xt_re(double v) { return v; }
 __device__ __forceinline__ double xt_im(double) { return 0.0; }
 __device__ __forceinline__ void xt_make(double re, double im, c128 *out) { *out = make_double2(re, im); }
 __device__ __forceinline__ void xt_make(double re, double, double *out) { *out = re; }
+__device__ __forceinline__ c128 xt_add(c128 a, c128 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double xt_add(double a, double b) { return a + b; }
 
 template <typename VT, typename XT, bool ACC>
 __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *__restrict__ indptr,
@@ -592,6 +594,72 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *
             }
             xt_make(sr, si, &y[r0]);
         }
+    }
+}
+
+// ------------------------------------------------------------------ sliced SpMV (regular matrices)
+// One lane per row; a SLICE of 64 consecutive rows is stored entry-major (entry k of all 64 rows, then
+// entry k + 1, ...), padded to the slice's longest row with column -1: a wave's value and column loads are
+// contiguous, its x gathers are as local as the matrix is (neighbouring rows of a stencil or a band read
+// neighbouring x), and a row is summed in column order in registers -- no LDS, no second pass.
+// Workgroups with the same blockIdx % 8 share an XCD (observed placement; speed only): each XCD gets a
+// contiguous eighth of the slices, so the x entries that rows a grid line or plane apart share are fetched
+// into ONE L2 rather than into all eight (profiles/microbench/sell_spmv.txt: 3-D Laplace 0.400 -> 0.347 ms).
+constexpr int SELL_U = 4;
+#ifndef AKS_NT_SELL
+#define AKS_NT_SELL 1            // non-temporal loads of the value / column streams (read once): 1-8 % (sell_spmv.txt)
+#endif
+__device__ __forceinline__ int ld_sell(const int32_t *p) { return AKS_NT_SELL ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ double ld_sell(const double *p) { return AKS_NT_SELL ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ c128 ld_sell(const c128 *p) {
+#if AKS_NT_SELL
+    typedef double nt_v2d __attribute__((ext_vector_type(2)));
+    const nt_v2d v = __builtin_nontemporal_load(reinterpret_cast<const nt_v2d *>(p));
+    return make_double2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+template <typename VT, typename XT, bool ACC>
+__global__ __launch_bounds__(BLOCK) void k_sell(int64_t n_rows, int64_t n_slices, const int64_t *__restrict__ slice_ptr,
+                                               const int32_t *__restrict__ col, const VT *__restrict__ val,
+                                               const XT *__restrict__ x, XT *__restrict__ y,
+                                               const aks_ctrl *__restrict__ ctrl) {
+    if (ctrl != nullptr && ctrl->broken) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t per_xcd = (gridDim.x + 7) >> 3;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t slice = wg * WAVES + (threadIdx.x >> 6);
+    if (slice >= n_slices) return;
+    const int64_t p0 = slice_ptr[slice];
+    const int W = (int)((slice_ptr[slice + 1] - p0) >> 6);
+    const int32_t *c = col + p0 + lane;
+    const VT *v = val + p0 + lane;
+    XT acc;
+    xt_make(0.0, 0.0, &acc);
+    int k = 0;
+    for (; k + SELL_U <= W; k += SELL_U) {
+        int cc[SELL_U];
+        VT vv[SELL_U];
+        XT xx[SELL_U];
+#pragma unroll
+        for (int u = 0; u < SELL_U; ++u) { cc[u] = ld_sell(&c[(int64_t)(k + u) * 64]); vv[u] = ld_sell(&v[(int64_t)(k + u) * 64]); }
+#pragma unroll
+        for (int u = 0; u < SELL_U; ++u) xx[u] = x[max(cc[u], 0)];
+#pragma unroll
+        for (int u = 0; u < SELL_U; ++u)
+            if (cc[u] >= 0) acc = xt_add(acc, cmul(vv[u], xx[u]));
+    }
+    for (; k < W; ++k) {
+        const int cc = ld_sell(&c[(int64_t)k * 64]);
+        const VT vv = ld_sell(&v[(int64_t)k * 64]);
+        const XT xx = x[max(cc, 0)];
+        if (cc >= 0) acc = xt_add(acc, cmul(vv, xx));
+    }
+    const int64_t row = slice * 64 + lane;
+    if (row < n_rows) {
+        if (ACC) acc = xt_add(acc, y[row]);
+        y[row] = acc;
     }
 }
 
@@ -1107,17 +1175,19 @@ int apply_block(const aks_csr_block &B, const void *x, void *y, int accumulate, 
     if (B.n_rows <= 0) return AKS_OK;
     if (real) {
         if (B.values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
-        return B.pb != nullptr
-                   ? aks_pb_spmv_real(B.pb, static_cast<const double *>(x), static_cast<double *>(y), accumulate, d_ws, stream)
-                   : aks_csr_spmv_real(B.n_rows, B.d_indptr, B.d_indices, static_cast<const double *>(B.d_values), B.d_tiles,
-                                       B.n_tiles, B.lanes_per_row, static_cast<const double *>(x),
-                                       static_cast<double *>(y), accumulate, d_ws, stream);
+        const double *xr = static_cast<const double *>(x);
+        double *yr = static_cast<double *>(y);
+        if (B.sell != nullptr) return aks_sell_spmv_real(B.sell, xr, yr, accumulate, d_ws, stream);
+        if (B.pb != nullptr) return aks_pb_spmv_real(B.pb, xr, yr, accumulate, d_ws, stream);
+        return aks_csr_spmv_real(B.n_rows, B.d_indptr, B.d_indices, static_cast<const double *>(B.d_values), B.d_tiles,
+                                 B.n_tiles, B.lanes_per_row, xr, yr, accumulate, d_ws, stream);
     }
-    return B.pb != nullptr
-               ? aks_pb_spmv(B.pb, static_cast<const aks_c128 *>(x), static_cast<aks_c128 *>(y), accumulate, d_ws, stream)
-               : aks_csr_spmv(B.n_rows, B.d_indptr, B.d_indices, B.d_values, B.values_complex, B.d_tiles, B.n_tiles,
-                              B.lanes_per_row, static_cast<const aks_c128 *>(x), static_cast<aks_c128 *>(y), accumulate,
-                              d_ws, stream);
+    const aks_c128 *xc = static_cast<const aks_c128 *>(x);
+    aks_c128 *yc = static_cast<aks_c128 *>(y);
+    if (B.sell != nullptr) return aks_sell_spmv(B.sell, xc, yc, accumulate, d_ws, stream);
+    if (B.pb != nullptr) return aks_pb_spmv(B.pb, xc, yc, accumulate, d_ws, stream);
+    return aks_csr_spmv(B.n_rows, B.d_indptr, B.d_indices, B.d_values, B.values_complex, B.d_tiles, B.n_tiles,
+                        B.lanes_per_row, xc, yc, accumulate, d_ws, stream);
 }
 
 // ---- tile-binned SpMV: host-side plan and launcher
@@ -1181,6 +1251,28 @@ int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const 
         hipLaunchKernelGGL((k_pb_phase2<XT, false>), dim3((unsigned)(cpx * 8)), dim3(PB_W * 64), lds2, s, A->n_rows,
                            A->n_rowblocks, n_chunks, cpx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
     AKS_CHECK_LAUNCH("aks_pb_spmv");
+    return AKS_OK;
+}
+
+int check_sell(const aks_sell_matrix *A, const void *x, const void *y) {
+    if (A == nullptr || x == nullptr || y == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    if (A->n_rows <= 0 || A->n_cols <= 0 || A->nnz < 0 || A->nnz_pad < 0 || (A->nnz_pad & 63) != 0 ||
+        A->n_slices != (A->n_rows + 63) / 64)
+        return fail(AKS_ERR_ARG, "bad sizes in aks_sell_matrix");
+    if (!A->d_slice_ptr || (A->nnz_pad > 0 && (!A->d_col || !A->d_val))) return fail(AKS_ERR_ARG, "null array in aks_sell_matrix");
+    if (x == y) return fail(AKS_ERR_ARG, "x and y must not alias");
+    return AKS_OK;
+}
+
+template <typename VT, typename XT>
+int launch_sell(const aks_sell_matrix *A, const XT *x, XT *y, int accumulate, const aks_ctrl *ctrl, hipStream_t s) {
+    const dim3 grid((unsigned)(((A->n_slices + WAVES - 1) / WAVES + 7) / 8 * 8));    // whole groups of 8: the XCD order
+    const VT *val = static_cast<const VT *>(A->d_val);
+    if (accumulate)
+        hipLaunchKernelGGL((k_sell<VT, XT, true>), grid, dim3(BLOCK), 0, s, A->n_rows, A->n_slices, A->d_slice_ptr, A->d_col, val, x, y, ctrl);
+    else
+        hipLaunchKernelGGL((k_sell<VT, XT, false>), grid, dim3(BLOCK), 0, s, A->n_rows, A->n_slices, A->d_slice_ptr, A->d_col, val, x, y, ctrl);
+    AKS_CHECK_LAUNCH("aks_sell_spmv");
     return AKS_OK;
 }
 
@@ -1599,6 +1691,73 @@ int aks_workspace_set_real(void *d_ws, int32_t real_packed, void *stream) {
                                      static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "hipMemsetD32Async(real_mode)");
     return AKS_OK;
+}
+
+// ---- sliced form: host helpers and entry points ---------------------------------------------
+int64_t aks_sell_plan_size(const int32_t *indptr, int64_t n_rows) {
+    if (indptr == nullptr || n_rows <= 0) return fail(AKS_ERR_ARG, "bad argument");
+    int64_t total = 0;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 64) {
+        int64_t w = 0;
+        for (int64_t r = r0; r < std::min(n_rows, r0 + 64); ++r) {
+            if (indptr[r + 1] < indptr[r]) return fail(AKS_ERR_ARG, "indptr is not monotone");
+            w = std::max<int64_t>(w, indptr[r + 1] - indptr[r]);
+        }
+        total += 64 * w;
+    }
+    return total;
+}
+
+int aks_sell_plan_fill(const int32_t *indptr, const int32_t *indices, const void *values, int32_t values_complex,
+                       int64_t n_rows, int64_t *slice_ptr_out, int32_t *col_out, void *val_out) {
+    if (!indptr || !indices || !values || !slice_ptr_out || n_rows <= 0) return fail(AKS_ERR_ARG, "bad argument");
+    const int64_t n_slices = (n_rows + 63) / 64;
+    const int64_t total = aks_sell_plan_size(indptr, n_rows);
+    if (total < 0) return (int)total;
+    if (total > 0 && (!col_out || !val_out)) return fail(AKS_ERR_ARG, "null output array");
+    const size_t vw = values_complex ? 2 : 1;
+    const double *vin = static_cast<const double *>(values);
+    double *vout = static_cast<double *>(val_out);
+    for (int64_t i = 0; i < total; ++i) col_out[i] = -1;
+    for (int64_t i = 0; i < total * (int64_t)vw; ++i) vout[i] = 0.0;
+    int64_t p = 0;
+    for (int64_t s = 0; s < n_slices; ++s) {
+        slice_ptr_out[s] = p;
+        int64_t w = 0;
+        for (int64_t r = s * 64; r < std::min(n_rows, s * 64 + 64); ++r) {
+            const int64_t len = indptr[r + 1] - indptr[r];
+            w = std::max(w, len);
+            for (int64_t k = 0; k < len; ++k) {
+                const int64_t q = p + k * 64 + (r - s * 64), src = indptr[r] + k;
+                col_out[q] = indices[src];
+                for (size_t c = 0; c < vw; ++c) vout[q * vw + c] = vin[src * vw + c];
+            }
+        }
+        p += 64 * w;
+    }
+    slice_ptr_out[n_slices] = p;
+    return AKS_OK;
+}
+
+int aks_sell_spmv(const aks_sell_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate, const void *d_ws,
+                  void *stream) {
+    int rc = check_sell(A, d_x, d_y);
+    if (rc != AKS_OK) return rc;
+    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const c128 *x = reinterpret_cast<const c128 *>(d_x);
+    c128 *y = reinterpret_cast<c128 *>(d_y);
+    return A->values_complex ? launch_sell<c128, c128>(A, x, y, accumulate, ctrl, s)
+                             : launch_sell<double, c128>(A, x, y, accumulate, ctrl, s);
+}
+
+int aks_sell_spmv_real(const aks_sell_matrix *A, const double *d_x, double *d_y, int32_t accumulate, const void *d_ws,
+                       void *stream) {
+    int rc = check_sell(A, d_x, d_y);
+    if (rc != AKS_OK) return rc;
+    if (A->values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
+    return launch_sell<double, double>(A, d_x, d_y, accumulate, static_cast<const aks_ctrl *>(d_ws),
+                                       static_cast<hipStream_t>(stream));
 }
 
 // ---- communicator: RCCL + a side stream for the ghost exchange ------------------------------

@@ -198,6 +198,32 @@ void aks_pb_plan_destroy(void *plan);
 int aks_pb_spmv(const aks_pb_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate,
                 const void *d_ws, void *stream);
 
+/* ---- sliced SpMV (same operation, for matrices with short rows of similar length: stencils, bands) ----
+ * One lane per row.  A SLICE is 64 consecutive rows stored entry-major -- entry k of the 64 rows, then
+ * entry k + 1, ... -- padded to the slice's longest row with column -1 (value 0): the value and column
+ * loads of a wave are contiguous, a row is summed in column order in registers, and the workgroups of
+ * one XCD take a contiguous eighth of the slices so that x entries shared by rows a grid line or plane
+ * apart are fetched into one L2.  Worth it while the padding is small (the host layer uses it up to
+ * 1.25 x nnz, by measurement against the CSR-stream kernel).
+ *   slice_ptr[s] = first slot of slice s (a multiple of 64), slice_ptr[n_slices] = nnz_pad;
+ *   slot slice_ptr[s] + k * 64 + (row - 64 s) holds entry k of `row`.                                  */
+typedef struct aks_sell_matrix {
+    int64_t n_rows, n_cols, nnz, nnz_pad, n_slices;     /* n_slices = ceil(n_rows / 64)                  */
+    int32_t values_complex, pad_;
+    const int64_t *d_slice_ptr;                         /* n_slices + 1                                  */
+    const int32_t *d_col;                               /* nnz_pad column indices, -1 = padding          */
+    const void *d_val;                                  /* nnz_pad values (f64 or c128)                  */
+} aks_sell_matrix;
+/* Host helpers (pure functions of a canonical CSR matrix, host pointers).  aks_sell_plan_size returns
+ * nnz_pad (or a negative error); aks_sell_plan_fill writes the three arrays (lengths n_slices + 1,
+ * nnz_pad, nnz_pad). */
+int64_t aks_sell_plan_size(const int32_t *indptr, int64_t n_rows);
+int aks_sell_plan_fill(const int32_t *indptr, const int32_t *indices, const void *values, int32_t values_complex,
+                       int64_t n_rows, int64_t *slice_ptr_out, int32_t *col_out, void *val_out);
+/* y = A x or y += A x with the sliced form (one launch on `stream`); _real: float64 vectors. */
+int aks_sell_spmv(const aks_sell_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate,
+                  const void *d_ws, void *stream);
+
 /* ---- orthogonalisation: replaces dgks_gs (ortho.py:56-107) ---------------
  * Stage entry points, in call order.  Between stages a multi-GPU host
  * all-reduces the named slot over the row shards (RCCL); with one GPU the
@@ -246,6 +272,7 @@ typedef struct aks_csr_block {
     int64_t n_tiles;
     int32_t values_complex, lanes_per_row;
     const aks_pb_matrix *pb;            /* not NULL: apply the block with the tile-binned form     */
+    const aks_sell_matrix *sell;        /* not NULL: apply the block with the sliced form          */
 } aks_csr_block;
 
 typedef struct aks_shard {
@@ -315,6 +342,9 @@ int aks_csr_spmv_real(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_
 /* Binned form; A->d_prod (nnz complex128) is used as nnz float64. */
 int aks_pb_spmv_real(const aks_pb_matrix *A, const double *d_x, double *d_y, int32_t accumulate,
                      const void *d_ws, void *stream);
+/* Sliced form (real matrix values). */
+int aks_sell_spmv_real(const aks_sell_matrix *A, const double *d_x, double *d_y, int32_t accumulate,
+                       const void *d_ws, void *stream);
 int aks_gather_f64(int64_t count, const int32_t *d_idx, const double *d_src, double *d_dst, void *stream);
 
 /* Real-packed expansion: aks_arnoldi_expand(..., flags | AKS_EXPAND_REAL_PACKED): diag.n_rows is the matrix

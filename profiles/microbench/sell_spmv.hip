@@ -1,0 +1,170 @@
+// Micro-benchmark (gfx950): a sliced-ELL SpMV (one lane per row, a slice of 64 rows stored entry-major so that
+// the value / column loads of a wave are contiguous) on the structured matrices of BASELINE.json -- the question
+// being whether such a form beats the library's CSR-stream kernel (k_spmv: 0.41 ms on the 3-D Laplacian
+// n = 16.2M, 0.161 ms on the Markov matrix n = 10M, 0.157 ms on the banded stand-in) by enough to be worth a
+// third SpMV form.  y = A x, A real (f64), x / y complex128.
+//   hipcc --offload-arch=gfx950 -O3 -o profiles/microbench/sell_spmv profiles/microbench/sell_spmv.hip
+//   ./profiles/microbench/sell_spmv
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+typedef double2 c128;
+
+template <int U, bool XCD, bool NT = false>
+__global__ __launch_bounds__(256) void k_sell(int64_t n_rows, const int64_t *__restrict__ slice_ptr,
+                                             const int32_t *__restrict__ col, const double *__restrict__ val,
+                                             const c128 *__restrict__ x, c128 *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    // XCD: workgroups with the same blockIdx % 8 share an XCD (observed placement); give each XCD a contiguous
+    // eighth of the rows so that the x entries its rows share are fetched into ONE L2, not into all eight
+    const int64_t per = (gridDim.x + 7) / 8;
+    const int64_t wg = XCD ? (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    const int64_t slice = wg * 4 + (threadIdx.x >> 6);
+    const int64_t row = slice * 64 + lane;
+    if (slice * 64 >= n_rows) return;
+    const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
+    const int W = (int)((p1 - p0) >> 6);
+    double sr = 0.0, si = 0.0;
+    const int32_t *c = col + p0 + lane;
+    const double *v = val + p0 + lane;
+    int k = 0;
+    for (; k + U <= W; k += U) {
+        int32_t cc[U];
+        double vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cc[u] = NT ? __builtin_nontemporal_load(&c[(int64_t)(k + u) * 64]) : c[(int64_t)(k + u) * 64];
+            vv[u] = NT ? __builtin_nontemporal_load(&v[(int64_t)(k + u) * 64]) : v[(int64_t)(k + u) * 64];
+        }
+        c128 xx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xx[u] = cc[u] >= 0 ? x[cc[u]] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { sr = fma(vv[u], xx[u].x, sr); si = fma(vv[u], xx[u].y, si); }
+    }
+    for (; k < W; ++k) {
+        const int32_t cc = c[(int64_t)k * 64];
+        const double vv = v[(int64_t)k * 64];
+        const c128 xx = cc >= 0 ? x[cc] : make_double2(0.0, 0.0);
+        sr = fma(vv, xx.x, sr);
+        si = fma(vv, xx.y, si);
+    }
+    if (row < n_rows) y[row] = make_double2(sr, si);
+}
+
+struct Csr { int64_t n; std::vector<int64_t> ptr; std::vector<int32_t> idx; std::vector<double> val; };
+
+static Csr laplace3d(int nx, int ny, int nz) {
+    Csr A; A.n = (int64_t)nx * ny * nz; A.ptr.assign(A.n + 1, 0);
+    A.idx.reserve(7 * A.n); A.val.reserve(7 * A.n);
+    for (int z = 0; z < nz; ++z) for (int yy = 0; yy < ny; ++yy) for (int xx = 0; xx < nx; ++xx) {
+        const int64_t r = ((int64_t)z * ny + yy) * nx + xx;
+        auto add = [&](int64_t c, double v) { A.idx.push_back((int32_t)c); A.val.push_back(v); };
+        if (z > 0) add(r - (int64_t)nx * ny, -1.0);
+        if (yy > 0) add(r - nx, -1.0);
+        if (xx > 0) add(r - 1, -1.0);
+        add(r, 6.0);
+        if (xx + 1 < nx) add(r + 1, -1.0);
+        if (yy + 1 < ny) add(r + nx, -1.0);
+        if (z + 1 < nz) add(r + (int64_t)nx * ny, -1.0);
+        A.ptr[r + 1] = (int64_t)A.idx.size();
+    }
+    return A;
+}
+
+static Csr banded(int64_t n, int per_row) {          // like bench.py --workload banded: per_row entries around the diagonal
+    Csr A; A.n = n; A.ptr.assign(n + 1, 0);
+    for (int64_t r = 0; r < n; ++r) {
+        for (int j = 0; j < per_row; ++j) {
+            const int64_t c = r + (int64_t)(j - per_row / 2) * 3;
+            if (c >= 0 && c < n) { A.idx.push_back((int32_t)c); A.val.push_back(1.0 + 0.01 * j); }
+        }
+        A.ptr[r + 1] = (int64_t)A.idx.size();
+    }
+    return A;
+}
+
+static Csr markov_like(int64_t n) {                  // 2-4 entries per row at +-1 and +-~sqrt(2n) (mark()'s pattern)
+    Csr A; A.n = n; A.ptr.assign(n + 1, 0);
+    const int64_t w = (int64_t)std::sqrt(2.0 * (double)n);
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t cs[4] = {r - w, r - 1, r + 1, r + w};
+        for (int j = 0; j < 4; ++j)
+            if (cs[j] >= 0 && cs[j] < n && ((r + j) % 7 != 0)) { A.idx.push_back((int32_t)cs[j]); A.val.push_back(0.25); }
+        A.ptr[r + 1] = (int64_t)A.idx.size();
+    }
+    return A;
+}
+
+template <typename T> static T *upload(const std::vector<T> &v) {
+    T *d; CK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    CK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+static void run(const char *name, const Csr &A) {
+    const int64_t n = A.n, nnz = A.ptr[n], ns = (n + 63) / 64;
+    std::vector<int64_t> sp(ns + 1, 0);
+    for (int64_t s = 0; s < ns; ++s) {
+        int64_t w = 0;
+        for (int64_t r = s * 64; r < std::min(n, (s + 1) * 64); ++r) w = std::max(w, A.ptr[r + 1] - A.ptr[r]);
+        sp[s + 1] = sp[s] + w * 64;
+    }
+    std::vector<int32_t> col(sp[ns], -1);
+    std::vector<double> val(sp[ns], 0.0);
+    for (int64_t r = 0; r < n; ++r)
+        for (int64_t k = A.ptr[r]; k < A.ptr[r + 1]; ++k) {
+            const int64_t q = sp[r / 64] + (k - A.ptr[r]) * 64 + (r % 64);
+            col[q] = A.idx[k]; val[q] = A.val[k];
+        }
+    std::vector<double> hx(2 * n);
+    for (int64_t i = 0; i < n; ++i) { hx[2 * i] = std::sin(0.001 * (double)(i % 100003)) + 0.5; hx[2 * i + 1] = std::cos(0.003 * (double)(i % 70001)); }
+    int64_t *d_sp = upload(sp); int32_t *d_col = upload(col); double *d_val = upload(val);
+    c128 *x = (c128 *)upload(hx), *y; CK(hipMalloc(&y, n * 16));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double alg = 12.0 * nnz + 36.0 * n + 4;
+    printf("%s: n = %lld, nnz = %lld, padded %lld (x %.3f)\n", name, (long long)n, (long long)nnz, (long long)sp[ns], (double)sp[ns] / nnz);
+    auto time_it = [&](auto launch, const char *what) {
+        for (int i = 0; i < 3; ++i) launch();
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 20; ++i) launch();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+        printf("   %-10s %.4f ms  %.3f TB/s algorithmic (%.3f of 8 TB/s)\n", what, ms, alg / ms / 1e9, alg / ms / 8e9);
+    };
+    const unsigned grid = (unsigned)((ns + 3) / 4);
+    const unsigned grid8 = (grid + 7) / 8 * 8;
+    time_it([&] { hipLaunchKernelGGL((k_sell<2, false>), dim3(grid), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "unroll 2");
+    time_it([&] { hipLaunchKernelGGL((k_sell<4, false>), dim3(grid), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "unroll 4");
+    time_it([&] { hipLaunchKernelGGL((k_sell<2, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "u2 + XCD");
+    time_it([&] { hipLaunchKernelGGL((k_sell<4, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "u4 + XCD");
+    time_it([&] { hipLaunchKernelGGL((k_sell<4, true, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "u4 XCD nt");
+    time_it([&] { hipLaunchKernelGGL((k_sell<7, true, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "u7 XCD nt");
+    time_it([&] { hipLaunchKernelGGL((k_sell<8, true, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "u8 XCD nt");
+    // check against the host CSR product on a sample of rows
+    std::vector<double> hy(2 * n);
+    CK(hipMemcpy(hy.data(), y, n * 16, hipMemcpyDeviceToHost));
+    double err = 0;
+    for (int64_t r = 0; r < n; r += 9973) {
+        double sr = 0, si = 0;
+        for (int64_t k = A.ptr[r]; k < A.ptr[r + 1]; ++k) { sr = std::fma(A.val[k], hx[2 * A.idx[k]], sr); si = std::fma(A.val[k], hx[2 * A.idx[k] + 1], si); }
+        err = std::max(err, std::max(std::fabs(sr - hy[2 * r]), std::fabs(si - hy[2 * r + 1])));
+    }
+    printf("   max error on sampled rows %.3e\n", err);
+    CK(hipFree(d_sp)); CK(hipFree(d_col)); CK(hipFree(d_val)); CK(hipFree(x)); CK(hipFree(y));
+}
+
+int main() {
+    run("3-D Laplace 253x254x255", laplace3d(253, 254, 255));
+    run("banded 35 per row, n = 1.5M", banded(1500000, 35));
+    run("Markov-like, n = 10M", markov_like(10000000));
+    run("2-D-like 5-point, n = 1M (as a 1000x1x1001 3-D grid)", laplace3d(1000, 1, 1001));
+    return 0;
+}

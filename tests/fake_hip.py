@@ -35,7 +35,8 @@ class FakeHip:
     def __init__(self, real):
         self._real = real
         for name in ("aks_last_error", "aks_abi_version", "aks_workspace_layout", "aks_csr_plan_tiles",
-                     "aks_pb_params", "aks_pb_plan_create", "aks_pb_plan_export", "aks_pb_plan_destroy"):
+                     "aks_pb_params", "aks_pb_plan_create", "aks_pb_plan_export", "aks_pb_plan_destroy",
+                     "aks_sell_plan_size", "aks_sell_plan_fill"):
             setattr(self, name, getattr(real, name))
         self.calls = []
 
@@ -160,6 +161,44 @@ class FakeHip:
         yv[:] = yv + r if acc else r
         return 0
 
+    def _sell_replay(self, A, x, y, acc, vec_dtype):
+        """The sliced form replayed with NumPy on the planned arrays: a row is the sum, in slot order, of its
+        non-padding slots slice_ptr[s] + k * 64 + lane."""
+        d = self._deref(A)
+        n_rows, n_cols, nnz, npad, ns = int(d.n_rows), int(d.n_cols), int(d.nnz), int(d.nnz_pad), int(d.n_slices)
+        assert ns == -(-n_rows // 64) and npad % 64 == 0
+        sp = _view(d.d_slice_ptr, np.int64, ns + 1)
+        assert sp[0] == 0 and sp[-1] == npad and np.all(np.diff(sp) % 64 == 0) and np.all(np.diff(sp) >= 0)
+        yv = _view(y, vec_dtype, n_rows)
+        out = np.zeros(n_rows, vec_dtype)
+        if npad:
+            col = _view(d.d_col, np.int32, npad).astype(np.int64)
+            val = _view(d.d_val, C128 if d.values_complex else np.float64, npad)
+            assert int((col >= 0).sum()) == nnz and col.max() < n_cols and np.all(val[col < 0] == 0)
+            slot = np.arange(npad)
+            sl = np.searchsorted(sp, slot, side="right") - 1
+            row = sl * 64 + (slot - sp[sl]) % 64
+            live = col >= 0
+            assert row[live].max() < n_rows
+            xv = _view(x, vec_dtype, n_cols)
+            np.add.at(out, row[live], val[live] * xv[col[live]])
+        yv[:] = yv + out if acc else out
+
+    def aks_sell_spmv(self, A, x, y, acc, ws, stream):
+        self.calls.append("sell_spmv")
+        if _addr(ws) and _view(ws, np.int32, 1)[0]:
+            return 0
+        self._sell_replay(A, x, y, acc, C128)
+        return 0
+
+    def aks_sell_spmv_real(self, A, x, y, acc, ws, stream):
+        self.calls.append("sell_spmv_real")
+        if _addr(ws) and _view(ws, np.int32, 1)[0]:
+            return 0
+        assert not self._deref(A).values_complex
+        self._sell_replay(A, x, y, acc, np.float64)
+        return 0
+
     def aks_pb_spmv(self, A, x, y, acc, ws, stream):
         self.calls.append("pb_spmv")
         if _addr(ws) and _view(ws, np.int32, 1)[0]:
@@ -244,7 +283,9 @@ class FakeHip:
         if B.n_rows <= 0:
             return
         pb = B.pb if bool(B.pb) else None
-        if real and pb is not None:
+        if bool(B.sell):
+            (self.aks_sell_spmv_real if real else self.aks_sell_spmv)(B.sell, x, y, acc, ws, stream)
+        elif real and pb is not None:
             self.aks_pb_spmv_real(pb, x, y, acc, ws, stream)
         elif real:
             self.aks_csr_spmv_real(B.n_rows, B.d_indptr, B.d_indices, B.d_values, B.d_tiles, B.n_tiles,

@@ -154,25 +154,86 @@ def test_spmv_binned_form(amd, kind):
         np.testing.assert_array_equal(dy2.cpu().numpy(), first)
 
 
+@pytest.mark.parametrize("kind", ["ragged_real", "ragged_complex", "laplace2d", "laplace3d", "markov", "wide", "tall", "banded"])
+def test_spmv_sliced_form(amd, kind):
+    """The sliced kernel (aks_sell_spmv: a lane per row, slices of 64 rows stored entry-major, padded with
+    column -1) against the oracle: ragged last slice, empty rows, a long row, complex values, non-square blocks,
+    accumulate, real vectors; run-to-run bitwise reproducible (a row is summed in column order in registers)."""
+    import torch
+    from arnoldi_amd import matrices
+    from arnoldi_amd.device import DeviceCSR
+
+    rng = np.random.default_rng(17)
+    if kind.startswith("ragged"):
+        A = _ragged_matrix(3000, 5, kind.endswith("complex"))
+    elif kind == "laplace2d":
+        A = matrices.laplace2d(300, 311)
+    elif kind == "laplace3d":
+        A = matrices.laplace3d(37, 41, 43)
+    elif kind == "markov":
+        A = matrices.mark(300)
+    elif kind == "wide":
+        A = sp.random(2500, 400_000, density=2e-5, random_state=np.random.RandomState(1), format="csr")
+    elif kind == "tall":
+        A = sp.random(150_001, 700, density=4e-3, random_state=np.random.RandomState(2), format="csr")
+    else:
+        n = 100_003
+        A = sp.diags([rng.standard_normal(n - abs(o)) for o in range(-17, 18)], list(range(-17, 18)), format="csr")
+    A = sp.csr_matrix(A)
+    n_rows, n_cols = A.shape
+    x = (rng.standard_normal(n_cols) + 1j * rng.standard_normal(n_cols)).astype(C128)
+    x[0] = np.inf          # padding slots must not read x (0 * inf = nan): column 0 is used by few rows only
+    y0 = (rng.standard_normal(n_rows) + 1j * rng.standard_normal(n_rows)).astype(C128)
+    dA = DeviceCSR(A)
+    assert dA.autotune(force="sliced") == "sliced" and dA.sliced is not None and dA.binned is None
+    dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y0).cuda()
+    dA.spmv(dx, dy)
+    first = dy.cpu().numpy().copy()
+    uses0 = np.zeros(n_rows, bool)
+    uses0[np.unique(A.tocoo().row[A.tocoo().col == 0])] = True
+    xs = x.copy()
+    xs[0] = 1.0
+    ref = oracle.csr_matvec(A, xs)
+    assert np.all(np.isfinite(first[~uses0])) and _relerr(first[~uses0], ref[~uses0]) < RTOL
+    assert np.all(first[np.diff(A.indptr) == 0] == 0)
+    dx = torch.from_numpy(xs).cuda()
+    dA.spmv(dx, dy)
+    first = dy.cpu().numpy().copy()
+    assert _relerr(first, ref) < RTOL
+    dA.spmv(dx, dy, accumulate=True)
+    assert _relerr(dy.cpu().numpy(), 2 * ref) < RTOL
+    dy2 = torch.empty_like(dy)
+    dA.spmv(dx, dy2)
+    np.testing.assert_array_equal(dy2.cpu().numpy(), first)
+    if not np.iscomplexobj(A.data):
+        xr = rng.standard_normal(n_cols)
+        dxr, dyr = torch.from_numpy(xr).cuda(), torch.zeros(n_rows, dtype=torch.float64, device="cuda")
+        dA.spmv(dxr, dyr, real=True)
+        assert _relerr(dyr.cpu().numpy(), A @ xr) < RTOL
+
+
 def test_spmv_autotune_picks_by_measurement(amd):
     from arnoldi_amd import matrices
     from arnoldi_amd.device import DeviceCSR
 
     lap = DeviceCSR(matrices.laplace2d(1500, 1501))
-    assert lap.autotune() == "csr" and lap.binned is None          # stencil: not even a candidate
+    choice = lap.autotune()                                        # stencil: no candidate for the binned form,
+    assert lap.binned is None and set(lap.tune_ms) == {"csr", "sliced"}    # rows of equal length: sliced is timed
+    assert (choice == "sliced") == (lap.tune_ms["sliced"] < 0.95 * lap.tune_ms["csr"]) and choice in ("csr", "sliced")
+    assert (lap.sliced is not None) == (choice == "sliced")
     rnd = DeviceCSR(matrices.random_csr(4_000_000, 5, 3))
-    choice = rnd.autotune()
-    assert set(rnd.tune_ms) == {"csr", "binned"} and choice in ("csr", "binned")
+    choice = rnd.autotune()                                        # gathers without locality: slices are not tried
+    assert set(rnd.tune_ms) == {"csr", "binned"} and choice in ("csr", "binned") and rnd.sliced is None
     assert (choice == "binned") == (rnd.tune_ms["binned"] < 0.9 * rnd.tune_ms["csr"])
 
 
 def test_partial_schur_with_binned_spmv(amd):
-    """Same solve through both SpMV forms: identical restart counts and eigenvalues."""
+    """Same solve through the three SpMV forms: identical restart counts and eigenvalues."""
     from arnoldi_amd.engine import CsrOperator
 
     g8 = load_golden("g8_random_planted")
     A = _planted_like_golden(int(g8["n"]))
-    for form in ("csr", "binned"):
+    for form in ("csr", "binned", "sliced"):
         op = CsrOperator(A, spmv_form=form)
         assert op.spmv_form == form
         _solve_and_compare(amd, op, g8, "s0_", 0, nev=5, max_dim=20, sort_function=oracle.arg_largest_magnitude,

@@ -483,6 +483,70 @@ def test_binned_plan_represents_the_matrix(fake, shape, complex_vals):
     assert "pb_spmv" in fake.calls and not np.array_equal(y0, y.numpy())
 
 
+@pytest.mark.parametrize("shape,complex_vals", [((1000, 1000), False), ((130, 4000), True), ((4097, 300), False)])
+def test_sliced_plan_represents_the_matrix(fake, shape, complex_vals):
+    """``aks_sell_plan_size`` / ``aks_sell_plan_fill`` (host code of the library) and the NumPy replay of the sliced
+    form: slices of 64 rows stored entry-major, padded with column -1; ragged last slice, empty rows, a long row."""
+    import torch
+    from arnoldi_amd.device import DeviceCSR
+
+    rng = np.random.default_rng(shape[1])
+    n_rows, n_cols = shape
+    nnz = 5 * n_rows
+    rows = rng.integers(0, n_rows, nnz)
+    rows[rows % 11 == 0] = 3                      # empty rows + one long row
+    cols = rng.integers(0, n_cols, nnz)
+    vals = rng.standard_normal(nnz) + (1j * rng.standard_normal(nnz) if complex_vals else 0)
+    A = sp.csr_matrix((vals, (rows, cols)), shape=shape)
+    A.sum_duplicates()
+    dA = DeviceCSR(A)
+    lens = np.diff(A.indptr)
+    want = sum(64 * int(lens[r0:r0 + 64].max()) for r0 in range(0, n_rows, 64))
+    assert abs(dA.sliced_padding() * A.nnz - want) < 0.5
+    b = dA.build_sliced()
+    d = b.desc
+    assert d.nnz_pad == want and d.n_slices == -(-n_rows // 64) and d.nnz == A.nnz
+    slice_ptr, col, val = b.slice_ptr.numpy(), b.col.numpy(), b.val.numpy()
+    for r in (0, 3, 63, 64, n_rows - 1):           # slot slice_ptr[s] + k * 64 + lane holds entry k of the row
+        s_, lane = divmod(r, 64)
+        k = np.arange(lens[r])
+        assert np.array_equal(col[slice_ptr[s_] + k * 64 + lane], A.indices[A.indptr[r]:A.indptr[r + 1]])
+        assert np.array_equal(val[slice_ptr[s_] + k * 64 + lane], A.data[A.indptr[r]:A.indptr[r + 1]])
+        width = (slice_ptr[s_ + 1] - slice_ptr[s_]) // 64
+        assert np.all(col[slice_ptr[s_] + np.arange(lens[r], width) * 64 + lane] == -1)
+    x = torch.from_numpy((rng.standard_normal(n_cols) + 1j * rng.standard_normal(n_cols)).astype(C128))
+    y = torch.from_numpy((rng.standard_normal(n_rows) + 0j).astype(C128))
+    dA.form = "sliced"
+    dA.spmv(x, y)
+    np.testing.assert_allclose(y.numpy(), A @ x.numpy(), rtol=1e-12, atol=1e-12)
+    dA.spmv(x, y, accumulate=True)
+    np.testing.assert_allclose(y.numpy(), 2 * (A @ x.numpy()), rtol=1e-12, atol=1e-12)
+    assert fake.calls.count("sell_spmv") == 2
+    blk = dA.block()
+    assert bool(blk.sell) and not bool(blk.pb)
+    if not complex_vals:
+        xr, yr = torch.from_numpy(rng.standard_normal(n_cols)), torch.zeros(n_rows, dtype=torch.float64)
+        dA.spmv(xr, yr, real=True)
+        np.testing.assert_allclose(yr.numpy(), A @ xr.numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_solver_runs_on_the_sliced_form(fake):
+    """``spmv_form="sliced"``: the operator hands aks_arnoldi_expand a block whose ``sell`` pointer is set, and the
+    solve matches the CSR-stream solve."""
+    import arnoldi_amd
+    from arnoldi_amd.engine import CsrOperator
+    from arnoldi_amd.matrices import mark
+    from arnoldi_amd.utils import arg_largest_real
+
+    A = mark(12)
+    ref = arnoldi_amd.partial_schur(A, 3, max_dim=12, sort_function=arg_largest_real, stopping_criterion=1e-9)
+    op = CsrOperator(A, spmv_form="sliced")
+    assert op.spmv_form == "sliced" and bool(op.shard.diag.sell)
+    Q, T, hist = arnoldi_amd.partial_schur(op, 3, max_dim=12, sort_function=arg_largest_real, stopping_criterion=1e-9)
+    np.testing.assert_allclose(np.sort_complex(np.diag(T)), np.sort_complex(np.diag(ref[1])), rtol=1e-9, atol=1e-12)
+    assert any(c.startswith("sell_spmv") for c in fake.calls)
+
+
 def test_binned_plan_refuses_what_it_cannot_index():
     """Too many (sub-slab, row block) tiles: the planner reports it through a NULL plan + aks_last_error and
     ``DeviceCSR.autotune`` keeps the CSR-stream kernel."""
