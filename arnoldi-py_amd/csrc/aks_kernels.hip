@@ -11,6 +11,9 @@
 //   k_pb_phase1/2   the same operator for matrices without column locality: products are formed
 //                   sub-slab by sub-slab (8192 x entries staged in LDS) and written sequentially,
 //                   then summed per 8192-row block in LDS (levels + barriers keep the order fixed).
+//   k_sell<VT,XT>   the same operator for matrices with column locality and rows of similar length
+//                   (stencils, bands): a lane per row, 64-row slices stored entry-major, rows summed in
+//                   registers, XCD-contiguous slice order.
 //   k_proj<NC>      tall-skinny  V[:, c0:c0+NC]^H w  with one lane per row and NC
 //                   complex accumulators per lane (exact NC: no masked loads), plus
 //                   ||w||^2.                            (ortho.py:92-94, 102)
