@@ -232,6 +232,9 @@ __global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *_
 
 // ------------------------------------------------------------------ fused update + re-projection
 // w[i] -= sum_c V[i,c] h[c];  partial[.., c] = sum conj(V[i,c]) w'[i];  partial[.., NC] = sum |w'[i]|^2
+#ifndef AKS_UPD_HS_LDS_FROM
+#define AKS_UPD_HS_LDS_FROM 18   // widths above this re-read the coefficients from LDS per tile (see the loop)
+#endif
 template <int NC>
 __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__restrict__ V, int64_t ldv,
                                                       c128 *__restrict__ w, const c128 *__restrict__ h,
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__
         // Keeps the NC coefficients in LDS (re-read per tile as broadcast ds_reads) instead of letting
         // the compiler hoist them into 4 NC VGPRs for the whole loop: that is the difference between
         // one and two waves per SIMD for NC = 20..28 (A/B at n = 1M, J = 28: 0.147 -> 0.102 ms).
-        if constexpr (NC > 16) asm volatile("" ::: "memory");
+        if constexpr (NC > AKS_UPD_HS_LDS_FROM) asm volatile("" ::: "memory");
         c128 wv = w[i];
         c128 v[NC];
 #pragma unroll
