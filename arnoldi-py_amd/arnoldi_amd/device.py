@@ -7,7 +7,6 @@ of ``libarnoldi_hip.so`` (``_hip.py``); nothing here computes on the CPU.
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 import scipy.sparse as sp
