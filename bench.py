@@ -620,7 +620,7 @@ def run_rank(args, argv):
 
         gc.collect()
         torch.cuda.empty_cache()
-        base = ["--steps", str(min(args.steps, 5)), "--warmup", "1", "--leg", "measure"]
+        base = ["--steps", str(min(args.steps, 5)), "--warmup", "2", "--leg", "measure"]
         if args.workload == "random" and args.arithmetic == "complex":
             if not args.no_real_leg:
                 leg = run_child(["--rows", str(args.n), "--per-row", str(args.per_row), "--nev", str(args.nev),
