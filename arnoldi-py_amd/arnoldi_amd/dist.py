@@ -119,23 +119,50 @@ class Comm:
 
         if self.backend != "nccl" or os.environ.get("AKS_DIST_PATH", "native") == "python":
             return None
-        if self._native is None:
+        if self._native is None and not getattr(self, "_native_refused", False):
             import ctypes as C
+            import warnings
 
             from . import _hip
 
             lib = _hip.load()
             ident = (C.c_char * _hip.COMM_ID_BYTES)()
+            box = [None]
             if self.rank == 0:
-                _hip.check(lib.aks_comm_unique_id(C.cast(ident, C.c_void_p)), "aks_comm_unique_id")
-            box = [bytes(ident)]
+                try:
+                    _hip.check(lib.aks_comm_unique_id(C.cast(ident, C.c_void_p)), "aks_comm_unique_id")
+                    box = [bytes(ident)]
+                except _hip.HipLibraryError as e:        # tell the others instead of leaving them in the broadcast
+                    warnings.warn(f"RCCL communicator not available ({e}); collectives stay with torch.distributed")
             if self.size > 1:
                 dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                            group=self.group)
-            handle = C.c_void_p()
-            ident = (C.c_char * _hip.COMM_ID_BYTES).from_buffer_copy(box[0])
-            _hip.check(lib.aks_comm_create(C.cast(ident, C.c_void_p), self.rank, self.size, C.byref(handle)),
-                       "aks_comm_create")
+            handle, err = C.c_void_p(), None
+            if box[0] is not None:
+                ident = (C.c_char * _hip.COMM_ID_BYTES).from_buffer_copy(box[0])
+                try:
+                    _hip.check(lib.aks_comm_create(C.cast(ident, C.c_void_p), self.rank, self.size, C.byref(handle)),
+                               "aks_comm_create")
+                    # prove the communicator before relying on it: sum of (rank + 1) over the ranks
+                    probe = torch.full((2,), float(self.rank + 1), dtype=torch.float64, device=self._wire_device())
+                    _hip.check(lib.aks_comm_allreduce_sum(handle, C.c_void_p(probe.data_ptr()), 2,
+                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                               "aks_comm_allreduce_sum")
+                    if abs(float(probe[0].item()) - self.size * (self.size + 1) / 2) > 1e-9:
+                        raise _hip.HipLibraryError(f"all-reduce self-test gave {probe.tolist()}")
+                except _hip.HipLibraryError as e:
+                    err = e
+            ok = torch.tensor([1 if (box[0] is not None and err is None) else 0], dtype=torch.int32,
+                              device=self._wire_device())
+            if self.size > 1:                            # all ranks take the same path
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 0:
+                if handle:
+                    lib.aks_comm_destroy(handle)
+                if err is not None:
+                    warnings.warn(f"RCCL communicator refused ({err}); collectives stay with torch.distributed")
+                self._native_refused = True
+                return None
             self._native = handle
         return self._native
 
