@@ -154,6 +154,50 @@ def test_spmv_binned_form(amd, kind):
         np.testing.assert_array_equal(dy2.cpu().numpy(), first)
 
 
+@pytest.mark.parametrize("kind", ["many_row_blocks", "empty_row_blocks", "dense_tiles"])
+def test_spmv_binned_schedule_edges(amd, kind):
+    """Shapes that stress the phase-2 schedule of the binned form: more row blocks than chunks (257 = 256 + 1: the
+    chunk-interleaved order and its remainder), row blocks without any entry (they still own a round and must come
+    out as zeros), tiles far larger than a wave-load (many wave-loads cut from one tile, every lane filled)."""
+    import torch
+    from arnoldi_amd.device import DeviceCSR
+
+    rng = np.random.default_rng(23)
+    if kind == "many_row_blocks":
+        n_rows, n_cols = 256 * 8192 + 4000, 30_000
+        rows = rng.integers(0, n_rows, 3_000_000)
+        cols = rng.integers(0, n_cols, rows.size)
+    elif kind == "empty_row_blocks":
+        n_rows, n_cols = 6 * 8192 + 17, 50_000
+        rows = rng.integers(0, n_rows, 400_000)
+        rows = rows[(rows < 8192) | (rows >= 3 * 8192)]               # row blocks 1 and 2 stay empty
+        rows = rows[rows < 5 * 8192]                                  # ... and so does the last one
+        cols = rng.integers(0, n_cols, rows.size)
+    else:
+        n_rows, n_cols = 9000, 9000
+        rows = rng.integers(0, n_rows, 2_000_000)
+        cols = rng.integers(0, n_cols, rows.size)
+    A = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(n_rows, n_cols))
+    A.sum_duplicates()
+    x = (rng.standard_normal(n_cols) + 1j * rng.standard_normal(n_cols)).astype(C128)
+    y0 = (rng.standard_normal(n_rows) + 1j * rng.standard_normal(n_rows)).astype(C128)
+    dA = DeviceCSR(A)
+    assert dA.autotune(force="binned") == "binned"
+    if kind == "dense_tiles":
+        assert dA.binned.lanes_per_load > 63
+    dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y0).cuda()
+    dA.spmv(dx, dy)
+    first = dy.cpu().numpy().copy()
+    ref = oracle.csr_matvec(A, x)
+    assert _relerr(first, ref) < RTOL
+    assert np.all(first[np.diff(A.indptr) == 0] == 0)
+    dA.spmv(dx, dy, accumulate=True)
+    assert _relerr(dy.cpu().numpy(), 2 * ref) < RTOL
+    dy2 = torch.empty_like(dy)
+    dA.spmv(dx, dy2)
+    np.testing.assert_array_equal(dy2.cpu().numpy(), first)
+
+
 @pytest.mark.parametrize("kind", ["ragged_real", "ragged_complex", "laplace2d", "laplace3d", "markov", "wide", "tall", "banded"])
 def test_spmv_sliced_form(amd, kind):
     """The sliced kernel (aks_sell_spmv: a lane per row, slices of 64 rows stored entry-major, padded with
