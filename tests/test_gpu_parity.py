@@ -256,6 +256,44 @@ def test_spmv_sliced_form(amd, kind):
         assert _relerr(dyr.cpu().numpy(), A @ xr) < RTOL
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_spmv_forms_agree_on_random_shapes(amd, seed):
+    """Differential test of the three SpMV forms on randomly drawn shapes, densities and row-length
+    distributions (uniform, geometric, a few hub rows, blocks of empty rows): CSR-stream vs tile-binned vs
+    sliced, against the oracle, complex or real values, accumulate."""
+    import torch
+    from arnoldi_amd.device import DeviceCSR
+
+    rng = np.random.default_rng(1000 + seed)
+    n_rows = int(rng.integers(1, 60_000))
+    n_cols = int(rng.integers(1, 60_000))
+    per_row = float(rng.choice([0.3, 1.0, 3.0, 9.0]))
+    nnz = max(1, int(per_row * n_rows))
+    if rng.random() < 0.5:
+        rows = rng.integers(0, n_rows, nnz)
+    else:
+        rows = np.minimum(rng.geometric(min(1.0, 8.0 / n_rows), nnz) - 1, n_rows - 1)         # most entries in the first rows
+    if rng.random() < 0.5:
+        rows[rng.random(nnz) < 0.2] = rng.integers(0, n_rows)                         # a hub row
+    cols = rng.integers(0, n_cols, nnz)
+    vals = rng.standard_normal(nnz) + (1j * rng.standard_normal(nnz) if seed % 3 == 0 else 0)
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(n_rows, n_cols))
+    A.sum_duplicates()
+    x = (rng.standard_normal(n_cols) + 1j * rng.standard_normal(n_cols)).astype(C128)
+    y0 = (rng.standard_normal(n_rows) + 1j * rng.standard_normal(n_rows)).astype(C128)
+    ref = oracle.csr_matvec(A, x)
+    scale = max(np.abs(ref).max(), 1e-300)
+    dx = torch.from_numpy(x).cuda()
+    for form in ("csr", "binned", "sliced"):
+        dA = DeviceCSR(A)
+        assert dA.autotune(force=form) == form
+        dy = torch.from_numpy(y0).cuda()
+        dA.spmv(dx, dy)
+        assert np.abs(dy.cpu().numpy() - ref).max() <= 1e-13 * scale * max(1.0, per_row), (form, n_rows, n_cols)
+        dA.spmv(dx, dy, accumulate=True)
+        assert np.abs(dy.cpu().numpy() - 2 * ref).max() <= 4e-13 * scale * max(1.0, per_row), (form, "accumulate")
+
+
 def test_spmv_autotune_picks_by_measurement(amd):
     from arnoldi_amd import matrices
     from arnoldi_amd.device import DeviceCSR
