@@ -4,7 +4,8 @@
  * src/arnoldi/decomposition.py:13-68), copies V and H back and checks the Arnoldi invariants
  *     V^H V = I      and      A V_m = V_{m+1} H
  * on the host, then compresses the basis with aks_truncate and re-checks orthonormality, and repeats the
- * factorisation in real-packed mode (aks_workspace_set_real + aks_arnoldi_expand with AKS_EXPAND_REAL_PACKED).
+ * factorisation with the operator in the sliced form (aks_sell_plan_size / _fill, aks_csr_block.sell) and in
+ * real-packed mode (aks_workspace_set_real + aks_arnoldi_expand with AKS_EXPAND_REAL_PACKED).
  *
  *   hipcc -x c abi_smoke.c -I../../include -L<dir of the .so> -larnoldi_hip -o abi_smoke
  * Exit code 0 = pass.  Used by tests/test_gpu_parity.py::test_c_abi_from_plain_c. */
@@ -125,6 +126,49 @@ int main(void) {
     printf("abi %d: |V^H V - I| = %.2e, |A V - V H| = %.2e, after truncate |V^H V - I| = %.2e, second passes %d\n",
            aks_abi_version(), worst_orth, worst_rel, worst_orth2, ctrl.second_passes);
     if (!(worst_orth < 1e-12 && worst_rel < 1e-12 && worst_orth2 < 1e-12)) return 1;
+
+    /* ---- the same factorisation with the operator in the sliced form (aks_sell_*): planned on the host by the
+     * library, uploaded here, handed over through aks_csr_block.sell; H must come out the same ---- */
+    {
+        const int64_t n_slices = (n + 63) / 64, nnz_pad = aks_sell_plan_size(indptr, n);
+        CHECK_AKS((int)(nnz_pad < 0 ? nnz_pad : 0));
+        int64_t *slice_ptr = malloc((n_slices + 1) * sizeof *slice_ptr);
+        int32_t *scol = malloc(nnz_pad * sizeof *scol);
+        double *sval = malloc(nnz_pad * sizeof *sval);
+        CHECK_AKS(aks_sell_plan_fill(indptr, indices, values, 0, n, slice_ptr, scol, sval));
+        aks_sell_matrix S;
+        memset(&S, 0, sizeof S);
+        S.n_rows = S.n_cols = n; S.nnz = nnz; S.nnz_pad = nnz_pad; S.n_slices = n_slices;
+        void *d_sp, *d_sc, *d_sv;
+        CHECK_HIP(hipMalloc(&d_sp, (n_slices + 1) * 8));
+        CHECK_HIP(hipMalloc(&d_sc, nnz_pad * 4));
+        CHECK_HIP(hipMalloc(&d_sv, nnz_pad * 8));
+        CHECK_HIP(hipMemcpy(d_sp, slice_ptr, (n_slices + 1) * 8, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(d_sc, scol, nnz_pad * 4, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(d_sv, sval, nnz_pad * 8, hipMemcpyHostToDevice));
+        S.d_slice_ptr = d_sp; S.d_col = d_sc; S.d_val = d_sv;
+        aks_c128 *d_V2, *d_H2;
+        CHECK_HIP(hipMalloc((void **)&d_V2, (size_t)(m + 1) * ldv * 16));
+        CHECK_HIP(hipMalloc((void **)&d_H2, (size_t)(m + 1) * m * 16));
+        CHECK_HIP(hipMemset(d_V2, 0, (size_t)(m + 1) * ldv * 16));
+        CHECK_HIP(hipMemset(d_H2, 0, (size_t)(m + 1) * m * 16));
+        double complex *v0 = malloc((size_t)n * sizeof *v0);
+        for (int64_t i = 0; i < n; ++i) v0[i] = sin(0.37 * (double)i + 1.0) + 0.5 * I * cos(0.11 * (double)i);
+        for (int64_t i = 0; i < n; ++i) v0[i] /= sqrt(nrm);
+        CHECK_HIP(hipMemcpy(d_V2, v0, (size_t)n * 16, hipMemcpyHostToDevice));
+        CHECK_AKS(aks_workspace_init(d_ws, lay.total_bytes, n, m, NULL));
+        aks_shard A2 = A;
+        A2.diag.sell = &S;
+        CHECK_AKS(aks_arnoldi_expand(&A2, d_V2, ldv, d_H2, m, 0, m, 1e-8, sqrt(0.5), d_ws, lay.total_bytes, m, NULL, NULL, 0));
+        CHECK_HIP(hipDeviceSynchronize());
+        double complex *H2 = malloc((size_t)(m + 1) * m * sizeof *H2);
+        CHECK_HIP(hipMemcpy(H2, d_H2, (size_t)(m + 1) * m * 16, hipMemcpyDeviceToHost));
+        double worst_h = 0.0;
+        for (int i = 0; i < (m + 1) * m; ++i)
+            if (cabs(H2[i] - H[i]) > worst_h) worst_h = cabs(H2[i] - H[i]);
+        printf("sliced form (padding x %.3f): max |H_sliced - H_csr| = %.2e\n", (double)nnz_pad / (double)nnz, worst_h);
+        if (!(worst_h < 1e-12)) return 1;
+    }
 
     /* ---- the same factorisation in real-packed mode: a column is n float64 = ceil(n/2) complex slots ---- */
     const int64_t n_panel = (n + 1) / 2, ldp = (n_panel + 63) / 64 * 64;
