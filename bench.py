@@ -420,6 +420,8 @@ def spmv_kernel_name(res, world):
         return f"sharded SpMV, rank 0 (pack + exchange + diag[{res['spmv_form']}] + off-diag)"
     if res["spmv_form"] == "binned":
         return "k_pb_phase1 + k_pb_phase2 (tile-binned SpMV, one pair per launch)"
+    if res["spmv_form"] == "sliced":
+        return "k_sell (sliced SpMV)"
     return "k_spmv (CSR-stream SpMV)"
 
 
@@ -439,6 +441,8 @@ def pmc_traffic(res, default_workload):
         if res["spmv_form"] == "binned":
             return (pmc["k_pb_phase1"]["hbm_bytes_per_launch_fetch_x2"]
                     + pmc["k_pb_phase2"]["hbm_bytes_per_launch_fetch_x2"]), "rocprofv3 --pmc, same build"
+        if res["spmv_form"] == "sliced":
+            return None, "no PMC pass collected for k_sell on this workload"
         return pmc["k_spmv"]["hbm_bytes_per_launch_raw"], "rocprofv3 --pmc, same build"
     except Exception as e:  # noqa: BLE001
         return None, f"pmc summary unreadable: {e}"
