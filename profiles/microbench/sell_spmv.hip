@@ -59,6 +59,67 @@ __global__ __launch_bounds__(256) void k_sell(int64_t n_rows, const int64_t *__r
     if (row < n_rows) y[row] = make_double2(sr, si);
 }
 
+// Round 3: the same walk as a two-stage software pipeline.  Two register sets (A, B) of U entries alternate: the
+// gathers of one set are issued, THEN the (column, value) loads of the set after next go out, then the gathered
+// set is summed -- vmcnt counts in issue order, so waiting for the gathers leaves the 2 U younger stream loads in
+// flight.  All loads are unconditional (slots past the slice's end re-read its last slot and are masked at use).
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_sell_ab(int64_t n_rows, const int64_t *__restrict__ slice_ptr,
+                                                const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                const c128 *__restrict__ x, c128 *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t per = (gridDim.x + 7) / 8;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int64_t slice = wg * 4 + (threadIdx.x >> 6);
+    const int64_t row = slice * 64 + lane;
+    if (slice * 64 >= n_rows) return;
+    const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
+    const int W = (int)((p1 - p0) >> 6);
+    double sr = 0.0, si = 0.0;
+    if (W > 0) {
+        const int32_t *c = col + p0 + lane;
+        const double *v = val + p0 + lane;
+        int32_t cA[U], cB[U];
+        double vA[U], vB[U];
+        auto fetch = [&](int32_t (&cc)[U], double (&vv)[U], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = min(k0 + u, W - 1);
+                cc[u] = NT ? __builtin_nontemporal_load(&c[(int64_t)k * 64]) : c[(int64_t)k * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = min(k0 + u, W - 1);
+                vv[u] = NT ? __builtin_nontemporal_load(&v[(int64_t)k * 64]) : v[(int64_t)k * 64];
+            }
+        };
+        // three register sets rotate (no register copies: a copy of a loaded value makes the compiler wait for it):
+        // trip t gathers set t % 3, then prefetches block t + 2 into the set trip t - 1 consumed, then sums
+        int32_t cC[U];
+        double vC[U];
+        fetch(cA, vA, 0);
+        fetch(cB, vB, U);
+        auto trip = [&](int32_t (&cc)[U], double (&vv)[U], int32_t (&cn)[U], double (&vn)[U], int k0) {
+            c128 xx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xx[u] = x[max(cc[u], 0)];
+            __builtin_amdgcn_sched_barrier(0);      // the machine scheduler otherwise sinks each gather to its use
+            fetch(cn, vn, k0 + 2 * U);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + u < W && cc[u] >= 0) { sr = fma(vv[u], xx[u].x, sr); si = fma(vv[u], xx[u].y, si); }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int k0 = 0; k0 < W; k0 += 3 * U) {
+            trip(cA, vA, cC, vC, k0);
+            trip(cB, vB, cA, vA, k0 + U);
+            trip(cC, vC, cB, vB, k0 + 2 * U);
+        }
+    }
+    if (row < n_rows) y[row] = make_double2(sr, si);
+}
+
 struct Csr { int64_t n; std::vector<int64_t> ptr; std::vector<int32_t> idx; std::vector<double> val; };
 
 static Csr laplace3d(int nx, int ny, int nz) {
@@ -83,7 +144,7 @@ static Csr banded(int64_t n, int per_row) {          // like bench.py --workload
     Csr A; A.n = n; A.ptr.assign(n + 1, 0);
     for (int64_t r = 0; r < n; ++r) {
         for (int j = 0; j < per_row; ++j) {
-            const int64_t c = r + (int64_t)(j - per_row / 2) * 3;
+            const int64_t c = r + (int64_t)(j - per_row / 2);      // a dense band, as matrices.banded_csr
             if (c >= 0 && c < n) { A.idx.push_back((int32_t)c); A.val.push_back(1.0 + 0.01 * j); }
         }
         A.ptr[r + 1] = (int64_t)A.idx.size();
@@ -148,6 +209,10 @@ static void run(const char *name, const Csr &A) {
     time_it([&] { hipLaunchKernelGGL((k_sell<4, true, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "u4 XCD nt");
     time_it([&] { hipLaunchKernelGGL((k_sell<7, true, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "u7 XCD nt");
     time_it([&] { hipLaunchKernelGGL((k_sell<8, true, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "u8 XCD nt");
+    time_it([&] { hipLaunchKernelGGL((k_sell_ab<2, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "ab2 XCD nt");
+    time_it([&] { hipLaunchKernelGGL((k_sell_ab<4, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "ab4 XCD nt");
+    time_it([&] { hipLaunchKernelGGL((k_sell_ab<6, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "ab6 XCD nt");
+    time_it([&] { hipLaunchKernelGGL((k_sell_ab<8, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "ab8 XCD nt");
     // check against the host CSR product on a sample of rows
     std::vector<double> hy(2 * n);
     CK(hipMemcpy(hy.data(), y, n * 16, hipMemcpyDeviceToHost));
