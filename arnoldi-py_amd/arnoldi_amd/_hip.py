@@ -10,7 +10,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_DIM = 128          # AKS_MAX_DIM
 MAX_TRUNC = 96         # AKS_MAX_TRUNC
 SPMV_TILE_NNZ = 256    # AKS_SPMV_TILE_NNZ
@@ -129,6 +129,7 @@ SIGNATURES = {
     "aks_gs_update_norm": (C.c_int, [_I64, _I32, _P, _I64, _P, _F64, _P, _I64, _I32, _P]),
     "aks_gs_finish": (C.c_int, [_I64, _I32, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
     "aks_dgks_gs": (C.c_int, [_I64, _I32, _P, _I64, _P, _P, _I64, _F64, _F64, _I32, _P, _I64, _I32, _P]),
+    "aks_device_init": (C.c_int, []),
     "aks_pb_params": (C.c_int, [C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "aks_pb_plan_create": (_P, [_P, _P, _P, _I32, _I64, _I64, C.POINTER(PbSizes)]),
     "aks_pb_plan_export": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
@@ -201,6 +202,26 @@ def check(status, what):
         msg = load().aks_last_error()
         raise HipLibraryError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
     return status
+
+
+_devices_ready = set()
+_device_lock = threading.Lock()
+
+
+def device_init(index):
+    """``aks_device_init`` once per device of this process: the library keeps no state of its own, so the host
+    layer remembers which devices have had the dynamic-LDS limit of the large-LDS kernels raised."""
+    if index in _devices_ready:
+        return
+    import torch
+
+    lib = load()                     # (takes _lock itself: not inside the device lock below)
+    with _device_lock:
+        if index in _devices_ready:
+            return
+        with torch.cuda.device(index):
+            check(lib.aks_device_init(), "aks_device_init")
+        _devices_ready.add(index)
 
 
 PROBE_SPMV, PROBE_ORTHO = 0, 1

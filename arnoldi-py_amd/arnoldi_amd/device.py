@@ -7,6 +7,8 @@ of ``libarnoldi_hip.so`` (``_hip.py``); nothing here computes on the CPU.
 from __future__ import annotations
 
 import ctypes as C
+import os
+import threading
 
 import numpy as np
 import scipy.sparse as sp
@@ -24,7 +26,9 @@ def _require_gpu(device):
             "no HIP device visible: arnoldi_amd runs its hot path on an MI355X only "
             "(there is no CPU fallback)"
         )
-    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    _hip.device_init(device.index if device.index is not None else torch.cuda.current_device())
+    return device
 
 
 def _ptr(t):
@@ -34,13 +38,14 @@ def _ptr(t):
     return C.c_void_p(t if isinstance(t, int) else t.data_ptr())
 
 
-_stream_cache = None
+_tls = threading.local()       # per host thread: independent solves may run concurrently, each on its own stream
 
 
 def _stream():
     """Current HIP stream as a void*.  ``cached_stream()`` pins the lookup for a hot loop."""
-    if _stream_cache is not None:
-        return _stream_cache
+    cached = getattr(_tls, "stream", None)
+    if cached is not None:
+        return cached
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -49,15 +54,13 @@ class cached_stream:
     lookup costs several microseconds per call, comparable to a launch)."""
 
     def __enter__(self):
-        global _stream_cache
-        self._prev = _stream_cache
-        _stream_cache = None
-        _stream_cache = _stream()
+        self._prev = getattr(_tls, "stream", None)
+        _tls.stream = None
+        _tls.stream = _stream()
         return self
 
     def __exit__(self, *exc):
-        global _stream_cache
-        _stream_cache = self._prev
+        _tls.stream = self._prev
         return False
 
 
@@ -189,13 +192,24 @@ class DeviceCSR:
             self.sliced = SlicedCSR(self._host, self.device)
         return self.sliced
 
-    def autotune(self, min_nnz=2_000_000, reps=3, force=None, real=False):
-        """Pick the SpMV form by timing the candidates on this device: the CSR-stream kernel always; the
-        tile-binned form for matrices that are large and scattered enough to miss L2; the sliced form for
-        matrices with column locality whose rows are of similar length (padding <= 1.25 x nnz).
-        ``force`` = "csr" | "binned" | "sliced" skips the measurement.  Frees the host copy.
+    def autotune(self, min_nnz=2_000_000, reps=3, force=None, real=False, measure=None):
+        """Pick the SpMV form.  Candidates by STRUCTURE: the tile-binned form for matrices that are large and
+        scattered enough to miss L2 (distinct x lines per non-zero > 0.5, >= 2M non-zeros, x larger than an
+        XCD's L2); the sliced form for matrices with column locality whose rows are of similar length (padding
+        <= 1.25 x nnz); the CSR-stream kernel otherwise.  By default a candidate is taken as it is -- every
+        measurement so far has it ahead (binned 2x on random graphs, sliced 1.1-1.35x on stencils, bands and
+        the Markov chain) -- so the choice, and with it the summation order of a row and the BITS of a solve,
+        is a function of the matrix alone, identical from run to run and from rank to rank.
+        ``measure=True`` (or AKS_SPMV_TUNE=measure) times the candidate against the CSR-stream kernel on this
+        device instead and keeps it only if it is >= 10 % (binned) / 5 % (sliced) faster: the answer then
+        depends on a timing (``tune_ms`` records it).
+        ``force`` = "csr" | "binned" | "sliced" skips both.  Frees the host copy.
         ``real``: time the real-vector kernels (real-packed mode)."""
+        if measure is None:
+            measure = os.environ.get("AKS_SPMV_TUNE", "structure") == "measure"
         choice = force
+        self.tune_ms = {}
+        self.tune_mode = "forced" if force else ("measured" if measure else "structure")
         if choice is None:
             forms = ["csr"]
             scattered = self.nnz >= min_nnz // 4 and self.scatter_ratio() > 0.5      # gathers without locality
@@ -210,6 +224,8 @@ class DeviceCSR:
                 forms.append("sliced")
             if len(forms) == 1:
                 choice = "csr"
+            elif not measure:
+                choice = forms[1]
         if choice is None:
             x = torch.zeros(self.n_cols, dtype=torch.complex128, device=self.device)
             y = torch.empty(self.n_rows, dtype=torch.complex128, device=self.device)

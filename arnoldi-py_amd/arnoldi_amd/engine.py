@@ -35,10 +35,12 @@ class CsrOperator:
 
     def __init__(self, A=None, *, local_rows=None, offsets=None, comm=None, device=None, spmv_form=None,
                  real=False):
-        """``spmv_form``: None/"auto" (time the CSR-stream kernel against the tile-binned form on large
-        scattered matrices and against the sliced form on matrices with rows of similar length, keep the
-        fastest), "csr", "binned" or "sliced".  Environment override:
-        AKS_SPMV_FORM.  ``real``: the operator works on real vectors (real-packed Krylov basis):
+        """``spmv_form``: None/"auto" (by the structure of the matrix -- ``DeviceCSR.autotune``: the tile-binned
+        form for large scattered matrices, the sliced form for matrices with column locality and rows of similar
+        length, the CSR-stream kernel otherwise; AKS_SPMV_TUNE=measure times the candidate instead), "csr",
+        "binned" or "sliced".  The form fixes the order in which a row's products are summed, i.e. the last
+        bits of a solve; it is reported in ``partial_schur(..., stats=)`` as ``spmv_form``.  Environment
+        override: AKS_SPMV_FORM.  ``real``: the operator works on real vectors (real-packed Krylov basis):
         real-vector SpMV kernels, float64 ghost exchange."""
         form = os.environ.get("AKS_SPMV_FORM", spmv_form or "auto")
         force = None if form == "auto" else form

@@ -216,6 +216,9 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
                      second_passes=int(ctx.last_ctrl.second_passes), solver=solver,
                      lookahead_applies=ctx.lookahead_applies, arithmetic=arithmetic,
                      tol=float(tol), max_dim=int(max_dim), p=int(p),
+                     spmv_form=getattr(solver.op, "spmv_form", None),      # which kernel applied A: decides the order
+                     spmv_form_chosen_by=getattr(getattr(solver.op, "diag", None), "tune_mode", None),   # of a row's sum
+
                      locked=int(getattr(solver, "locked", 0)), truncation_bytes=list(getattr(solver, "trunc_bytes", [])))
     if not converged:
         raise ValueError("Has not converged !")                      # krylov_schur.py:108-109

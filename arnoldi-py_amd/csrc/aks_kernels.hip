@@ -1082,7 +1082,10 @@ void dispatch_proj(int nc, dim3 grid, hipStream_t s, int64_t n, int c0, const c1
 }
 
 // exact-width fused kernel up to FUSED_EXACT_MAX columns, column-split fused kernel beyond
-constexpr int FUSED_EXACT_MAX = 20;
+#ifndef AKS_FUSED_EXACT_MAX
+#define AKS_FUSED_EXACT_MAX 20
+#endif
+constexpr int FUSED_EXACT_MAX = AKS_FUSED_EXACT_MAX;
 
 void dispatch_update_proj(int nc, dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
                           const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl) {
@@ -1130,25 +1133,33 @@ void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c12
                        ws.lay.ld_partial, 0, red_out, J, nullptr, nullptr, 0.0, zero_slot, ws.ctrl);
 }
 
+// Dynamic LDS above the default limit has to be allowed per kernel AND per device: aks_device_init does that for
+// every instantiation below on the current device; the library itself keeps no state (no "done" flags).
+constexpr size_t AKS_LDS_BYTES = 160 * 1024;
+template <typename K> int raise_lds(K kernel, size_t bytes, const char *where) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)bytes);
+    return e == hipSuccess ? AKS_OK : hip_fail(e, where);
+}
+
 template <int MT>
 int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_t ldv, const c128 *Qp, c128 *O,
-                         int64_t ldo, int copy_last) {
+                         int64_t ldo, int copy_last, bool init_only = false) {
     // rows per wave = 16 NS: 128 for p <= 16 (more loads in flight per K-step: 1.041 -> 1.011 ms at m = 20, p = 10,
     // n = 10M; the read/write mix of this kernel streams at ~5.4 TB/s = 0.95 ms), fewer as the accumulators grow
     constexpr int NS = MT <= 2 ? 8 : (MT <= 9 ? 4 : 2);      // keeps NS * MT * 8 accumulator registers below the spill point
     const size_t smem = (size_t)((m + 3) & ~3) * MT * 8 * sizeof(c128);
-    if (smem > 160 * 1024) return fail(AKS_ERR_UNSUPPORTED, "Qp does not fit the 160 KiB LDS");
-    static size_t smem_allowed = 48 * 1024;   // per instantiation (one process drives one GPU): raise once
-    if (smem > smem_allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_truncate_mfma<MT, NS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_truncate_mfma)");
-        smem_allowed = smem;
-    }
+    if (smem > AKS_LDS_BYTES) return fail(AKS_ERR_UNSUPPORTED, "Qp does not fit the 160 KiB LDS");
+    if (init_only) return raise_lds(k_truncate_mfma<MT, NS>, AKS_LDS_BYTES, "hipFuncSetAttribute(k_truncate_mfma)");
     const int64_t want = ((n + 16 * NS - 1) / (16 * NS) + WAVES - 1) / WAVES;
     const dim3 grid((unsigned)(want < 4096 ? want : 4096));
     hipLaunchKernelGGL((k_truncate_mfma<MT, NS>), grid, dim3(BLOCK), smem, s, n, m, p, V, ldv, Qp, O, ldo, copy_last);
-    AKS_CHECK_LAUNCH("k_truncate_mfma");
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        hip_fail(e, "k_truncate_mfma");
+        if (smem > 48 * 1024) g_err += " (dynamic LDS above the default limit: call aks_device_init on this device first)";
+        return AKS_ERR_HIP;
+    }
     return AKS_OK;
 }
 
@@ -1224,26 +1235,18 @@ int check_pb(const aks_pb_matrix *A, const void *x, const void *y) {
     return AKS_OK;
 }
 
-// dynamic LDS above the default limit has to be allowed once per kernel (one process drives one GPU)
-template <typename K> int allow_lds(K kernel, size_t bytes, bool *done) {
-    if (*done) return AKS_OK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(binned SpMV)");
-    *done = true;
-    return AKS_OK;
-}
-
 template <typename VT, typename XT>
-int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const aks_ctrl *ctrl, hipStream_t s) {
-    XT *prod = reinterpret_cast<XT *>(A->d_prod);       // real vectors use the first 8 nnz_pad bytes
+int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const aks_ctrl *ctrl, hipStream_t s,
+              bool init_only = false) {
     const size_t lds1 = (size_t)PB_CW * sizeof(XT);
     const size_t lds2 = (size_t)PB_RB * sizeof(XT);
-    static bool ok1 = false, ok2a = false, ok2b = false;
-    int rc = allow_lds(k_pb_phase1<VT, XT>, lds1, &ok1);
-    if (rc == AKS_OK) rc = allow_lds(k_pb_phase2<XT, true>, lds2, &ok2a);
-    if (rc == AKS_OK) rc = allow_lds(k_pb_phase2<XT, false>, lds2, &ok2b);
-    if (rc != AKS_OK) return rc;
+    if (init_only) {
+        int rc = raise_lds(k_pb_phase1<VT, XT>, lds1, "hipFuncSetAttribute(k_pb_phase1)");
+        if (rc == AKS_OK) rc = raise_lds(k_pb_phase2<XT, true>, lds2, "hipFuncSetAttribute(k_pb_phase2)");
+        if (rc == AKS_OK) rc = raise_lds(k_pb_phase2<XT, false>, lds2, "hipFuncSetAttribute(k_pb_phase2)");
+        return rc;
+    }
+    XT *prod = reinterpret_cast<XT *>(A->d_prod);       // real vectors use the first 8 nnz_pad bytes
     if (A->nnz > 0)
         hipLaunchKernelGGL((k_pb_phase1<VT, XT>), dim3((unsigned)A->n_slabs), dim3(PB_P1_THREADS), lds1, s, A->n_cols,
                            A->d_slab_begin, A->d_slab_end, static_cast<const VT *>(A->d_val), A->d_lcol, x, prod, ctrl);
@@ -1256,7 +1259,12 @@ int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const 
     else
         hipLaunchKernelGGL((k_pb_phase2<XT, false>), dim3((unsigned)(cpx * 8)), dim3(PB_W * 64), lds2, s, A->n_rows,
                            A->n_rowblocks, n_chunks, cpx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
-    AKS_CHECK_LAUNCH("aks_pb_spmv");
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        hip_fail(e, "aks_pb_spmv");
+        g_err += " (the binned kernels use 128 KiB of dynamic LDS: call aks_device_init on this device first)";
+        return AKS_ERR_HIP;
+    }
     return AKS_OK;
 }
 
@@ -1289,6 +1297,16 @@ extern "C" {
 
 const char *aks_last_error(void) { return g_err.c_str(); }
 int32_t aks_abi_version(void) { return AKS_ABI_VERSION; }
+
+int aks_device_init(void) {
+    int rc = launch_pb<double, c128>(nullptr, nullptr, nullptr, 0, nullptr, nullptr, true);
+    if (rc == AKS_OK) rc = launch_pb<c128, c128>(nullptr, nullptr, nullptr, 0, nullptr, nullptr, true);
+    if (rc == AKS_OK) rc = launch_pb<double, double>(nullptr, nullptr, nullptr, 0, nullptr, nullptr, true);
+#define M(N) if (rc == AKS_OK) rc = launch_truncate_mfma<N>(nullptr, 0, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0, true);
+    M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12)
+#undef M
+    return rc;
+}
 
 int aks_workspace_layout(int64_t n_rows, int32_t max_dim, aks_ws_layout *out) {
     if (out == nullptr) return fail(AKS_ERR_ARG, "layout pointer is null");
@@ -1416,9 +1434,9 @@ int aks_gs_update_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_
     c128 *w = reinterpret_cast<c128 *>(d_w);
     // Measured at n = 10M (profiles/ab_kernels.py): the column-split kernel wins for 5 <= J <= 12 (more waves
     // in flight) and for J > 20 (the exact-width kernel drops to one wave per SIMD); the exact-width kernel
-    // wins for 13 <= J <= 20.  AKS_FUSED_EXACT_MAX overrides the upper switch point for A/B runs.
-    static const int exact_max = getenv("AKS_FUSED_EXACT_MAX") ? atoi(getenv("AKS_FUSED_EXACT_MAX")) : FUSED_EXACT_MAX;
-    const bool exact = J <= exact_max && J <= NC_MAX && !(J >= 5 && J <= 12 && exact_max == FUSED_EXACT_MAX);
+    // wins for 13 <= J <= 20.  (-DAKS_FUSED_EXACT_MAX=.. moves the upper switch point for A/B builds.)
+    constexpr int exact_max = FUSED_EXACT_MAX;
+    const bool exact = J <= exact_max && J <= NC_MAX && !(J >= 5 && J <= 12);
     if (exact)
         dispatch_update_proj(J, dim3(ws.lay.n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
                              ws.lay.ld_partial, ws.ctrl);

@@ -404,7 +404,8 @@ def measure(args, comm, world, rank):
         "elapsed": elapsed,
         "n": n, "nnz_local": nnz_local, "nev": nev, "m": m, "p": p, "native": native,
         "initial_ms": initial_ms, "setup_s": t_setup, "steps_done": steps_done,
-        "spmv_form": op.spmv_form, "spmv_tune_ms": getattr(op.diag, "tune_ms", None),
+        "spmv_form": op.spmv_form, "spmv_tune_ms": getattr(op.diag, "tune_ms", None) or None,
+        "spmv_tune_mode": getattr(op.diag, "tune_mode", None),
         "spmv_bytes": spmv_bytes, "spmv_avg_ms": spmv_avg_ms, "n_spmv": n_spmv, "achieved": achieved,
         "ortho": ortho, "frac_second": frac_second, "per_cycle": per_cycle, "n_panel": n_panel,
         "n_local": op.n_local, "exchange": exchange,
@@ -586,6 +587,7 @@ def run_rank(args, argv):
             "roofline": {
                 "kernel": spmv_kernel_name(res, world),
                 "spmv_form": res["spmv_form"],
+                "spmv_form_chosen_by": res["spmv_tune_mode"],
                 "spmv_autotune_ms": res["spmv_tune_ms"],
                 "bound": "hbm",
                 "achieved": round(achieved, 1) if achieved else None,

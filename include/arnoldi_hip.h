@@ -20,6 +20,12 @@
  *     reference's row-major (m+1) x m array (krylov_schur.py:43), ld = ldh.
  *   - Return value: AKS_OK (0) or a negative AKS_ERR_*; aks_last_error() gives
  *     the text (thread-local).  No C++ exception crosses the boundary.
+ *   - The library keeps NO mutable global state (the only static datum is the thread-local
+ *     error string): independent call sequences may run concurrently from several host
+ *     threads, on one device or on several; a workspace / probe / communicator handle belongs
+ *     to one sequence at a time.  aks_device_init() must have run once on every device whose
+ *     kernels need more than the default 64 KiB of dynamic LDS (the binned SpMV, and
+ *     aks_truncate / aks_combine with a large Qp).
  *   - Breakdown (reference: decomposition.py:61-63) is detected ON THE DEVICE:
  *     the control block's `broken` word is set, `n_iter` records j+1, and every
  *     later launch that is handed the same workspace becomes a no-op.  The host
@@ -34,7 +40,7 @@
 extern "C" {
 #endif
 
-#define AKS_ABI_VERSION 2
+#define AKS_ABI_VERSION 3
 
 #define AKS_OK 0
 #define AKS_ERR_ARG (-1)         /* bad argument (null pointer, size, alignment) */
@@ -78,6 +84,11 @@ typedef struct aks_ws_layout {
 
 const char *aks_last_error(void);
 int32_t aks_abi_version(void);
+/* Raises the dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize, a per-device, per-kernel
+ * attribute) of every kernel that may use up to 160 KiB, on the CURRENT device.  Call it once per device
+ * and process before the first aks_pb_spmv* / aks_truncate / aks_combine there; calling it again is
+ * harmless, and it may be called from any thread.  Without it those launches fail with AKS_ERR_HIP. */
+int aks_device_init(void);
 
 /* ---- workspace ---------------------------------------------------------- */
 /* Pure host computation of the layout for a local row count and max_dim. */

@@ -44,6 +44,7 @@ int main(int argc, char **argv) {
     for (auto &v : values) v = (double)(rnd() >> 11) * (2.0 / 9007199254740992.0) - 1.0;
     for (int64_t r = 0; r < n; ++r) std::sort(indices.begin() + r * per_row, indices.begin() + (r + 1) * per_row);
 
+    AK(aks_device_init());
     // ---- plans
     std::vector<int32_t> tiles(n + 2);
     const int64_t n_tiles = aks_csr_plan_tiles(indptr.data(), n, AKS_SPMV_TILE_NNZ, tiles.data(), n + 2);

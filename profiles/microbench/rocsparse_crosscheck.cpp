@@ -77,6 +77,7 @@ int main(int argc, char **argv) {
     };
 
     // ---- the library's two forms (reference result = the CSR-stream kernel)
+    AK(aks_device_init());
     std::vector<int32_t> tiles(n + 2);
     const int64_t n_tiles = aks_csr_plan_tiles(indptr.data(), n, AKS_SPMV_TILE_NNZ, tiles.data(), n + 2);
     AK((int)std::min<int64_t>(n_tiles, 0));

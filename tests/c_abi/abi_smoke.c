@@ -45,6 +45,7 @@ int main(void) {
     const int64_t n_tiles = aks_csr_plan_tiles(indptr, n, AKS_SPMV_TILE_NNZ, tiles, n + 2);
     CHECK_AKS(n_tiles);
 
+    CHECK_AKS(aks_device_init());                    /* once per device: dynamic-LDS limits of the large-LDS kernels */
     aks_ws_layout lay;
     CHECK_AKS(aks_workspace_layout(n, m, &lay));
 

@@ -40,6 +40,9 @@ class FakeHip:
             setattr(self, name, getattr(real, name))
         self.calls = []
 
+    def aks_device_init(self):
+        return 0
+
     # ---- workspace ---------------------------------------------------------------
     def _ws(self, ws, n_rows, max_dim):
         from arnoldi_amd import _hip

@@ -294,15 +294,24 @@ def test_spmv_forms_agree_on_random_shapes(amd, seed):
         assert np.abs(dy.cpu().numpy() - 2 * ref).max() <= 4e-13 * scale * max(1.0, per_row), (form, "accumulate")
 
 
-def test_spmv_autotune_picks_by_measurement(amd):
+def test_spmv_form_is_chosen_by_structure_or_by_measurement(amd, monkeypatch):
     from arnoldi_amd import matrices
     from arnoldi_amd.device import DeviceCSR
 
+    # default: the candidate form follows from the matrix alone (no timing => same bits on every run and rank)
     lap = DeviceCSR(matrices.laplace2d(1500, 1501))
-    choice = lap.autotune()                                        # stencil: no candidate for the binned form,
-    assert lap.binned is None and set(lap.tune_ms) == {"csr", "sliced"}    # rows of equal length: sliced is timed
+    assert lap.autotune() == "sliced" and lap.tune_mode == "structure" and lap.tune_ms == {} and lap.binned is None
+    rnd = DeviceCSR(matrices.random_csr(4_000_000, 5, 3))
+    assert rnd.autotune() == "binned" and rnd.tune_ms == {} and rnd.sliced is None
+    small = DeviceCSR(matrices.random_csr(20_000, 5, 3))
+    assert small.autotune() == "csr"
+    # measure=True / AKS_SPMV_TUNE=measure: the candidate is timed against the CSR-stream kernel
+    lap = DeviceCSR(matrices.laplace2d(1500, 1501))
+    choice = lap.autotune(measure=True)                            # stencil: no candidate for the binned form,
+    assert lap.binned is None and set(lap.tune_ms) == {"csr", "sliced"} and lap.tune_mode == "measured"
     assert (choice == "sliced") == (lap.tune_ms["sliced"] < 0.95 * lap.tune_ms["csr"]) and choice in ("csr", "sliced")
     assert (lap.sliced is not None) == (choice == "sliced")
+    monkeypatch.setenv("AKS_SPMV_TUNE", "measure")
     rnd = DeviceCSR(matrices.random_csr(4_000_000, 5, 3))
     choice = rnd.autotune()                                        # gathers without locality: slices are not tried
     assert set(rnd.tune_ms) == {"csr", "binned"} and choice in ("csr", "binned") and rnd.sliced is None
@@ -320,6 +329,55 @@ def test_partial_schur_with_binned_spmv(amd):
         assert op.spmv_form == form
         _solve_and_compare(amd, op, g8, "s0_", 0, nev=5, max_dim=20, sort_function=oracle.arg_largest_magnitude,
                            residual_matrix=A)
+
+
+def test_two_host_threads_solve_concurrently(amd):
+    """The library keeps no mutable global state (threading row): two solves driven from two host
+    threads at the same time, each on its own stream -- one through the binned form (128 KiB of dynamic LDS per
+    workgroup), one with a wide restart block (Qp in more than 48 KiB of LDS) -- return the bits of the same
+    solves run one after the other."""
+    import threading
+
+    import torch
+    from arnoldi_amd.engine import CsrOperator
+    from arnoldi_amd.matrices import laplace2d
+
+    g8 = load_golden("g8_random_planted")
+    A1 = _planted_like_golden(int(g8["n"]))
+    A2 = laplace2d(60, 61)
+    v1 = np.random.default_rng(5).standard_normal(A1.shape[0])
+    v2 = np.random.default_rng(6).standard_normal(A2.shape[0])
+    v1, v2 = v1 / np.linalg.norm(v1), v2 / np.linalg.norm(v2)
+
+    def solve1():
+        return amd.partial_schur(CsrOperator(A1, spmv_form="binned"), 5, max_dim=20, v0=v1.copy(),
+                                 sort_function=oracle.arg_largest_magnitude)
+
+    def solve2():
+        return amd.partial_schur(A2, 30, max_dim=100, p=80, v0=v2.copy(), stopping_criterion=1e-9, max_restarts=400)
+
+    ref = [solve1(), solve2()]
+    for _ in range(2):
+        out, errors = [None, None], []
+
+        def run(i, f):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    out[i] = f()
+                    torch.cuda.current_stream().synchronize()
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=run, args=(i, f)) for i, f in enumerate((solve1, solve2))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for (Q, T, h), (Qr, Tr, hr) in zip(out, ref):
+            np.testing.assert_array_equal(Q, Qr)
+            np.testing.assert_array_equal(T, Tr)
+            np.testing.assert_array_equal(h.restarts, hr.restarts)
 
 
 # ---------------------------------------------------------------------------- Gram-Schmidt

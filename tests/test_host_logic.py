@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in arnoldi_hip.h but not exported"
     assert sorted(_hip.SIGNATURES) == declared, "ctypes binding and header disagree"
     lib = _hip.load()
-    assert lib.aks_abi_version() == _hip.ABI_VERSION == 2
+    assert lib.aks_abi_version() == _hip.ABI_VERSION == 3
 
 
 def test_header_constants_match_binding():
@@ -193,6 +193,30 @@ def test_no_gpu_means_loud_failure():
 
     with pytest.raises(_hip.HipLibraryError, match="no CPU fallback"):
         arnoldi_amd.partial_schur(mark(10), 3, max_dim=5)
+
+
+def test_device_init_reaches_the_library_without_a_gpu(monkeypatch):
+    """_hip.device_init (first thing every device object does) must load the library and call aks_device_init --
+    which, here, reports the missing GPU -- rather than block (it once took _hip's load lock twice)."""
+    import torch
+    from arnoldi_amd import _hip
+
+    class _Dev:
+        def __init__(self, index):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+    monkeypatch.setattr(torch.cuda, "device", _Dev)
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "_devices_ready", set())
+    with pytest.raises(_hip.HipLibraryError, match="aks_device_init failed"):
+        _hip.device_init(0)
+    assert not _hip._devices_ready
 
 
 # ---------------------------------------------------------------------------- driver over the fake device
