@@ -224,7 +224,7 @@ def device_init(index):
         _devices_ready.add(index)
 
 
-PROBE_SPMV, PROBE_ORTHO = 0, 1
+PROBE_SPMV, PROBE_ORTHO, PROBE_PACK, PROBE_EXCHANGE, PROBE_DIAG, PROBE_OFFDIAG = range(6)   # AKS_PROBE_*
 
 
 class Probe:

@@ -18,6 +18,9 @@ AKS_DIST_PATH=python.
 """
 from __future__ import annotations
 
+import atexit
+import weakref
+
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -84,6 +87,32 @@ def split_local_rows(A_rows, offsets, rank):
 
 
 # --------------------------------------------------------------------------- communicator
+_live_comms = weakref.WeakSet()   # Comms that own an RCCL communicator: destroyed at interpreter exit at the latest
+_default_comms = {}          # process group -> Comm, so that repeated solves share one communicator
+
+
+def _close_all():
+    for c in list(_live_comms):
+        try:
+            c.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all)
+
+
+def comm_for(group=None):
+    """The Comm of a process group (the default group if None), created once per group: every
+    ``partial_schur`` without an explicit ``comm`` used to build a new one -- and with it a new RCCL
+    communicator (bootstrap, device buffers) that nothing destroyed."""
+    key = group if group is not None else "default"
+    c = _default_comms.get(key)
+    if c is None or (dist.is_initialized() and c.size != dist.get_world_size(group)):
+        c = _default_comms[key] = Comm(group)
+    return c
+
+
 class Comm:
     """Thin wrapper over a torch.distributed process group.
 
@@ -111,59 +140,79 @@ class Comm:
 
     def native(self):
         """``aks_comm`` handle (RCCL communicator owned by libarnoldi_hip.so) for this group, or None when the
-        group does not run over RCCL (gloo: CPU tests, several test ranks on one GPU).  With it the whole
-        expansion -- ghost exchange and the reductions between the Gram-Schmidt stages included -- is one C
-        call per rank (``aks_arnoldi_expand``); torch.distributed is then only the out-of-band channel that
-        carries the communicator's id.  AKS_DIST_PATH=python keeps the stage chaining in Python."""
+        group does not run over RCCL (gloo: CPU tests, several test ranks on one GPU) or AKS_DIST_PATH=python
+        asks for the stage chaining in Python.  With it the whole expansion -- ghost exchange and the reductions
+        between the Gram-Schmidt stages included -- is one C call per rank (``aks_arnoldi_expand``);
+        torch.distributed is then only the out-of-band channel that carries the communicator's id.
+
+        A communicator that cannot be created, or fails its self-test, is an ERROR on every rank
+        (``HipLibraryError``), not a quiet change of path: which path ran must not depend on a warning nobody
+        reads.  Every rank votes after each step (id drawn, communicator created, self-test passed) BEFORE
+        the next collective is entered, so a rank that failed never leaves its peers waiting in one."""
         import os
 
-        if self.backend != "nccl" or os.environ.get("AKS_DIST_PATH", "native") == "python":
+        path = os.environ.get("AKS_DIST_PATH", "native")
+        over_gloo = os.environ.get("AKS_COMM_OVER_GLOO") == "1"     # tests: the id travels over gloo, the ranks
+        if path == "python" or (self.backend != "nccl" and not over_gloo):   # share a GPU (tests/mock_rccl)
             return None
-        if self._native is None and not getattr(self, "_native_refused", False):
-            import ctypes as C
-            import warnings
+        if self._native is not None:
+            return self._native
+        import ctypes as C
 
-            from . import _hip
+        from . import _hip
 
-            lib = _hip.load()
-            ident = (C.c_char * _hip.COMM_ID_BYTES)()
-            box = [None]
-            if self.rank == 0:
-                try:
-                    _hip.check(lib.aks_comm_unique_id(C.cast(ident, C.c_void_p)), "aks_comm_unique_id")
-                    box = [bytes(ident)]
-                except _hip.HipLibraryError as e:        # tell the others instead of leaving them in the broadcast
-                    warnings.warn(f"RCCL communicator not available ({e}); collectives stay with torch.distributed")
+        lib = _hip.load()
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def agree(ok, what, err=None):
+            """All ranks learn whether every rank got through ``what``; the first failure raises everywhere."""
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._wire_device())
             if self.size > 1:
-                dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
-                                           group=self.group)
-            handle, err = C.c_void_p(), None
-            if box[0] is not None:
-                ident = (C.c_char * _hip.COMM_ID_BYTES).from_buffer_copy(box[0])
-                try:
-                    _hip.check(lib.aks_comm_create(C.cast(ident, C.c_void_p), self.rank, self.size, C.byref(handle)),
-                               "aks_comm_create")
-                    # prove the communicator before relying on it: sum of (rank + 1) over the ranks
-                    probe = torch.full((2,), float(self.rank + 1), dtype=torch.float64, device=self._wire_device())
-                    _hip.check(lib.aks_comm_allreduce_sum(handle, C.c_void_p(probe.data_ptr()), 2,
-                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                               "aks_comm_allreduce_sum")
-                    if abs(float(probe[0].item()) - self.size * (self.size + 1) / 2) > 1e-9:
-                        raise _hip.HipLibraryError(f"all-reduce self-test gave {probe.tolist()}")
-                except _hip.HipLibraryError as e:
-                    err = e
-            ok = torch.tensor([1 if (box[0] is not None and err is None) else 0], dtype=torch.int32,
-                              device=self._wire_device())
-            if self.size > 1:                            # all ranks take the same path
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-            if int(ok.item()) == 0:
-                if handle:
-                    lib.aks_comm_destroy(handle)
-                if err is not None:
-                    warnings.warn(f"RCCL communicator refused ({err}); collectives stay with torch.distributed")
-                self._native_refused = True
-                return None
-            self._native = handle
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if int(flag.item()) == 0:
+                raise _hip.HipLibraryError(
+                    f"RCCL communicator of the row-sharded solve: {what} failed on "
+                    + (f"this rank ({err})" if err is not None else "another rank")
+                    + "; set AKS_DIST_PATH=python to chain the stages through torch.distributed instead")
+
+        ident = (C.c_char * _hip.COMM_ID_BYTES)()
+        box, err = [None], None
+        if self.rank == 0:
+            try:
+                _hip.check(lib.aks_comm_unique_id(C.cast(ident, C.c_void_p)), "aks_comm_unique_id")
+                box = [bytes(ident)]
+            except _hip.HipLibraryError as e:
+                err = e
+        if self.size > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                       group=self.group)
+        agree(box[0] is not None, "aks_comm_unique_id", err)
+        handle, err = C.c_void_p(), None
+        ident = (C.c_char * _hip.COMM_ID_BYTES).from_buffer_copy(box[0])
+        try:
+            _hip.check(lib.aks_comm_create(C.cast(ident, C.c_void_p), self.rank, self.size, C.byref(handle)),
+                       "aks_comm_create")
+        except _hip.HipLibraryError as e:
+            err = e
+        try:
+            agree(err is None, "aks_comm_create", err)
+            # prove the communicator before relying on it: sum of (rank + 1) over the ranks
+            probe = torch.full((2,), float(self.rank + 1), dtype=torch.float64, device=dev)
+            try:
+                _hip.check(lib.aks_comm_allreduce_sum(handle, C.c_void_p(probe.data_ptr()), 2,
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                           "aks_comm_allreduce_sum")
+                if abs(float(probe[0].item()) - self.size * (self.size + 1) / 2) > 1e-9:
+                    raise _hip.HipLibraryError(f"all-reduce self-test gave {probe.tolist()}")
+            except _hip.HipLibraryError as e:
+                err = e
+            agree(err is None, "the all-reduce self-test", err)
+        except _hip.HipLibraryError:
+            if handle:
+                lib.aks_comm_destroy(handle)
+            raise
+        self._native = handle
+        _live_comms.add(self)
         return self._native
 
     def close(self):
@@ -172,6 +221,13 @@ class Comm:
 
             _hip.load().aks_comm_destroy(self._native)
             self._native = None
+        _live_comms.discard(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # -- small host-side exchanges used while building plans -----------------
     def allgather_int64(self, values):

@@ -244,6 +244,7 @@ class ArnoldiContext:
         # multi-rank: leave the third all-reduce out until a step turns out to need a second DGKS pass
         self.lazy_third = os.environ.get("AKS_LAZY_THIRD", "1") != "0"
         self.lazy_redos = 0
+        self.discarded_second_passes = self.discarded_steps = self.discarded_applies = 0   # work of repeated expansions
         self.last_ctrl = None
         self._look = None           # scratch columns; [_look_col] holds A V[:, end] of the last expansion
         self._look_col = 0
@@ -278,6 +279,7 @@ class ArnoldiContext:
         # on).  Its inputs V[:, :start+1] (and the look-ahead product) are untouched by the failed attempt.
         lazy = multi and self.lazy_third
         passes_before = int(self.last_ctrl.second_passes) if self.last_ctrl is not None else 0
+        steps_before = int(self.last_ctrl.steps_done) if self.last_ctrl is not None else 0
         want_look = lookahead and self.allow_lookahead and isinstance(op, CsrOperator) and end > start
         if want_look and self._look is None:
             # two scratch columns: the product consumed by this expansion stays intact (a repeated
@@ -294,14 +296,20 @@ class ArnoldiContext:
             fetch = dev.fetch_H_and_ctrl(b, ws)             # queued before the look-ahead, waited for after it
             if want_look:
                 op.apply(b.col(end), self._look.col(1 - self._look_col), ws)   # a device no-op after a breakdown
-                self.lookahead_applies += 1
             Hd, ctrl = fetch()
             if lazy and int(ctrl.second_passes) != passes_before:
                 self.lazy_third = lazy = False              # a step needed the second pass: do it over, exactly
                 self.lazy_redos += 1
+                # the device counters are cumulative: what the discarded attempt added is kept apart, so that
+                # ``second_passes`` / ``steps`` describe the expansions whose results were used
+                self.discarded_second_passes += int(ctrl.second_passes) - passes_before
+                self.discarded_steps += int(ctrl.steps_done) - steps_before
+                self.discarded_applies += (end - start - (1 if w_ready else 0)) + (1 if want_look else 0)
+                passes_before, steps_before = int(ctrl.second_passes), int(ctrl.steps_done)
                 continue
             break
         if want_look:
+            self.lookahead_applies += 1
             self._look_col = 1 - self._look_col
             self._look_valid = not ctrl.broken
         n_iter = int(ctrl.n_iter) if ctrl.broken else end
@@ -332,10 +340,16 @@ class ArnoldiContext:
         # every restart (DGKS decisions and breakdown are taken on the device), so it can be
         # captured once into a hipGraph and replayed: one host call per restart instead of
         # ~10 launches per Arnoldi step (opt-in: AKS_GRAPH=1; pays off when the host is slow
-        # relative to the kernels).  Not used while a probe records per-kernel events, nor with
-        # collectives in the sequence.
-        key = (start, end, float(tol), float(eta), w_ready)
-        if self.use_graph and self.probe is None and start > 0 and not op.native_comm and b.V.is_cuda:
+        # relative to the kernels).  Not used while a probe records per-kernel events.  With a communicator the
+        # sequence contains RCCL calls.  The stage all-reduces can be captured with it (AKS_GRAPH_COMM=1, opt-in:
+        # checked on a one-rank communicator only -- tests/nccl_single_worker.py -- where replay is bit-identical
+        # to eager); a ghost exchange cannot: ending the capture of the grouped ncclSend / ncclRecv forked onto the
+        # communicator's side stream crashes inside hipStreamEndCapture (ROCm 7.2, RCCL 2.26), so sequences with
+        # an exchange stay eager.  At the shard sizes of the BASELINE configs on 8 GPUs (1.25M - 2M rows) a kernel
+        # lasts 20-60 us against ~4 us to launch it, so the eager sequence is not host-bound there.
+        key = (start, end, float(tol), float(eta), w_ready, lazy)
+        graph_ok = not op.native_comm or (os.environ.get("AKS_GRAPH_COMM", "0") == "1" and not op.any_exchange)
+        if self.use_graph and self.probe is None and start > 0 and graph_ok and b.V.is_cuda:
             g = self._graphs.get(key)
             if g is None:
                 g = torch.cuda.CUDAGraph()
@@ -574,5 +588,7 @@ def default_comm():
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return Comm()
+        from .dist import comm_for
+
+        return comm_for()            # one Comm (and one RCCL communicator) per process group, not per solve
     return None

@@ -213,7 +213,8 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
     if stats is not None:
         ctx = solver.ctx
         stats.update(restarts=solver.restarts_run, matvecs=ctx.matvecs,
-                     second_passes=int(ctx.last_ctrl.second_passes), solver=solver,
+                     second_passes=int(ctx.last_ctrl.second_passes) - ctx.discarded_second_passes, solver=solver,
+                     lazy_redos=ctx.lazy_redos, discarded_operator_applies=ctx.discarded_applies,
                      lookahead_applies=ctx.lookahead_applies, arithmetic=arithmetic,
                      tol=float(tol), max_dim=int(max_dim), p=int(p),
                      spmv_form=getattr(solver.op, "spmv_form", None),      # which kernel applied A: decides the order

@@ -1834,7 +1834,17 @@ int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *strea
     return AKS_OK;
 }
 
-int aks_shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *d_ws, void *stream, int32_t flags) {
+// y = A x for one rank's rows.  With a communicator: pack -> [side stream: grouped send/recv] || diagonal block ->
+// off-diagonal block.  ORDER OF THE COMMUNICATOR'S OPERATIONS: the all-reduces of the Gram-Schmidt stages (compute
+// stream) and the exchanges (side stream) share ONE ncclComm_t, which RCCL allows as long as the operations
+// are serialised -- and they are, by stream dependencies, not by luck: an exchange is issued behind the event
+// `packed`, recorded on the compute stream after everything that precedes it there (the all-reduces of the step
+// before included); the compute stream waits for `arrived`, recorded behind the exchange, before the off-diagonal
+// block and hence before the next all-reduce.  Every rank issues the same sequence, so the n-th operation of the
+// communicator is the same collective on every rank.  (tests/mock_rccl runs 2-4 ranks through exactly this code
+// with a stand-in that aborts on any mismatch of order, peer or size.)
+static int shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *d_ws, void *stream, int32_t flags,
+                       Probe *pr) {
     if (A == nullptr || d_x == nullptr || d_y == nullptr) return fail(AKS_ERR_ARG, "null pointer");
     const bool real = (flags & AKS_EXPAND_REAL_PACKED) != 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1844,16 +1854,29 @@ int aks_shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *
     if (A->send_counts == nullptr || A->recv_counts == nullptr) return fail(AKS_ERR_ARG, "null exchange counts");
     if ((A->n_send > 0 && (!A->d_send_idx || !A->d_sendbuf)) || (A->n_ghost > 0 && !A->d_ghostbuf))
         return fail(AKS_ERR_ARG, "null exchange buffer");
+    {   // validate the plan BEFORE anything is enqueued: a bad count must not leave a half-issued group behind
+        int64_t so = 0, ro = 0;
+        for (int peer = 0; peer < c->size; ++peer) {
+            const int64_t ns = A->send_counts[peer], nr = A->recv_counts[peer];
+            if (ns < 0 || nr < 0) return fail(AKS_ERR_ARG, "negative exchange count");
+            so += ns;
+            ro += nr;
+        }
+        if (so != A->n_send || ro != A->n_ghost) return fail(AKS_ERR_ARG, "exchange counts do not add up to n_send / n_ghost");
+    }
     int rc = AKS_OK;
+    hipEvent_t done = pr ? pr->begin(AKS_PROBE_PACK, s) : nullptr;
     if (A->n_send > 0)
         rc = real ? aks_gather_f64(A->n_send, A->d_send_idx, static_cast<const double *>(d_x),
                                    static_cast<double *>(A->d_sendbuf), stream)
                   : aks_gather_c128(A->n_send, A->d_send_idx, static_cast<const aks_c128 *>(d_x),
                                     static_cast<aks_c128 *>(A->d_sendbuf), stream);
+    if (done) (void)hipEventRecord(done, s);
     if (rc != AKS_OK) return rc;
     hipError_t e = hipEventRecord(c->packed, s);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->side, c->packed, 0);
     if (e != hipSuccess) return hip_fail(e, "aks_shard_apply(events)");
+    done = pr ? pr->begin(AKS_PROBE_EXCHANGE, c->side) : nullptr;
     {   // all-to-all of the packed entries: every pair of ranks exchanges its slice, one group
         const size_t words = real ? 1 : 2;
         const double *sb = static_cast<const double *>(A->d_sendbuf);
@@ -1862,10 +1885,6 @@ int aks_shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *
         int64_t so = 0, ro = 0;
         for (int peer = 0; peer < c->size && r == ncclSuccess; ++peer) {
             const int64_t ns = A->send_counts[peer], nr = A->recv_counts[peer];
-            if (ns < 0 || nr < 0 || so + ns > A->n_send || ro + nr > A->n_ghost) {
-                (void)ncclGroupEnd();
-                return fail(AKS_ERR_ARG, "exchange counts do not fit the buffers");
-            }
             if (ns > 0) r = ncclSend(sb + so * words, (size_t)ns * words, ncclDouble, peer, c->nccl, c->side);
             if (nr > 0 && r == ncclSuccess) r = ncclRecv(gb + ro * words, (size_t)nr * words, ncclDouble, peer, c->nccl, c->side);
             so += ns;
@@ -1875,14 +1894,23 @@ int aks_shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *
         if (r != ncclSuccess) return nccl_fail(r, "ncclSend/ncclRecv");
         if (r2 != ncclSuccess) return nccl_fail(r2, "ncclGroupEnd");
     }
+    if (done) (void)hipEventRecord(done, c->side);
     e = hipEventRecord(c->arrived, c->side);
     if (e != hipSuccess) return hip_fail(e, "hipEventRecord");
+    done = pr ? pr->begin(AKS_PROBE_DIAG, s) : nullptr;
     rc = apply_block(A->diag, d_x, d_y, 0, d_ws, stream, real);          // overlaps the exchange
+    if (done) (void)hipEventRecord(done, s);
     if (rc != AKS_OK) return rc;
+    done = pr ? pr->begin(AKS_PROBE_OFFDIAG, s) : nullptr;               // = wait for the ghosts + off-diagonal block
     e = hipStreamWaitEvent(s, c->arrived, 0);
     if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
     if (A->off.n_rows > 0) rc = apply_block(A->off, A->d_ghostbuf, d_y, 1, d_ws, stream, real);
+    if (done) (void)hipEventRecord(done, s);
     return rc;
+}
+
+int aks_shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *d_ws, void *stream, int32_t flags) {
+    return shard_apply(A, d_x, d_y, d_ws, stream, flags, nullptr);
 }
 
 int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
@@ -1915,7 +1943,7 @@ int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 
         hipEvent_t done = nullptr;
         if (!(first_w_ready && j == start_dim)) {
             done = pr ? pr->begin(AKS_PROBE_SPMV, s) : nullptr;
-            rc = aks_shard_apply(A, x, w, d_ws, stream, flags);
+            rc = shard_apply(A, x, w, d_ws, stream, flags, pr);
             if (done) (void)hipEventRecord(done, s);
             if (rc != AKS_OK) return rc;
         }

@@ -42,8 +42,10 @@ for _p in (ROOT, os.path.join(ROOT, "arnoldi-py_amd")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CONFIG_OF = {"random": 5, "laplace2d": 2, "laplace3d": 4, "markov": 1, "banded": 3}   # BASELINE.json configs[] (1-based)
-FAKE = os.environ.get("AKS_BENCH_FAKE_DEVICE") == "1"   # CPU rehearsal of the launcher / rank logic (tests only)
+CONFIG_OF = {"random": 5, "laplace2d": 2, "laplace3d": 4, "markov": 1, "banded": 3, "file": 3}   # BASELINE.json configs[] (1-based)
+_FILE_MATRIX = {}   # --matrix: path -> CSR, loaded once per process
+GPU = None     # torch.cuda.is_available(), set by run_rank: the device-timing objects need a GPU (the product
+               # itself refuses to run without one; tests/bench_rehearsal.py drives the launcher / rank logic on CPU)
 
 
 def parse_args(argv=None):
@@ -57,11 +59,16 @@ def parse_args(argv=None):
     ap.add_argument("--per-row", type=int, default=5)
     ap.add_argument("--nev", type=int, default=5)
     ap.add_argument("--max-dim", type=int, default=20)
-    ap.add_argument("--workload", choices=sorted(CONFIG_OF), default="random",
+    ap.add_argument("--workload", choices=sorted(set(CONFIG_OF) - {"file"}), default="random",
                     help="random = BASELINE config 5 (default); laplace2d / laplace3d = configs 2 / 4; "
                          "markov = mark(M) of the reference's README scaled to ~n rows (sorted LR); "
                          "banded = stand-in for config 3 (af_shell10 is not available offline): use "
                          "--n 1500000 --per-row 35 --nev 20 --max-dim 41")
+    ap.add_argument("--matrix", default=None, metavar="FILE",
+                    help="a matrix file (SuiteSparse .mat with Problem.A, MatrixMarket .mtx, scipy .npz) through "
+                         "arnoldi_amd.harness.load_matrix, e.g. af_shell10.mat for BASELINE config 3 (the reference's "
+                         "inputs, scripts/download_matrices.sh; not obtainable offline): becomes the workload, with "
+                         "--nev / --max-dim as given (config 3: --nev 20 --max-dim 41)")
     ap.add_argument("--cpu-sample-n", type=int, default=1_000_000)
     ap.add_argument("--cpu-restarts", type=int, default=3)
     ap.add_argument("--cpu-budget-s", type=float, default=150.0,
@@ -74,7 +81,7 @@ def parse_args(argv=None):
                     help="force the Python-chained stage path on one GPU (the multi-GPU code path)")
     ap.add_argument("--arithmetic", choices=["complex", "real"], default="complex",
                     help="complex = the drop-in path (headline); real = partial_schur(arithmetic='real')")
-    ap.add_argument("--leg", choices=["measure", "cpu"], default=None,
+    ap.add_argument("--leg", choices=["measure", "cpu", "preflight"], default=None,
                     help="(internal) run one extra leg and print its JSON object")
     return ap.parse_args(argv)
 
@@ -96,7 +103,7 @@ def launch_ranks(args, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     failed = None
     line = ""
@@ -142,8 +149,21 @@ def grid_dims(workload, n):
     return (nx, nx + 1, nx + 2)
 
 
+def file_matrix(args):
+    if args.matrix not in _FILE_MATRIX:
+        from arnoldi_amd import harness
+
+        A = harness.load_matrix(args.matrix).tocsr()
+        if A.shape[0] != A.shape[1]:
+            raise SystemExit(f"bench.py: {args.matrix} is {A.shape[0]} x {A.shape[1]}, not square")
+        _FILE_MATRIX[args.matrix] = A
+    return _FILE_MATRIX[args.matrix]
+
+
 def problem_size(args):
     """(n, dims), computed ONCE per process from the arguments: every rank must agree on them."""
+    if args.workload == "file":
+        return file_matrix(args).shape[0], None
     if args.workload in ("random", "banded"):
         return args.n, None
     dims = grid_dims(args.workload, args.n)
@@ -154,6 +174,8 @@ def problem_size(args):
 def build_rows(args, r0, r1, n, dims):
     from arnoldi_amd import matrices
 
+    if args.workload == "file":
+        return file_matrix(args)[r0:r1]
     if args.workload == "random":
         return matrices.random_csr(n, args.per_row, 1234, row_range=(r0, r1))
     if args.workload == "banded":
@@ -196,6 +218,8 @@ def cpu_baseline(args):
     n_full, _ = problem_size(args)
 
     def build(ns):
+        if args.workload == "file":
+            return file_matrix(args), f"{os.path.basename(args.matrix)} (n={n_full})"
         if args.workload == "random":
             return matrices.random_csr(ns, args.per_row, 1234), f"random CSR n={ns} ({args.per_row}/row, same generator)"
         if args.workload == "banded":
@@ -228,7 +252,7 @@ def cpu_baseline(args):
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         blas_threads = len(os.sched_getaffinity(0))
-    ns = min(args.cpu_sample_n, n_full)
+    ns = n_full if args.workload == "file" else min(args.cpu_sample_n, n_full)     # (a file cannot be sampled)
     A, what, per, wall, intervals = timed(ns, 2 if ns < n_full else args.cpu_restarts)
     if per is None:
         return None
@@ -303,7 +327,7 @@ def measure(args, comm, world, rank):
     t_setup = time.perf_counter() - t_setup
 
     def sync():
-        if not FAKE:
+        if GPU:
             torch.cuda.synchronize()
         if comm is not None:
             comm.barrier()
@@ -311,7 +335,7 @@ def measure(args, comm, world, rank):
     sync()
     t0 = time.perf_counter()
     assert solver.start() == m
-    if not FAKE:
+    if GPU:
         torch.cuda.synchronize()
     initial_ms = (time.perf_counter() - t0) * 1e3
 
@@ -320,13 +344,13 @@ def measure(args, comm, world, rank):
         solver.expand()
 
     probe = None
-    if native and not FAKE:
-        probe = _hip.Probe(capacity=2 * m * args.steps + 8)
+    if native and GPU:
+        probe = _hip.Probe(capacity=8 * m * args.steps + 8)
         ctx.probe = probe
-    elif not FAKE:
+    elif GPU:
         ctx.spmv_events = []
-    second0 = int(ctx.last_ctrl.second_passes)
-    steps0 = int(ctx.last_ctrl.steps_done)
+    second0 = int(ctx.last_ctrl.second_passes) - ctx.discarded_second_passes      # (an expansion that had to be
+    steps0 = int(ctx.last_ctrl.steps_done) - ctx.discarded_steps                  # repeated is counted once)
 
     sync()
     t0 = time.perf_counter()
@@ -355,8 +379,8 @@ def measure(args, comm, world, rank):
     spmv_bytes = op.algorithmic_bytes()
     achieved = spmv_bytes / (spmv_avg_ms * 1e-3) / 1e9 if n_spmv and spmv_avg_ms > 0 else None
 
-    steps_done = int(ctx.last_ctrl.steps_done) - steps0
-    seconds = int(ctx.last_ctrl.second_passes) - second0
+    steps_done = int(ctx.last_ctrl.steps_done) - ctx.discarded_steps - steps0
+    seconds = int(ctx.last_ctrl.second_passes) - ctx.discarded_second_passes - second0
     frac_second = seconds / max(steps_done, 1)
     n_panel = ctx.basis.n_rows                      # rows of the panel the Gram-Schmidt kernels see
     per_cycle = 0.0   # Gram-Schmidt bytes of one restart's steps, at the measured second-pass rate
@@ -376,7 +400,8 @@ def measure(args, comm, world, rank):
     # Small problems (kernels of 20-60 us) follow the host's launch latency: the same restarts again with the
     # re-expansion replayed as a hipGraph (AKS_GRAPH=1 of the product: one launch per restart), no probe.
     graph_rate = None
-    if native and not FAKE and comm is None and op.n_local <= 4_000_000:
+    comm_in_graph = comm is not None and os.environ.get("AKS_GRAPH_COMM") == "1" and not getattr(op, "any_exchange", False)
+    if native and GPU and (comm is None or comm_in_graph) and op.n_local <= 4_000_000:
         ctx.probe = None
         was_graph, ctx.use_graph = ctx.use_graph, True
         for i in range(2):
@@ -397,7 +422,17 @@ def measure(args, comm, world, rank):
         exchange = {"ghost_bytes_received_per_spmv_rank0": int(op.n_ghost) * w,
                     "packed_bytes_sent_per_spmv_rank0": int(getattr(op, "n_send", 0)) * w,
                     "collectives_per_arnoldi_step": ctx.collectives_per_step(),
-                    "allreduce_payload_bytes": 16 * (m + 1)}
+                    "allreduce_payload_bytes": 16 * (m + 1), "lazy_redos": ctx.lazy_redos}
+        if probe is not None:
+            # where a sharded SpMV of rank 0 spends its device time (HIP events inside aks_shard_apply): packing the
+            # entries other ranks need; the grouped send / recv (side stream); the diagonal block, which overlaps
+            # it; then the wait for the ghost entries + the off-diagonal block
+            split = {}
+            for key, tag in (("pack", _hip.PROBE_PACK), ("exchange", _hip.PROBE_EXCHANGE), ("diag_block", _hip.PROBE_DIAG),
+                             ("ghost_wait_plus_offdiag_block", _hip.PROBE_OFFDIAG)):
+                k, ms = probe.read(tag)
+                split[key] = round(ms / k, 4) if k else None
+            exchange["spmv_device_ms_rank0"] = split
     res = {
         "value": round(args.steps / elapsed, 4),
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -426,32 +461,40 @@ def spmv_kernel_name(res, world):
     return "k_spmv (CSR-stream SpMV)"
 
 
-def pmc_traffic(res, default_workload):
-    """HBM bytes per SpMV from the committed rocprofv3 --pmc passes of this same command on the default
-    workload (profiles/collect_pmc.sh -> profiles/pmc_summary.json), valid only for the build it was collected
-    on (source stamp).  FETCH_SIZE is doubled for the coalesced streams of the binned kernels (gfx950 counts
-    their 128-B requests as 64 B, MI355X_MICROARCH.md "HBM"); the CSR kernel's 16-B gathers are reported raw."""
-    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if not (default_workload and os.path.exists(path)):
+def pmc_traffic(res, args, world=1):
+    """HBM bytes per SpMV from the committed rocprofv3 --pmc passes of this same command (profiles/collect_pmc.sh ->
+    profiles/pmc_summary.json for the default workload, profiles/pmc_summary_<workload>.json for the others), valid
+    only for the build they were collected on (source stamp) and the sizes they were collected at.  FETCH_SIZE is
+    doubled for coalesced streams (gfx950 counts their 128-B requests as 64 B, MI355X_MICROARCH.md "HBM"): the binned
+    and sliced kernels; the CSR kernel's 16-B gathers are reported raw."""
+    shape = {"random": (10_000_000, 5), "markov": (10_000_000, None), "laplace2d": (1_000_000, None),
+             "banded": (1_500_000, 35), "laplace3d": (16_000_000, None)}.get(args.workload)
+    if shape is None or world != 1 or args.arithmetic != "complex" or args.n != shape[0] or \
+            (shape[1] is not None and args.per_row != shape[1]):
+        return None, None
+    name = "pmc_summary.json" if args.workload == "random" else f"pmc_summary_{args.workload}.json"
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
         return None, None
     try:
         pmc = json.load(open(path))
         stamp = pmc.get("_source_stamp")
         if stamp != source_stamp():
-            return None, f"profiles/pmc_summary.json was collected on another build (stamp {stamp}); not reported"
+            return None, f"profiles/{name} was collected on another build (stamp {stamp}); not reported"
         if res["spmv_form"] == "binned":
             return (pmc["k_pb_phase1"]["hbm_bytes_per_launch_fetch_x2"]
                     + pmc["k_pb_phase2"]["hbm_bytes_per_launch_fetch_x2"]), "rocprofv3 --pmc, same build"
         if res["spmv_form"] == "sliced":
-            return None, "no PMC pass collected for k_sell on this workload"
+            return pmc["k_sell"]["hbm_bytes_per_launch_fetch_x2"], "rocprofv3 --pmc, same build"
         return pmc["k_spmv"]["hbm_bytes_per_launch_raw"], "rocprofv3 --pmc, same build"
     except Exception as e:  # noqa: BLE001
         return None, f"pmc summary unreadable: {e}"
 
 
-def leg_summary(res):
+def leg_summary(res, args):
     """What an extra leg (child process) reports back."""
-    out = {"restarts_per_s": res["value"], "ms_per_step": res["ms_per_step"], "n": res["n"], "nnz": res["nnz_local"],
+    traffic, note = pmc_traffic(res, args)
+    out = {"spmv_traffic_bytes": traffic, "spmv_traffic_source": note, "restarts_per_s": res["value"], "ms_per_step": res["ms_per_step"], "n": res["n"], "nnz": res["nnz_local"],
            "nev": res["nev"], "max_dim": res["m"], "spmv_form": res["spmv_form"],
            "spmv_avg_ms": round(res["spmv_avg_ms"], 4), "spmv_algorithmic_bytes": res["spmv_bytes"],
            "spmv_achieved_GBs": round(res["achieved"], 1) if res["achieved"] else None,
@@ -486,6 +529,105 @@ def run_child(extra_argv, timeout_s):
     return {"error": f"exit status {cp.returncode}: " + " | ".join(tail)}
 
 
+# ------------------------------------------------------------------------------------------- multi-rank preflight
+def preflight_child(args):
+    """``--leg preflight`` (one process per rank, started by ``native_preflight``): the C-driven collective path
+    (aks_arnoldi_expand issuing the ghost exchange and the stage all-reduces on the library's RCCL communicator)
+    against the Python-chained torch.distributed path on two small row-sharded problems -- a random graph (nearly
+    every remote entry is exchanged) and a 2-D Laplacian (every step needs the second DGKS pass: the lazy third
+    all-reduce is found out and the expansion repeated on all ranks).  Prints {"ok": ..} and exits."""
+    import torch
+    import torch.distributed as dist
+    from arnoldi_amd import matrices
+    from arnoldi_amd.dist import Comm, row_offsets
+    from arnoldi_amd.engine import CsrOperator
+    from arnoldi_amd.krylov_schur import KrylovSchurSolver
+    from arnoldi_amd.utils import arg_largest_magnitude
+
+    world, rank, local_rank = (int(os.environ[k]) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    out = {"ok": True, "world": world}
+    cases = (("random", matrices.random_csr(60_000 * world, 5, 7, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5)), 5, 20, 3),
+             ("laplace2d", matrices.laplace2d(200, 40 * world + 1), 6, 24, 2))
+    for name, A, nev, m, restarts in cases:
+        n = A.shape[0]
+        offs = row_offsets(n, world)
+        rows = A[int(offs[rank]): int(offs[rank + 1])]
+        got = {}
+        for path in ("native", "python"):
+            os.environ["AKS_DIST_PATH"] = path
+            comm = Comm(force=(world == 1))
+            op = CsrOperator(local_rows=rows, offsets=offs, comm=comm)
+            np.random.seed(0)
+            solver = KrylovSchurSolver(op, nev, m, min(nev + 5, m - 1), 1e-10, arg_largest_magnitude, comm=comm)
+            solver.start()
+            Hs = [solver.H.copy()]
+            for i in range(restarts):
+                solver.contract(i)
+                solver.expand()
+                Hs.append(solver.H.copy())
+            torch.cuda.synchronize()
+            got[path] = (np.stack(Hs), bool(op.native_comm), int(solver.ctx.lazy_redos), int(op.n_ghost))
+            comm.close()
+        (Hn, nat, redo_n, ghosts), (Hp, nat_p, redo_p, _) = got["native"], got["python"]
+        err = float(np.abs(Hn - Hp).max() / max(np.abs(Hp).max(), 1e-300))
+        ok = nat and not nat_p and err < 1e-12 and redo_n == redo_p and np.isfinite(Hn).all()
+        out[name] = {"ok": bool(ok), "max_rel_diff_H": err, "native_comm": nat, "lazy_redos": redo_n, "n_ghost_rank": ghosts}
+        out["ok"] = out["ok"] and bool(ok)
+    flag = torch.tensor([1 if out["ok"] else 0], device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    out["ok"] = bool(flag.item())
+    dist.barrier()
+    dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def native_preflight(world, rank, local_rank, timeout_s=300):
+    """The C-driven RCCL path has only ever met one GPU per developer box; the first time several GPUs see it is the
+    driver's scaling run.  So before THIS process touches its GPU, every rank starts a child (``--leg preflight``,
+    own rendezvous port, same GPU) that checks the path against the torch.distributed one, with a time-out: a
+    child that fails, hangs or crashes costs a minute, and the measurement then runs on the Python-chained path
+    (all ranks agree through a gloo group that never touches a GPU) instead of taking the whole run down.
+    Returns the verdict dict; sets AKS_DIST_PATH=python if it failed."""
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo")
+    port = [free_port() if rank == 0 else None]
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, MASTER_PORT=str(port[0]), RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world))
+    env.pop("AKS_DIST_PATH", None)
+    verdict = {"ok": False}
+    t0 = time.perf_counter()
+    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--leg", "preflight"], env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        so, se = proc.communicate(timeout=timeout_s)
+        for ln in reversed(so.splitlines()):
+            if ln.startswith("{"):
+                verdict = json.loads(ln)
+                break
+        else:
+            verdict = {"ok": False, "error": f"exit status {proc.returncode}: " + " | ".join((se or so).strip().splitlines()[-3:])}
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        verdict = {"ok": False, "error": f"timed out after {timeout_s} s"}
+    import torch
+
+    flag = torch.tensor([1 if verdict.get("ok") else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    verdict["all_ranks_ok"] = bool(flag.item())
+    verdict["seconds"] = round(time.perf_counter() - t0, 1)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not verdict["all_ranks_ok"]:
+        os.environ["AKS_DIST_PATH"] = "python"
+        sys.stderr.write(f"bench.py: rank {rank}: native RCCL preflight failed ({verdict}); using AKS_DIST_PATH=python\n")
+    return verdict
+
+
 # ------------------------------------------------------------------------------------------- rank main
 def emit(line):
     """The ONE line of this process on the real stdout (fd 1 is pointed at stderr while the rank runs, so that
@@ -513,13 +655,19 @@ def run_rank(args, argv):
     # AKS_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path with all ranks sharing the visible GPU(s)
     # (collectives staged through host memory); the measured numbers then mean nothing.
     backend = os.environ.get("AKS_BENCH_BACKEND", "nccl")
-    if FAKE:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import fake_hip          # TEST INFRASTRUCTURE: NumPy stand-in for the device entry points
-
-        fake_hip.install()
-        backend = "gloo"
-    else:
+    forced = os.environ.get("AKS_FORCE_COMM") == "1"
+    preflight = None
+    if ((world > 1 or forced) and backend == "nccl" and "AKS_DIST_PATH" not in os.environ
+            and os.environ.get("AKS_BENCH_PREFLIGHT", "1") != "0" and args.leg is None
+            and torch.cuda.device_count() > 0):          # (device_count does not initialise the GPU)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
+        preflight = native_preflight(world, rank, local_rank)
+    global GPU
+    GPU = torch.cuda.is_available()
+    if GPU:
         if backend != "nccl":
             local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
@@ -546,15 +694,13 @@ def run_rank(args, argv):
     res = measure(args, comm, world, rank)
 
     if args.leg == "measure":                      # child process of a one-GPU run: report and leave
-        emit(json.dumps(leg_summary(res)))
+        emit(json.dumps(leg_summary(res, args)))
         return 0
 
     out = None
     if rank == 0:
         n, m, p, nev = res["n"], res["m"], res["p"], res["nev"]
-        default_workload = (args.workload == "random" and n == 10_000_000 and world == 1
-                            and args.arithmetic == "complex" and args.per_row == 5)
-        traffic, traffic_note = pmc_traffic(res, default_workload)
+        traffic, traffic_note = pmc_traffic(res, args, world)
         achieved, spmv_bytes = res["achieved"], res["spmv_bytes"]
         out = {
             "metric": "krylov_restarts_per_sec",
@@ -568,9 +714,10 @@ def run_rank(args, argv):
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "complex128" if args.arithmetic == "complex" else "float64",
-            "data": "synthetic" if not FAKE else "rehearsal (NumPy stand-in for the device, numbers meaningless)",
+            "data": "synthetic" if args.matrix is None else f"file {os.path.basename(args.matrix)}",
             "config": {
-                "workload": (f"{args.workload} CSR n={n} nnz={res['nnz_local'] if world == 1 else 'sharded'} "
+                "workload": ((f"{os.path.basename(args.matrix)}" if args.matrix else f"{args.workload} CSR")
+                             + f" n={n} nnz={res['nnz_local'] if world == 1 else 'sharded'} "
                              f"(BASELINE config {CONFIG_OF[args.workload]} shape), "
                              f"partial_schur k={nev} max_dim={m} p={p}, "
                              f"1 step = 1 Krylov-Schur restart ({m - p} Arnoldi steps + host Schur + truncation)"),
@@ -580,6 +727,7 @@ def run_rank(args, argv):
                           + (", RCCL all-reduces and ghost exchange issued from C" if res["exchange"] or comm_forced else ""))
                          if res["native"] else "python-chained stages + torch.distributed collectives"),
                 "exchange": res["exchange"],
+                "native_preflight": preflight,
             },
             "initial_expand_ms": round(res["initial_ms"], 2),
             "setup_s": round(res["setup_s"], 2),
@@ -621,7 +769,7 @@ def run_rank(args, argv):
         dist.destroy_process_group()
 
     # ---- extra legs (one GPU only): child processes, after this process has released the GPU memory
-    if rank == 0 and world == 1 and not FAKE:
+    if rank == 0 and world == 1 and GPU:
         import gc
 
         gc.collect()
@@ -651,7 +799,8 @@ def run_rank(args, argv):
                     legs.append(leg)
                 out["workloads"] = legs
         if not args.no_cpu_baseline:
-            leg = run_child(["--leg", "cpu", "--workload", args.workload, "--rows", str(args.n), "--per-row",
+            leg = run_child((["--matrix", args.matrix] if args.matrix else []) +
+                            ["--leg", "cpu", "--workload", "random" if args.matrix else args.workload, "--rows", str(args.n), "--per-row",
                              str(args.per_row), "--nev", str(args.nev), "--max-dim", str(args.max_dim),
                              "--cpu-sample-n", str(args.cpu_sample_n), "--cpu-restarts", str(args.cpu_restarts),
                              "--cpu-budget-s", str(args.cpu_budget_s)], 900)
@@ -664,9 +813,13 @@ def run_rank(args, argv):
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
+    if args.matrix is not None:
+        args.workload = "file"
     if args.leg == "cpu":
         print(json.dumps(cpu_baseline(args)), flush=True)
         return 0
+    if args.leg == "preflight":
+        return preflight_child(args)
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, argv)
     return run_rank(args, argv)

@@ -390,6 +390,13 @@ int aks_scale(int64_t n_rows, aks_c128 *d_w, double alpha_re, double alpha_im, v
  * sum of their elapsed times in milliseconds. */
 #define AKS_PROBE_SPMV 0
 #define AKS_PROBE_ORTHO 1
+/* inside a sharded SpMV (communicator with an exchange): packing the entries other ranks need; the grouped
+ * send / recv (recorded on the communicator's side stream); the diagonal block; waiting for the ghost entries
+ * + the off-diagonal block.  PACK + max(EXCHANGE, DIAG) + the off-diagonal kernel ~ the SPMV pair. */
+#define AKS_PROBE_PACK 2
+#define AKS_PROBE_EXCHANGE 3
+#define AKS_PROBE_DIAG 4
+#define AKS_PROBE_OFFDIAG 5
 int aks_probe_create(int32_t capacity, void **probe_out);
 int aks_probe_destroy(void *probe);
 int aks_probe_reset(void *probe);

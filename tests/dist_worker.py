@@ -30,7 +30,14 @@ def main():
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--device", default="cpu")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--native-mock", action="store_true",
+                    help="(with --device cuda) the C-DRIVEN multi-rank path: the library's own communicator, RCCL "
+                         "replaced by tests/mock_rccl (shared memory), because the ranks share one GPU")
     args = ap.parse_args()
+    if args.native_mock:           # before arnoldi_amd is imported: _hip reads AKS_LIB_PATH at import
+        os.environ["AKS_LIB_PATH"] = os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so")
+        os.environ["AKS_COMM_OVER_GLOO"] = "1"
+        os.environ["AKS_GRAPH"] = "0"          # the stand-in synchronises streams: nothing to capture
 
     dist.init_process_group(args.backend)
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -74,6 +81,7 @@ def main():
             "lazy_redos": int(stats["solver"].ctx.lazy_redos),
             "second_passes": int(stats["second_passes"]),
             "collectives_per_step": int(stats["solver"].ctx.collectives_per_step()),
+            "native_comm": bool(getattr(stats["solver"].op, "native_comm", False)),
         }
 
     LR, LM = oracle.arg_largest_real, oracle.arg_largest_magnitude

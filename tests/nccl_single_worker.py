@@ -134,6 +134,25 @@ def main(out_path):
         ref = D @ xh + O @ xh[send_idx]
         res["self_exchange_real" if real else "self_exchange"] = float(np.abs(y.cpu().numpy() - ref).max()
                                                                        / max(np.abs(ref).max(), 1e-300))
+    # a whole solve with the re-expansions replayed as hipGraphs that contain the RCCL all-reduces: the same bits
+    # as the eager launch sequence (AKS_GRAPH is read when the context is made)
+    # (opt-in, AKS_GRAPH_COMM=1, and only for sequences without a ghost exchange: ending the capture of a grouped
+    # ncclSend / ncclRecv forked onto the communicator's side stream crashed inside hipStreamEndCapture on
+    # ROCm 7.2 / RCCL 2.26 -- round 3, this worker)
+    graph = {}
+    os.environ["AKS_GRAPH_COMM"] = "1"
+    for mode in ("0", "1"):
+        os.environ["AKS_GRAPH"] = mode
+        np.random.seed(0)
+        st4 = {}
+        Q4, T4, hist4 = partial_schur(L, 10, max_dim=40, sort_function=oracle.arg_largest_magnitude, comm=comm, stats=st4)
+        graph[mode] = (Q4, T4, hist4.restarts.copy(), len(st4["solver"].ctx._graphs), bool(st4["solver"].op.native_comm))
+    del os.environ["AKS_GRAPH"], os.environ["AKS_GRAPH_COMM"]
+    res["graph_with_comm"] = {"bit_identical": bool(np.array_equal(graph["0"][0], graph["1"][0])
+                                                    and np.array_equal(graph["0"][1], graph["1"][1])
+                                                    and np.array_equal(graph["0"][2], graph["1"][2])),
+                              "graphs_eager": graph["0"][3], "graphs_replayed": graph["1"][3],
+                              "native_comm": graph["1"][4]}
     # the library's own all-reduce entry point on a float64 view inside a byte buffer
     view.copy_(torch.arange(42, dtype=torch.float64, device="cuda"))
     _hip.check(_hip.load().aks_comm_allreduce_sum(comm.native(), dev._ptr(view), 42, dev._stream()), "allreduce")

@@ -1,6 +1,7 @@
 """bench.py as the driver runs it: ``python bench.py --gpus N`` must start its own N ranks (VERDICT r01:
-`assert world == args.gpus` killed it).  Rehearsed here on CPU: AKS_BENCH_FAKE_DEVICE=1 swaps the device
-entry points for tests/fake_hip.py (test infrastructure) and the ranks talk over gloo."""
+`assert world == args.gpus` killed it).  Rehearsed here on CPU through tests/bench_rehearsal.py, which swaps the device
+entry points for tests/fake_hip.py (test infrastructure), makes the ranks talk over gloo and runs bench.main()
+unchanged; bench.py itself carries no test double."""
 import json
 import os
 import subprocess
@@ -10,11 +11,16 @@ from conftest import ROOT
 
 
 def _run(extra, timeout=600):
-    env = dict(os.environ, AKS_BENCH_FAKE_DEVICE="1", OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
-                          timeout=timeout, env=env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_rehearsal.py")] + extra, capture_output=True,
+                          text=True, timeout=timeout, env=env)
+
+
+def test_bench_carries_no_test_double():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "fake_hip" not in src and "FAKE" not in src
 
 
 def test_bench_starts_its_own_ranks():
@@ -40,7 +46,7 @@ def test_bench_reports_a_failed_rank():
 
 
 def test_bench_refuses_a_half_launched_world():
-    env = dict(os.environ, AKS_BENCH_FAKE_DEVICE="1", WORLD_SIZE="1", RANK="0")
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "5000"],
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--gpus", "2", "--rows", "5000"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr

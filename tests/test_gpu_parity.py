@@ -7,6 +7,8 @@ relative), and solver-level results by the north_star criterion: same restart
 count, eigenvalues to 1e-9, and  max_k ||A v_k - l_k v_k|| / |l_k|  <= 1.05 x the
 reference's own residual (with a 1e-13 floor for residuals at rounding level).
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -750,6 +752,23 @@ def test_row_sharded_two_ranks_share_the_gpu(amd, tmp_path):
     check_dist_verdicts(run_dist_worker(tmp_path, 2, "gloo", "cuda"))
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_row_sharded_c_driven_path_ranks_share_the_gpu(amd, tmp_path, ranks):
+    """The C-DRIVEN multi-rank path -- aks_arnoldi_expand issuing the ghost exchange (grouped send / recv on the
+    side stream, peer offsets from send_counts / recv_counts) and the stage all-reduces itself, the lazy third
+    all-reduce and its redo across ranks -- with 2 and 3 ranks on GPU 0 and the real kernels.  RCCL cannot put
+    two ranks on one device, so the library is built against tests/mock_rccl: a shared-memory stand-in that
+    aborts on any mismatch of call order, peer or message size between the ranks.  Same cases and bars as the
+    gloo runs (History equal to the oracle's, residuals, device-side residuals, mismatched shards)."""
+    import subprocess
+
+    from test_host_logic import ROOT, check_dist_verdicts, run_dist_worker
+
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    check_dist_verdicts(run_dist_worker(tmp_path, ranks, "gloo", "cuda", extra=["--native-mock"]), native=True)
+
+
 def test_rccl_collectives_one_rank(amd, tmp_path):
     """The collectives of the multi-rank path issued through RCCL (torch 'nccl') on a one-rank
     group, real kernels: workspace-slot all-reduces, uneven all-to-all incl. empty messages, the
@@ -779,6 +798,10 @@ def test_rccl_collectives_one_rank(amd, tmp_path):
     lp = r["laplace"]
     assert lp["restarts_equal"] and lp["eig_err"] < 1e-9 and lp["lazy_redos"] == 1 and lp["collectives_per_step"] == 3
     assert r["self_exchange"] < 1e-14 and r["self_exchange_real"] < 1e-14 and r["native_allreduce_ok"]
+    # hipGraph capture with the communicator's all-reduces in the sequence (AKS_GRAPH_COMM=1): a whole solve whose
+    # re-expansions are replayed, bit for bit the eager one
+    gc_ = r["graph_with_comm"]
+    assert gc_["bit_identical"] and gc_["native_comm"] and gc_["graphs_eager"] == 0 and gc_["graphs_replayed"] >= 1, gc_
 
 
 def test_graph_replay_gives_identical_results(amd, monkeypatch):

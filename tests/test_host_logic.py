@@ -379,21 +379,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_dist_worker(tmp_path, nproc, backend, device, timeout=600):
+def run_dist_worker(tmp_path, nproc, backend, device, timeout=600, extra=()):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["OMP_NUM_THREADS"] = "2"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "dist_worker.py"), "--backend", backend, "--device", device,
-           "--out", str(tmp_path)]
+           "--out", str(tmp_path)] + list(extra)
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     return [json.load(open(os.path.join(tmp_path, f"rank{r}.json"))) for r in range(nproc)]
 
 
-def check_dist_verdicts(verdicts):
+def check_dist_verdicts(verdicts, native=False):
     for v in verdicts:
+        assert all(c["native_comm"] == native for c in v.values() if "native_comm" in c), "unexpected collective path"
+        for c in v.values():
+            c.pop("native_comm", None)
         mm = v.pop("mismatch")
         assert mm["size"].startswith("ValueError: row shards disagree"), mm
         assert mm["offsets"].startswith("ValueError: row shards disagree"), mm
