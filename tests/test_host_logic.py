@@ -443,6 +443,21 @@ def test_row_sharded_solve_two_ranks_gloo(tmp_path):
     check_dist_verdicts(run_dist_worker(tmp_path, 2, "gloo", "cpu"))
 
 
+def test_host_planners_under_address_and_ub_sanitizers():
+    """tests/asan: the library source with -fsanitize=address,undefined on its host code (CPU build; the pool has no
+    GPU ASan), driven through every host-side planner entry point on the shapes of the SpMV form tests plus
+    degenerate ones; every planned array is compared with the matrix it came from."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "asan")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    exe = os.path.join(ROOT, "tests", "asan", "planner_asan")
+    syms = subprocess.run(["nm", exe], capture_output=True, text=True).stdout
+    assert "__asan_report_load" in syms and "__ubsan_handle" in syms          # the instrumentation is really in
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "all planner checks passed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
 # ---------------------------------------------------------------------------- tile-binned SpMV form
 @pytest.mark.parametrize("shape,complex_vals", [((5000, 5000), False), ((3000, 200_000), True), ((70_000, 900), False),
                                                 ((20_000, 20_000), False),
