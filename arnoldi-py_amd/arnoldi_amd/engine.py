@@ -453,6 +453,12 @@ class ArnoldiContext:
         res = self.residual_norms(vecs, vals)
         return vals, res, res / np.abs(vals)
 
+    def residual_norms_real_pairs(self, k, S, vals):
+        """``||A u_i - vals[i] u_i||`` for ``u_i = V[:, :k] @ S[:, i]`` on a real-packed basis (``S`` complex: each
+        eigenvector is a pair of real combinations of the real basis columns)."""
+        assert self.real
+        return self._residual_norms_real(k, S, vals)
+
     def _residual_norms_real(self, k, S, vals):
         """Real-packed basis (``Q`` real, eigenvectors ``u = Q S`` complex): with ``u = ur + i ui``,
         ``ur = Q Re S`` and ``ui = Q Im S`` are two real combinations (``aks_combine`` with real coefficients),
@@ -526,23 +532,36 @@ class ArnoldiContext:
                                       dev._ptr(Sd), dev._stream())
         _hip.check(rc, "aks_truncate")
 
+    def ritz_vectors_into_first(self, k, m, S):
+        """``V[:, k:k+q] = V[:, k:m] @ S`` in place for a few (q >= 1) coefficient columns -- the two real vectors
+        that span a conjugate pair's invariant subspace in the real-arithmetic explicit-restart solver."""
+        b = self.basis
+        S = np.ascontiguousarray(np.asarray(S, dtype=C128).reshape(m - k, -1))
+        q = S.shape[1]
+        assert 1 <= q <= m - k
+        Sd = torch.from_numpy(S).to(b.device)
+        rc = _hip.load().aks_truncate(b.n_rows, m - k, q, b.V.data_ptr() + 16 * b.ldv * k, b.ldv,
+                                      dev._ptr(Sd), dev._stream())
+        _hip.check(rc, "aks_truncate")
+
     def _scratch_col(self):
         if getattr(self, "_scratch", None) is None:
             self._scratch = dev.DeviceColumns(self.basis.n_rows, 1, self.basis.device)
         return self._scratch.col(0)
 
-    def rayleigh_column(self, k):
-        """``[vdot(V[:, i], A @ V[:, k]) for i <= k]`` (explicit_restarts.py:149-150): one operator
-        application into a scratch column and one (k+1)-column projection."""
+    def rayleigh_column(self, k, ncols=None):
+        """``[vdot(V[:, i], A @ V[:, k]) for i < ncols]`` (default ``ncols = k + 1``: explicit_restarts.py:149-150):
+        one operator application into a scratch column and one ``ncols``-column projection."""
         b, ws = self.basis, self.ws
+        ncols = k + 1 if ncols is None else int(ncols)
         self._clear_ctrl()
         y = self._scratch_col()
         self.op.apply(b.col(k), y, ws)
-        dev.gs_project(b, k + 1, y, ws)
-        red = ws.red(1, k + 2)
+        dev.gs_project(b, ncols, y, ws)
+        red = ws.red(1, ncols + 1)
         if self._multi():
             self.comm.allreduce_sum_(red)
-        return red[: 2 * (k + 1)].cpu().numpy().view(C128).copy()
+        return red[: 2 * ncols].cpu().numpy().view(C128).copy()
 
     def residual_norms(self, block, values, j0=0):
         """``||A u_i - values[i] u_i||`` for the device columns ``u_i = block.col(j0 + i)`` (``block`` is
@@ -550,12 +569,14 @@ class ArnoldiContext:
         decomposition.py:134-146: operator application into a scratch column, then
         ``aks_gs_update_project`` with J = 1 and coefficient values[i], whose norm output is
         ``||A u_i - values[i] u_i||^2``."""
-        if self.real:
-            raise NotImplementedError("real-packed basis: use true_residuals() (eigenvectors are complex pairs of "
-                                      "real-packed columns)")
+        values = np.atleast_1d(np.asarray(values, dtype=C128))
+        if self.real and values.imag.any():
+            # a real-packed column is a REAL vector: it can only be an eigenvector of a real eigenvalue
+            raise ValueError("real-packed basis: the columns are real vectors, so the values must be real; the "
+                             "residuals of complex eigenpairs (pairs of real-packed columns) come from "
+                             "residual_norms_real_pairs() / true_residuals()")
         b, ws, lib = self.basis, self.ws, _hip.load()
         self._clear_ctrl()
-        values = np.atleast_1d(np.asarray(values, dtype=C128))
         lam = torch.from_numpy(values).to(b.device).view(torch.float64)
         y = self._scratch_col()
         red1, red2 = ws.red(1, 1), ws.red(2, 2)

@@ -91,14 +91,17 @@ def naive_explicit_restarts(A, m=None, *, stopping_criterion=None, max_restarts=
 
 
 def explicit_restarts_with_deflation(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts=100,
-                                     sort_function=None, comm=None, device=None, gather=True, stats=None):
+                                     sort_function=None, comm=None, device=None, gather=True, stats=None,
+                                     arithmetic="complex"):
     """``nev`` eigenpairs one after the other; converged Schur vectors stay locked in the first
     columns of the basis (explicit_restarts.py:81-168).  Returns ``(eigenvalues, eigenvectors,
     history)``; raises ``ValueError("Could not converge for value k")`` like the reference.
 
     Extra keyword-only arguments as in ``partial_schur``: ``comm`` / ``device`` (row-sharded multi-GPU
     solve), ``gather`` (full eigenvectors on every rank, or this rank's rows), ``stats`` (dict that
-    receives the true operator-application count and the context).
+    receives the true operator-application count and the context); ``arithmetic="real"``: for a real matrix, iterate
+    on a real-packed basis (half the memory traffic) -- real Ritz values as in the reference, a complex Ritz value
+    together with its conjugate as two real Schur vectors (see ``_deflation_real``).
     """
     tol = _tolerance(A, stopping_criterion)
     if sort_function is None:
@@ -110,6 +113,11 @@ def explicit_restarts_with_deflation(A, nev, *, max_dim=None, stopping_criterion
         max_dim = min(max(2 * nev + 1, 20), n)
     if comm is None:
         comm = default_comm()
+    assert arithmetic in ("complex", "real")
+    if arithmetic == "real":
+        if np.issubdtype(np.dtype(A.dtype), np.complexfloating):
+            raise ValueError("arithmetic='real' needs a real matrix")
+        return _deflation_real(A, nev, max_dim, float(tol), max_restarts, sort_function, comm, device, gather, stats)
     op = as_operator(A, comm=comm, device=device)
     ctx = ArnoldiContext(op, max_dim, device)
     H = np.zeros((max_dim + 1, max_dim), dtype=WORK_DTYPE)
@@ -155,3 +163,83 @@ def explicit_restarts_with_deflation(A, nev, *, max_dim=None, stopping_criterion
     if comm is not None and comm.size > 1 and not gather:
         return eivals, np.asfortranarray(block.get_cols()), history
     return eivals, ctx.gather_block(block), history
+
+
+def _deflation_real(A, nev, max_dim, tol, max_restarts, sort_function, comm, device, gather, stats):
+    """Explicit restarts with deflation in real arithmetic (real-packed basis, real H).
+
+    Same outer structure as the reference's solver: Arnoldi from the locked columns, pick the wanted Ritz value of
+    the active block, restart from its Ritz vector, lock on convergence.  A REAL wanted Ritz value is handled
+    exactly as in the reference.  A COMPLEX one comes with its conjugate: the real and imaginary parts of its Ritz
+    vector span the pair's invariant subspace, so the restart continues from the (real) real part, and on
+    convergence BOTH are orthonormalised and locked -- two Schur vectors, a 2x2 diagonal block of the real
+    quasi-triangular ``H[:K, :K]``.  The pair counts as two of the ``nev`` wanted values; if that makes
+    ``K = nev + 1`` the member with negative imaginary part is dropped from the returned eigenpairs."""
+    n = A.shape[0]
+    if max_dim < nev + 2:
+        raise ValueError("arithmetic='real' needs max_dim >= nev + 2")
+    op = as_operator(A, comm=comm, device=device, real=True)
+    ctx = ArnoldiContext(op, max_dim, device)
+    H = np.zeros((max_dim + 1, max_dim), dtype=np.float64)
+    history = History.from_k(nev)
+    extra_applies = 0
+    k = 0
+    while k < nev:
+        v0 = rand_normalized_vector(n).real                   # the reference's draw is real-valued
+        ctx.basis.set_col(k, np.ascontiguousarray(v0[op.r0: op.r1]))
+        ctx.mgs(k, k, tol)
+        for restart in range(max_restarts):
+            m = ctx.expand(H, k, max_dim, tol)
+            assert m > k
+            happy_breakdown = m != max_dim
+            matvecs = restart * (max_dim - k) + (m - k)
+            vals, S = np.linalg.eig(H[k:m, k:m])
+            i0 = sort_function(vals)[0]
+            theta, s = vals[i0], S[:, i0]
+            pair = theta.imag != 0.0 and m - k >= 2
+            approx = np.abs(H[m, m - 1] * s[-1])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                has_converged = happy_breakdown or (approx / np.abs(theta) < tol)
+            if pair:
+                ctx.ritz_vectors_into_first(k, m, np.stack([s.real, s.imag], axis=1))
+                ctx.mgs(k, k, tol)
+                if has_converged:
+                    ctx.mgs(k + 1, k + 1, tol)
+            else:
+                ctx.ritz_vector_into_first(k, m, s.real)
+                ctx.mgs(k, k, tol)
+            if has_converged:
+                width = 2 if pair else 1
+                for c in range(width):
+                    col = ctx.rayleigh_column(k + c, k + width).real       # projections on all locked columns
+                    H[: k + width, k + c] = col
+                    H[k + width:, k + c] = 0.0
+                extra_applies += width
+                history.matvecs[k: k + width] = matvecs
+                history.restarts[k: k + width] = restart + 1
+                k += width
+                break
+        else:
+            raise ValueError(f"Could not converge for value {k}")
+
+    K = k
+    eivals, Y = np.linalg.eig(H[:K, :K])
+    keep = np.arange(K)
+    if K > nev:                                               # the last locked block is a pair: drop its lower member
+        tail = np.linalg.eigvals(H[K - 2: K, K - 2: K])
+        lower = tail[np.argmin(tail.imag)]
+        keep = np.delete(keep, int(np.argmin(np.abs(eivals - lower))))
+    eivals, Y = eivals[keep], Y[:, keep]
+    block_re, block_im = ctx.combine(0, K, Y.real), ctx.combine(0, K, Y.imag)
+    if stats is not None:
+        stats.update(matvecs=ctx.matvecs + extra_applies, ctx=ctx, H=H, tol=float(tol), max_dim=int(max_dim),
+                     locked=K, schur_coefficients=Y, eigenvectors_device_real_imag=(block_re, block_im))
+
+    def host(block):                                          # real-packed columns -> float64 rows of this rank
+        loc = np.ascontiguousarray(block.V[:, : ctx.basis.n_rows].cpu().numpy()).view(np.float64)[:, : ctx.basis.n_real].T
+        if comm is not None and comm.size > 1 and gather:
+            return np.asfortranarray(comm.allgather_rows(np.ascontiguousarray(loc)))
+        return np.asfortranarray(loc)
+
+    vecs = host(block_re) + 1j * host(block_im)
+    return eivals, np.asfortranarray(vecs), history

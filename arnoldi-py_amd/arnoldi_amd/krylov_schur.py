@@ -171,23 +171,21 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
         real_matrix = not np.issubdtype(np.dtype(A.dtype), np.complexfloating)
         real_start = v0 is None or not (np.iscomplexobj(v0) and np.asarray(v0).imag.any())
         csr_able = (A.real if isinstance(A, CsrOperator) else _dev.canonical_csr(A) is not None)
-        arithmetic = ("real" if (real_matrix and real_start and csr_able and on_breakdown == "raise"
-                                 and max_dim >= nev + 2) else "complex")
+        arithmetic = "real" if (real_matrix and real_start and csr_able and max_dim >= nev + 2) else "complex"
 
     if comm is None:
         comm = default_comm()
-    if arithmetic == "real" and locking:
-        raise ValueError("locking=True is implemented for arithmetic='complex'")
     if arithmetic == "real":
-        from .krylov_schur_real import RealKrylovSchurSolver
+        from .krylov_schur_real import RealKrylovSchurSolver, RealLockingKrylovSchurSolver
 
         if np.issubdtype(np.dtype(A.dtype), np.complexfloating):
             raise ValueError("arithmetic='real' needs a real matrix")
-        if on_breakdown != "raise":
-            raise ValueError("on_breakdown='deflate' is only implemented for arithmetic='complex'")
         if max_dim < nev + 2:      # room to keep the partner of a conjugate pair cut at nev
             raise ValueError("arithmetic='real' needs max_dim >= nev + 2")
-        solver = RealKrylovSchurSolver(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)
+        if locking and on_breakdown != "raise":
+            raise ValueError("on_breakdown='deflate' is not implemented together with locking=True")
+        cls = RealLockingKrylovSchurSolver if locking else RealKrylovSchurSolver
+        solver = cls(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)
     elif locking:
         from .krylov_schur_locking import LockingKrylovSchurSolver
 

@@ -147,6 +147,28 @@ class RealKrylovSchurSolver:
         self.p_now, self.nev_now = p, nev_now
         return bool(np.all(estimate[:nev_now] < self.tol))
 
+    def contract_invariant(self, restart):
+        """Happy breakdown (``A V_m = V_m H_m`` to the invariance tolerance, ``m < max_dim``): the eigenvalues of
+        ``H[:m, :m]`` are eigenvalues of A.  Rotate the wanted ``nev`` real Schur vectors (one more if that
+        completes a conjugate pair) to the front and stop -- ``on_breakdown="deflate"``, as the complex driver."""
+        H, m, nev = self.H, self.m, self.nev
+        if m < nev:
+            raise ValueError(f"Happy breakdown: invariant subspace of dimension {m} < nev = {nev}")
+        T, Z = scipy.linalg.schur(H[:m, :m], output="real")
+        T, Z = reorder_real_schur(T, Z, self.sort_function)
+        k = nev
+        if 0 < k < m and T[k, k - 1] != 0.0:              # never cut a 2x2 block
+            k += 1
+        self.ctx.truncate(Z[:, :k], m, k)
+        H[:] = 0.0
+        H[:k, :k] = T[:k, :k]
+        self.history.matvecs[:] = self.ctx.matvecs
+        self.history.restarts[:] = restart + 1
+        self.restarts_run = restart + 1
+        self.estimate = np.zeros(k)
+        self.p_now = self.nev_now = k
+        return True
+
     def expand(self):
         self.m = self.ctx.expand(self.H, self.p_now, self.max_dim, self.tol, lookahead=True,
                                  consume_lookahead=True)
@@ -172,3 +194,88 @@ class RealKrylovSchurSolver:
         Tc, U = scipy.linalg.rsf2csf(self.H[:k, :k].copy(), np.eye(k))
         Q = Qr @ U
         return np.asfortranarray(Q[:, : self.nev]), np.array(Tc[: self.nev, : self.nev]), self.history
+
+
+class RealLockingKrylovSchurSolver(RealKrylovSchurSolver):
+    """Locking and a dynamic restart size (krylov_schur_locking.py) on the real-packed basis: only the active
+    block ``S = H[l:m, l:m]`` is rotated (real Schur form, ``dtrexc`` by the caller's sort key); converged leading
+    1x1 / 2x2 blocks are locked as a whole (a conjugate pair locks, and counts, as two columns), the restart
+    compression multiplies the active columns only, and neither ``l`` nor ``p`` ever cuts a pair."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.p0 = self.p
+        self.locked = 0
+        self.trunc_bytes = []
+        self.locked_history = []
+
+    def contract(self, restart):
+        H, m, nev, l, tol = self.H, self.m, self.nev, self.locked, self.tol
+        T, Z = scipy.linalg.schur(H[l:m, l:m], output="real")
+        T, Z = reorder_real_schur(T, Z, self.sort_function)
+        ma = m - l
+        blocks = real_blocks(T)
+        ev = block_eigenvalues(T, blocks)
+        beta = H[m, m - 1]
+        tail = np.abs(Z[-1, :])
+        for s, size in blocks:
+            if size == 2:
+                tail[s] = tail[s + 1] = np.hypot(Z[-1, s], Z[-1, s + 1])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            estimate = np.abs(beta) * tail / np.abs(ev)
+
+        newly = 0                                           # lock leading wanted blocks, whole blocks only
+        for s, size in blocks:
+            if l + newly >= nev or not np.all(estimate[s: s + size] < tol):
+                break
+            newly += size
+        l_new = l + newly
+        done = l_new >= nev
+
+        def no_cut(k):                                      # a boundary inside the active block must not split a pair
+            if 0 < k < ma and T[k, k - 1] != 0.0:
+                return k + 1 if k + 1 < ma else k - 1
+            return k
+
+        p_new = min(self.p0 + min(l_new, (self.max_dim - self.p0) // 2), m - 1)
+        p_new = max(p_new, l_new + 1) if not done else max(p_new, l_new)
+        pa = no_cut(p_new - l)
+        pa = max(pa, newly)
+        p_new = l + pa
+        assert l_new <= p_new <= m - 1 or (done and p_new <= m)
+
+        Zp = Z[:, :pa]
+        self.ctx.truncate_active(Zp, l, m, p_new)           # V[:, l:p_new] = V[:, l:m] Zp ; V[:, p_new] = V[:, m]
+        self.trunc_bytes.append(16 * self.ctx.basis.n_rows * (ma + pa + 2))
+        R = H[:l, l:m].copy()
+        coupling = beta * Z[-1, :pa]
+        H[:l, l:p_new] = R @ Zp
+        H[l:p_new, l:p_new] = T[:pa, :pa]
+        H[p_new:, :p_new] = 0.0
+        H[p_new, l:p_new] = coupling
+        H[p_new, l:l_new] = 0.0                              # deflation: |coupling| < tol |theta|
+        H[:, p_new:] = 0.0
+
+        under = np.zeros(nev, bool)
+        under[: min(l_new, nev)] = True
+        k_act = max(min(nev - l, len(estimate)), 0)
+        under[l: l + k_act] |= estimate[:k_act] <= tol
+        first = under & (self.history.restarts == 0)
+        self.history.matvecs[first] = self.ctx.matvecs
+        self.history.restarts[first] = restart + 1
+        self.restarts_run = restart + 1
+        est = np.zeros(max(nev, l_new))
+        est[l: l + k_act] = estimate[:k_act]
+        self.estimate = est
+        self.locked = l_new
+        self.p_now = p_new
+        # the columns returned: nev, or one more when a locked / leading pair straddles position nev
+        k_out = max(nev, l_new) if done else nev
+        if not done and l <= nev - 1 < l + ma - 1 and T[nev - l, nev - l - 1] != 0.0:
+            k_out = nev + 1
+        self.nev_now = k_out
+        self.locked_history.append(l_new)
+        return done
+
+    def contract_invariant(self, restart):
+        raise ValueError("Happy breakdown with locking=True is not supported; use locking=False")

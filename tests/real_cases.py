@@ -154,3 +154,112 @@ def check_reorder_real_schur():
             score = np.abs(ev) if key is oracle.arg_largest_magnitude else ev.real
             best = [max(score[s: s + size]) for s, size in real_blocks(T)]
             assert all(best[i] >= best[i + 1] - 1e-9 for i in range(len(best) - 1)), best
+
+
+# ---- the real-arithmetic counterparts of the widened solvers ("real-arithmetic islands") ----------------
+def check_locking_real(A, nev, seed, **kw):
+    """partial_schur(arithmetic="real", locking=True) against the oracle of the reference's algorithm."""
+    import arnoldi_amd
+
+    np.random.seed(seed)
+    st = {}
+    Q, T, hist = arnoldi_amd.partial_schur(A, nev, arithmetic="real", locking=True, stats=st, max_restarts=3000, **kw)
+    np.random.seed(seed)
+    Qo, To, histo = oracle.krylov_schur(A, nev, max_restarts=3000, **kw)
+    tol = float(st["tol"])
+    assert st["arithmetic"] == "real" and st["locked"] >= nev and Q.shape == (A.shape[0], nev)
+    assert _match(np.diag(T), np.diag(To)) < 10 * tol * max(1.0, np.abs(np.diag(To)).max()), (np.diag(T), np.diag(To))
+    assert np.abs(np.tril(T, -1)).max() == 0.0
+    np.testing.assert_allclose(Q.conj().T @ Q, np.eye(nev), atol=1e-11)
+    _, _, rel = oracle.eig_residuals(A, Q, T)
+    _, _, rel_o = oracle.eig_residuals(A, Qo, To)
+    assert rel.max() <= max(1.05 * rel_o.max(), 10 * tol), (rel.max(), rel_o.max())
+    tb = st["truncation_bytes"]
+    assert min(tb) < tb[0] or st["restarts"] <= 2              # locked columns leave the restart compression
+    assert 0 < st["restarts"] <= 2 * int(histo.restarts.max()) + 5
+    return st
+
+
+def check_deflate_real():
+    """on_breakdown="deflate" in real arithmetic: a start vector inside a 7-dimensional invariant subspace (a
+    diagonal block holding a conjugate pair) => the expansion breaks down at m = 7 and the wanted Schur vectors of
+    that subspace come back, as from the complex driver."""
+    import arnoldi_amd
+
+    rng = np.random.default_rng(11)
+    B = np.diag([5.0, 4.0, 3.0, 2.5, 1.0]).astype(float)
+    B = np.block([[B, np.zeros((5, 2))], [np.zeros((2, 5)), np.array([[4.5, 1.5], [-1.5, 4.5]])]])
+    R, _ = np.linalg.qr(rng.standard_normal((7, 7)))
+    n = 60
+    A = np.zeros((n, n))
+    A[:7, :7] = R @ B @ R.T
+    A[7:, 7:] = np.diag(np.linspace(0.1, 0.9, n - 7))
+    v0 = np.zeros(n)
+    v0[:7] = rng.standard_normal(7)
+    v0 /= np.linalg.norm(v0)
+    out = {}
+    for mode in ("complex", "real"):
+        st = {}
+        Q, T, hist = arnoldi_amd.partial_schur(sp.csr_matrix(A), 3, max_dim=20, v0=v0.copy(), on_breakdown="deflate",
+                                               arithmetic=mode, stats=st, sort_function=oracle.arg_largest_magnitude)
+        assert st["restarts"] == 1 and Q.shape == (n, 3)
+        assert np.linalg.norm(A @ Q - Q @ T) < 1e-10 and np.abs(Q.conj().T @ Q - np.eye(3)).max() < 1e-11
+        out[mode] = np.diag(T)
+    want = np.array([5.0, 4.5 + 1.5j, 4.5 - 1.5j])           # |4.5 +- 1.5i| = 4.74 < 5
+    assert _match(out["real"], want) < 1e-9 and _match(out["complex"], want) < 1e-9
+    with pytest.raises(ValueError, match="Happy breakdown not supported yet"):
+        arnoldi_amd.partial_schur(sp.csr_matrix(A), 3, max_dim=20, v0=v0.copy(), arithmetic="real")
+
+
+def check_residual_norms_real():
+    """ArnoldiContext.residual_norms on a real-packed basis: real eigenpairs directly, complex ones refused with a
+    pointer to the pair routine, whose result matches the host's."""
+    import arnoldi_amd
+    from arnoldi_amd import matrices
+
+    A = matrices.mark(30)
+    np.random.seed(3)
+    st = {}
+    arnoldi_amd.partial_schur(A, 4, arithmetic="real", max_dim=20, stopping_criterion=1e-9, stats=st,
+                              sort_function=oracle.arg_largest_real)
+    solver = st["solver"]
+    ctx, k = solver.ctx, solver.nev_now
+    vals, S = np.linalg.eig(solver.H[:k, :k])
+    assert not vals.imag.any()                                # the dominant eigenvalues of the Markov chain are real
+    block = ctx.combine(0, k, S.real)
+    got = ctx.residual_norms(block, vals.real)
+    Qr = ctx.gather_columns(0, k)
+    U = Qr @ S.real
+    np.testing.assert_allclose(got, np.linalg.norm(A @ U - U * vals.real, axis=0), rtol=1e-6, atol=1e-14)
+    with pytest.raises(ValueError, match="values must be real"):
+        ctx.residual_norms(block, vals + 1e-3j)
+    np.testing.assert_allclose(ctx.residual_norms_real_pairs(k, S, vals), got, rtol=1e-6, atol=1e-14)
+
+
+def check_explicit_deflation_real(A, nev, seed, **kw):
+    """explicit_restarts_with_deflation(arithmetic="real") against the oracle of the reference's (complex) solver."""
+    from arnoldi_amd.explicit_restarts import explicit_restarts_with_deflation
+
+    np.random.seed(seed)
+    st = {}
+    vals, vecs, hist = explicit_restarts_with_deflation(A, nev, arithmetic="real", stats=st, **kw)
+    np.random.seed(seed)
+    vo, xo, ho = oracle.explicit_restarts_with_deflation(A, nev, **kw)
+    tol = float(st["tol"])
+    assert vals.shape == (nev,) and vecs.shape == (A.shape[0], nev) and st["locked"] in (nev, nev + 1)
+    assert _match(vals, vo) < 10 * tol * max(1.0, np.abs(vo).max()), (vals, vo)
+    res = np.linalg.norm(A @ vecs - vecs * vals, axis=0) / np.abs(vals)
+    res_o = np.linalg.norm(A @ xo - xo * vo, axis=0) / np.abs(vo)
+    assert res.max() <= max(1.05 * res_o.max(), 10 * tol), (res, res_o)
+    K, ctx = st["locked"], st["ctx"]
+    Hk = st["H"][:K, :K]
+    assert np.abs(np.tril(Hk, -2)).max() == 0.0               # real quasi-triangular
+    Qr = ctx.gather_columns(0, K)
+    np.testing.assert_allclose(Qr.T @ Qr, np.eye(K), atol=1e-10)
+    # device-side residuals of the (complex) eigenpairs of the locked block against the host's
+    ev, Y = np.linalg.eig(Hk)
+    dres = ctx.residual_norms_real_pairs(K, Y, ev)
+    U = Qr @ Y
+    np.testing.assert_allclose(dres, np.linalg.norm(A @ U - U * ev, axis=0), rtol=1e-5, atol=1e-13)
+    assert np.all(hist.restarts > 0)
+    return st

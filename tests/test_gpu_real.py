@@ -246,3 +246,27 @@ def test_real_arithmetic_tiny_sizes(amd, n):
     fold = lambda z: complex(z.real, abs(z.imag))          # noqa: E731  (either member of a dominant pair)
     assert abs(fold(out["real"]) - fold(out["complex"])) < 1e-7 * abs(out["complex"])
     assert np.abs(ev - out["real"]).min() < 1e-6 * abs(out["real"])
+
+
+# ---- the real-arithmetic counterparts of the widened solvers (no more "complex only") ---------------------------------
+@pytest.mark.parametrize("name", ["mark50_readme", "laplace2d", "pair_cut_at_nev5", "conjugate_pairs"])
+def test_real_arithmetic_locking(amd, name):
+    """partial_schur(arithmetic="real", locking=True): eigenvalues of the oracle to 10 tol, residuals <= 1.05 x the
+    oracle's (floor 10 tol), conjugate pairs locked as a whole."""
+    A, nev, seed, kw = rc.cases()[name]
+    rc.check_locking_real(A, nev, seed, **{k: v for k, v in kw.items() if k != "max_restarts"})
+
+
+def test_real_arithmetic_deflate_and_residual_norms(amd):
+    rc.check_deflate_real()
+    rc.check_residual_norms_real()
+
+
+@pytest.mark.parametrize("name", ["mark30_lr", "pair_cut_at_nev3", "planted_odd_n"])
+def test_real_arithmetic_explicit_restarts_with_deflation(amd, name):
+    """explicit_restarts_with_deflation(arithmetic="real") (explicit_restarts.py:80-168 in real arithmetic): real
+    Ritz values as in the reference, conjugate pairs as two real Schur vectors; against the oracle of the
+    reference's complex solver."""
+    A, nev, seed, kw = rc.cases()[name]
+    kw = {k: v for k, v in kw.items() if k != "max_restarts"}
+    rc.check_explicit_deflation_real(A, min(nev, 3), seed, max_restarts=400, **kw)

@@ -699,6 +699,30 @@ def test_real_arithmetic_errors(fake):
     rc.check_auto()
 
 
+@pytest.mark.parametrize("name", ["mark50_readme", "laplace2d", "pair_cut_at_nev5", "conjugate_pairs"])
+def test_real_arithmetic_locking_host_logic(fake, name):
+    import real_cases as rc
+
+    A, nev, seed, kw = rc.cases()[name]
+    rc.check_locking_real(A, nev, seed, **{k: v for k, v in kw.items() if k != "max_restarts"})
+
+
+def test_real_arithmetic_deflate_and_residuals_host_logic(fake):
+    import real_cases as rc
+
+    rc.check_deflate_real()
+    rc.check_residual_norms_real()
+
+
+@pytest.mark.parametrize("name", ["mark30_lr", "pair_cut_at_nev3", "planted_odd_n"])
+def test_real_arithmetic_explicit_restarts_host_logic(fake, name):
+    import real_cases as rc
+
+    A, nev, seed, kw = rc.cases()[name]
+    kw = {k: v for k, v in kw.items() if k != "max_restarts"}
+    rc.check_explicit_deflation_real(A, min(nev, 3), seed, max_restarts=400, **kw)
+
+
 # ---------------------------------------------------------------------------- locking + dynamic p
 @pytest.mark.parametrize("case", ["mark50_lr", "laplace_lm", "planted_lm"])
 def test_locking_gives_the_oracles_eigenpairs(fake, case):
