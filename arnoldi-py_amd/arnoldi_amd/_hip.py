@@ -35,6 +35,7 @@ class WsLayout(C.Structure):
         ("ld_partial", C.c_int32),
         ("red_len", C.c_int32),
         ("pad_", C.c_int32),
+        ("colscale_off", C.c_int64),
     ]
 
 
@@ -60,7 +61,7 @@ _I32, _I64, _F64 = C.c_int32, C.c_int64, C.c_double
 PB_SLAB_BITS = 13       # AKS_PB_SLAB_BITS
 PB_ROWBLOCK_BITS = 13   # AKS_PB_ROWBLOCK_BITS
 PB_RUNS_PER_ROUND = 32  # AKS_PB_WAVES * AKS_PB_RUNS_PER_WAVE
-EXPAND_FROM_W, EXPAND_REAL_PACKED, EXPAND_LAZY_THIRD = 1, 2, 4   # AKS_EXPAND_* flags of aks_arnoldi_expand
+EXPAND_FROM_W, EXPAND_REAL_PACKED, EXPAND_LAZY_THIRD, EXPAND_DEFER_SCALE = 1, 2, 4, 8   # AKS_EXPAND_* flags
 COMM_ID_BYTES = 128     # AKS_COMM_ID_BYTES
 
 
@@ -151,6 +152,8 @@ SIGNATURES = {
     "aks_sell_spmv_real": (C.c_int, [C.POINTER(SellMatrix), _P, _P, _I32, _P, _P]),
     "aks_gather_f64": (C.c_int, [_I64, _P, _P, _P, _P]),
     "aks_truncate": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P]),
+    "aks_truncate_ws": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
+    "aks_shard_apply_col": (C.c_int, [C.POINTER(Shard), _P, _I64, _I32, _P, _P, _I64, _I32, _P, _I32]),
     "aks_combine": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P, _I64, _P]),
     "aks_scale": (C.c_int, [_I64, _P, _F64, _F64, _P]),
     "aks_gather_c128": (C.c_int, [_I64, _P, _P, _P, _P]),

@@ -498,9 +498,18 @@ def dgks_gs_device(basis, J, w, hcol, ldh, tol, ws, eta=ETA_DGKS, normalize=True
     _hip.check(rc, "aks_dgks_gs")
 
 
-def truncate(basis, m, p, Qp_dev):
-    rc = _hip.load().aks_truncate(basis.n_rows, m, p, _ptr(basis.V), basis.ldv, _ptr(Qp_dev), _stream())
-    _hip.check(rc, "aks_truncate")
+def truncate(basis, m, p, Qp_dev, ws=None, col0=0):
+    """``V[:, col0:col0+p] = V[:, col0:col0+m] @ Qp ; V[:, col0+p] = V[:, col0+m]`` in place.  With ``ws``: through
+    ``aks_truncate_ws`` -- columns left raw by an expansion that deferred its normalisations are divided by their
+    scales as they are read, and the scales are cleared."""
+    first = basis.V.data_ptr() + 16 * basis.ldv * col0
+    if ws is None:
+        rc = _hip.load().aks_truncate(basis.n_rows, m, p, first, basis.ldv, _ptr(Qp_dev), _stream())
+        _hip.check(rc, "aks_truncate")
+    else:
+        rc = _hip.load().aks_truncate_ws(basis.n_rows, m, p, first, basis.ldv, _ptr(Qp_dev), col0, _ptr(ws.buf),
+                                         ws.nbytes, ws.max_dim, _stream())
+        _hip.check(rc, "aks_truncate_ws")
 
 
 def gather_c128(count, idx, src, dst):

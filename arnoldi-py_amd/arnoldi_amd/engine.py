@@ -244,6 +244,10 @@ class ArnoldiContext:
         # multi-rank: leave the third all-reduce out until a step turns out to need a second DGKS pass
         self.lazy_third = os.environ.get("AKS_LAZY_THIRD", "1") != "0"
         self.lazy_redos = 0
+        # deferred normalisation of new basis columns (see expand): AKS_DEFER_SCALE=0 switches it off
+        self.allow_defer = os.environ.get("AKS_DEFER_SCALE", "1") != "0"
+        self._raw_from = None       # first raw column of the basis, if an expansion left any
+        self.deferred_expansions = 0
         self.discarded_second_passes = self.discarded_steps = self.discarded_applies = 0   # work of repeated expansions
         self.last_ctrl = None
         self._look = None           # scratch columns; [_look_col] holds A V[:, end] of the last expansion
@@ -252,7 +256,8 @@ class ArnoldiContext:
         self.lookahead_applies = 0  # operator applications issued ahead of time (the last one of a solve is unused)
 
     # -- seam 1 ------------------------------------------------------------------
-    def expand(self, H, start, end, tol, eta=dev.ETA_DGKS, *, lookahead=False, consume_lookahead=False):
+    def expand(self, H, start, end, tol, eta=dev.ETA_DGKS, *, lookahead=False, consume_lookahead=False,
+               defer_scale=False):
         """Run Arnoldi steps j = start..end-1 on the device, then mirror the new columns
         of H into the host array exactly as the reference's in-place writes would.
         Returns n_iter (== end unless a step broke down).
@@ -263,7 +268,14 @@ class ArnoldiContext:
         device work instead of leaving the GPU idle.  ``consume_lookahead``: the caller guarantees that
         ``V[:, start]`` now holds the vector the look-ahead was applied to (Krylov-Schur:
         ``V[:, p] = V[:, m]``), so the first step starts from the stored product.  Results are identical
-        with and without (same kernels, same operands)."""
+        with and without (same kernels, same operands).
+
+        ``defer_scale``: the caller's next operation on the basis is ``truncate`` / ``truncate_active`` (the
+        Krylov-Schur drivers): the new columns may then stay RAW -- the device keeps their norms as scales and every
+        kernel that reads them divides on the fly, instead of a 32 n byte normalisation pass per step
+        (AKS_EXPAND_DEFER_SCALE; honoured by the C-driven path when the diagonal block is in the binned form).
+        H and all results are bit for bit the same; until the truncation the columns ``> start`` must not be
+        read by anything else (``local_columns`` / ``gather_columns`` refuse)."""
         b, ws, op = self.basis, self.ws, self.op
         # The reference's arnoldi_decomposition keeps no state between calls: a breakdown in the
         # last step of one expansion (n_iter == max_dim, accepted by the driver) must not turn the
@@ -271,6 +283,9 @@ class ArnoldiContext:
         w_ready = bool(consume_lookahead and self._look_valid and end > start)
         self._look_valid = False
         native = isinstance(op, CsrOperator) and op.c_driven and not self.force_chained
+        defer = bool(defer_scale and native and self.allow_defer and op.spmv_form == "binned")
+        if self._raw_from is not None and start >= self._raw_from:
+            raise _hip.HipLibraryError("expansion from a raw column: the basis must be truncated first")
         multi = self.comm is not None and self.comm.active
         # Multi-rank: the norm after a second DGKS pass needs a third all-reduce.  While no step has needed a
         # second pass it is left out (two collectives per step); the control block's second_passes count --
@@ -290,11 +305,16 @@ class ArnoldiContext:
             if w_ready:
                 b.V[start + 1].copy_(self._look.V[self._look_col])       # device-to-device, stream-ordered
             if native:
-                self._expand_native(start, end, tol, eta, w_ready, lazy)
+                self._expand_native(start, end, tol, eta, w_ready, lazy, defer)
             else:
                 self._expand_chained(start, end, tol, eta, w_ready, lazy, multi)
             fetch = dev.fetch_H_and_ctrl(b, ws)             # queued before the look-ahead, waited for after it
-            if want_look:
+            if want_look and defer:                          # column `end` is raw: its scale comes from the workspace
+                rc = _hip.load().aks_shard_apply_col(
+                    C.byref(op.shard), dev._ptr(b.V), b.ldv, end, dev._ptr(self._look.col(1 - self._look_col)),
+                    dev._ptr(ws.buf), ws.nbytes, ws.max_dim, dev._stream(), _hip.EXPAND_REAL_PACKED if self.real else 0)
+                _hip.check(rc, "aks_shard_apply_col")
+            elif want_look:
                 op.apply(b.col(end), self._look.col(1 - self._look_col), ws)   # a device no-op after a breakdown
             Hd, ctrl = fetch()
             if lazy and int(ctrl.second_passes) != passes_before:
@@ -313,6 +333,9 @@ class ArnoldiContext:
             self._look_col = 1 - self._look_col
             self._look_valid = not ctrl.broken
         n_iter = int(ctrl.n_iter) if ctrl.broken else end
+        if defer:
+            self._raw_from = start + 1      # columns start+1 .. n_iter hold beta v until the next truncation
+            self.deferred_expansions += 1
         self.matvecs += n_iter - start
         if not np.iscomplexobj(H):
             Hd = Hd.real                                  # real-packed mode: a real Hessenberg matrix
@@ -322,12 +345,12 @@ class ArnoldiContext:
         self.last_ctrl = ctrl
         return n_iter
 
-    def _expand_native(self, start, end, tol, eta, w_ready, lazy):
+    def _expand_native(self, start, end, tol, eta, w_ready, lazy, defer=False):
         """One C call: every kernel (and, over RCCL, every collective) of the expansion is enqueued by
         ``aks_arnoldi_expand`` with no host round trip."""
         b, ws, op = self.basis, self.ws, self.op
         flags = ((_hip.EXPAND_FROM_W if w_ready else 0) | (_hip.EXPAND_REAL_PACKED if self.real else 0)
-                 | (_hip.EXPAND_LAZY_THIRD if lazy else 0))
+                 | (_hip.EXPAND_LAZY_THIRD if lazy else 0) | (_hip.EXPAND_DEFER_SCALE if defer else 0))
 
         def enqueue():
             rc = _hip.load().aks_arnoldi_expand(
@@ -347,7 +370,7 @@ class ArnoldiContext:
         # communicator's side stream crashes inside hipStreamEndCapture (ROCm 7.2, RCCL 2.26), so sequences with
         # an exchange stay eager.  At the shard sizes of the BASELINE configs on 8 GPUs (1.25M - 2M rows) a kernel
         # lasts 20-60 us against ~4 us to launch it, so the eager sequence is not host-bound there.
-        key = (start, end, float(tol), float(eta), w_ready, lazy)
+        key = (start, end, float(tol), float(eta), w_ready, lazy, defer)
         graph_ok = not op.native_comm or (os.environ.get("AKS_GRAPH_COMM", "0") == "1" and not op.any_exchange)
         if self.use_graph and self.probe is None and start > 0 and graph_ok and b.V.is_cuda:
             g = self._graphs.get(key)
@@ -411,7 +434,8 @@ class ArnoldiContext:
     # -- seam 2 ------------------------------------------------------------------
     def truncate(self, Qp, m, p):
         Qd = torch.from_numpy(np.ascontiguousarray(Qp, dtype=C128)).to(self.basis.device)
-        dev.truncate(self.basis, m, p, Qd)
+        dev.truncate(self.basis, m, p, Qd, self.ws)         # (reads raw columns, writes normalised ones)
+        self._raw_from = None
 
     def truncate_active(self, Zp, l, m, p):
         """Restart compression behind ``l`` locked columns (krylov_schur_locking.py):
@@ -419,15 +443,17 @@ class ArnoldiContext:
         starts at column ``l``; the locked columns are neither read nor written."""
         b = self.basis
         Zd = torch.from_numpy(np.ascontiguousarray(Zp, dtype=C128).reshape(m - l, p - l)).to(b.device)
-        rc = _hip.load().aks_truncate(b.n_rows, m - l, p - l, b.V.data_ptr() + 16 * b.ldv * l, b.ldv,
-                                      dev._ptr(Zd), dev._stream())
-        _hip.check(rc, "aks_truncate")
+        dev.truncate(b, m - l, p - l, Zd, self.ws, col0=l)
+        self._raw_from = None
 
     # -- data movement --------------------------------------------------------------
     def set_start_vector(self, v_full):
         self.basis.set_col(0, v_full[self.op.r0: self.op.r1])
 
     def local_columns(self, j0, j1):
+        if self._raw_from is not None and j1 > self._raw_from:
+            raise _hip.HipLibraryError("columns of an expansion with deferred normalisation are raw until the basis "
+                                       "has been truncated")
         return self.basis.get_cols(j0, j1)
 
     def gather_columns(self, j0, j1):

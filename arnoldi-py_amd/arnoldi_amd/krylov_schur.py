@@ -41,7 +41,7 @@ class KrylovSchurSolver:
 
     def start(self):
         """Initial m-step expansion (krylov_schur.py:51-54)."""
-        self.m = self.ctx.expand(self.H, 0, self.max_dim, self.tol, lookahead=True)
+        self.m = self.ctx.expand(self.H, 0, self.max_dim, self.tol, lookahead=True, defer_scale=True)
         return self.m
 
     def contract(self, restart):
@@ -98,7 +98,8 @@ class KrylovSchurSolver:
         """Re-expansion from p to max_dim (krylov_schur.py:103-106).  Its first product
         ``A V[:, p]`` (= ``A V[:, m]`` of the previous cycle, ``contract`` copies that column) was
         queued at the end of the previous expansion and ran while the host did the Schur step."""
-        self.m = self.ctx.expand(self.H, self.p, self.max_dim, self.tol, lookahead=True, consume_lookahead=True)
+        self.m = self.ctx.expand(self.H, self.p, self.max_dim, self.tol, lookahead=True, consume_lookahead=True,
+                                 defer_scale=True)
         return self.m
 
     def true_residuals(self):
@@ -213,6 +214,7 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
         stats.update(restarts=solver.restarts_run, matvecs=ctx.matvecs,
                      second_passes=int(ctx.last_ctrl.second_passes) - ctx.discarded_second_passes, solver=solver,
                      lazy_redos=ctx.lazy_redos, discarded_operator_applies=ctx.discarded_applies,
+                     deferred_normalisations=ctx.deferred_expansions,     # expansions whose new columns stayed raw
                      lookahead_applies=ctx.lookahead_applies, arithmetic=arithmetic,
                      tol=float(tol), max_dim=int(max_dim), p=int(p),
                      spmv_form=getattr(solver.op, "spmv_form", None),      # which kernel applied A: decides the order

@@ -107,7 +107,7 @@ class RealKrylovSchurSolver:
         self.restarts_run = 0
 
     def start(self):
-        self.m = self.ctx.expand(self.H, 0, self.max_dim, self.tol, lookahead=True)
+        self.m = self.ctx.expand(self.H, 0, self.max_dim, self.tol, lookahead=True, defer_scale=True)
         return self.m
 
     def contract(self, restart):
@@ -171,7 +171,7 @@ class RealKrylovSchurSolver:
 
     def expand(self):
         self.m = self.ctx.expand(self.H, self.p_now, self.max_dim, self.tol, lookahead=True,
-                                 consume_lookahead=True)
+                                 consume_lookahead=True, defer_scale=True)
         return self.m
 
     def true_residuals(self):

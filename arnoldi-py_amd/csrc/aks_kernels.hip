@@ -195,6 +195,17 @@ __device__ __forceinline__ void block_reduce_panel(const double (&ar)[NC], const
     }
 }
 
+// Deferred normalisation (AKS_EXPAND_DEFER_SCALE).  The reference normalises a new basis vector at once
+// (decomposition.py:66, w /= beta): a pass of 32 n bytes per Arnoldi step that does nothing but scale.  Here a column
+// may stay RAW instead -- it holds beta v, and its scale beta sits in the workspace (colscale[column]; 0 = the column
+// is normalised) -- and every kernel that reads basis columns divides a raw column's entries by its scale as it loads
+// them: the same IEEE division k_finish performs, so every value that enters an FMA is bit for bit the one the
+// normalised column would have held.  Raw columns only exist between an expansion and the restart compression
+// that follows it (aks_truncate_ws writes normalised columns and clears the scales).
+__device__ __forceinline__ bool is_raw(double s) { return __builtin_bit_cast(long long, s) != 0ll; }
+__device__ __forceinline__ c128 unscale(c128 v, double s) { return make_double2(v.x / s, v.y / s); }
+__device__ __forceinline__ double unscale(double v, double s) { return v / s; }
+
 __device__ __forceinline__ bool second_pass_needed(const c128 *red1, const c128 *red2, int J, double eta) {
     // ortho.py:101   beta < beta_before * eta
     return sqrt(red2[J].x) < sqrt(red1[J].x) * eta;
@@ -206,8 +217,12 @@ __device__ __forceinline__ bool second_pass_needed(const c128 *red1, const c128 
 template <int NC>
 __global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *__restrict__ V, int64_t ldv,
                                                const c128 *__restrict__ w, c128 *__restrict__ partial,
-                                               int ldp, int nrm_slot, const aks_ctrl *__restrict__ ctrl) {
+                                               int ldp, int nrm_slot, const aks_ctrl *__restrict__ ctrl,
+                                               const double *__restrict__ cs, int raw0) {
     if (ctrl->broken) return;
+    __shared__ double ssc[NC];                            // scales of this group's columns (raw columns: >= raw0)
+    if (threadIdx.x < NC) ssc[threadIdx.x] = cs[c0 + threadIdx.x];
+    __syncthreads();
     double ar[NC], ai[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) ar[c] = ai[c] = 0.0;
@@ -219,6 +234,9 @@ __global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *_
         c128 v[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) v[c] = ld_panel(&Vc[i + (int64_t)c * ldv]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c0 + c >= raw0 && is_raw(ssc[c])) v[c] = unscale(v[c], ssc[c]);      // (wave-uniform)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             ar[c] = fma(v[c].x, wv.x, fma(v[c].y, wv.y, ar[c]));
@@ -239,10 +257,12 @@ template <int NC>
 __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__restrict__ V, int64_t ldv,
                                                       c128 *__restrict__ w, const c128 *__restrict__ h,
                                                       c128 *__restrict__ partial, int ldp,
-                                                      const aks_ctrl *__restrict__ ctrl) {
+                                                      const aks_ctrl *__restrict__ ctrl,
+                                                      const double *__restrict__ cs, int raw0) {
     if (ctrl->broken) return;
     __shared__ c128 hs[NC];
-    if (threadIdx.x < NC) hs[threadIdx.x] = h[threadIdx.x];
+    __shared__ double ssc[NC];
+    if (threadIdx.x < NC) { hs[threadIdx.x] = h[threadIdx.x]; ssc[threadIdx.x] = cs[threadIdx.x]; }
     __syncthreads();
     double ar[NC], ai[NC];
 #pragma unroll
@@ -258,6 +278,9 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__
         c128 v[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) v[c] = ld_panel(&V[i + (int64_t)c * ldv]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c >= raw0 && is_raw(ssc[c])) v[c] = unscale(v[c], ssc[c]);           // (wave-uniform)
         double sr = 0.0, si = 0.0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -290,15 +313,17 @@ template <int NQ>
 __global__ __launch_bounds__(BLOCK) void k_update_proj_split(int64_t n, int J, const c128 *__restrict__ V,
                                                             int64_t ldv, c128 *__restrict__ w,
                                                             const c128 *__restrict__ h, c128 *__restrict__ partial,
-                                                            int ldp, const aks_ctrl *__restrict__ ctrl) {
+                                                            int ldp, const aks_ctrl *__restrict__ ctrl,
+                                                            const double *__restrict__ cs, int raw0) {
     if (ctrl->broken) return;
     __shared__ c128 hs[AKS_MAX_DIM + 4];
+    __shared__ double ssc[AKS_MAX_DIM + 4];
     __shared__ double ps_re[2][WAVES][64], ps_im[2][WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int base = J / WAVES, extra = J % WAVES;
     const int c_begin = wave * base + min(wave, extra);
     const int cnt = base + (wave < extra ? 1 : 0);      // <= NQ
-    for (int c = threadIdx.x; c < J; c += BLOCK) hs[c] = h[c];
+    for (int c = threadIdx.x; c < J; c += BLOCK) { hs[c] = h[c]; ssc[c] = cs[c]; }
     __syncthreads();
     if (threadIdx.x < 4) hs[J + threadIdx.x] = make_double2(0.0, 0.0);   // coefficient of padding slots
     __syncthreads();
@@ -320,6 +345,11 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj_split(int64_t n, int J, c
         c128 v[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[q] = ld_panel(&Vw[i + (int64_t)min(q, cnt - 1) * ldv]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int cq = c_begin + min(q, cnt - 1);                                // (wave-uniform)
+            if (cq >= raw0 && is_raw(ssc[cq])) v[q] = unscale(v[q], ssc[cq]);
+        }
         double sr = 0.0, si = 0.0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -382,13 +412,18 @@ __global__ __launch_bounds__(BLOCK) void k_update(int64_t n, int J, const c128 *
                                                  c128 *__restrict__ w, const c128 *__restrict__ h,
                                                  c128 *__restrict__ partial, int ldp, int nrm_slot,
                                                  const c128 *__restrict__ red1, const c128 *__restrict__ red2,
-                                                 double eta, const aks_ctrl *__restrict__ ctrl) {
+                                                 double eta, const aks_ctrl *__restrict__ ctrl,
+                                                 const double *__restrict__ cs, int raw0) {
     if (ctrl->broken) return;
     if (PRED && !second_pass_needed(red1, red2, J, eta)) return;
     __shared__ c128 hs[AKS_MAX_DIM + 8];
+    __shared__ double ssc[AKS_MAX_DIM + 8];
     __shared__ double red_n[WAVES];
     const int Jpad = (J + 3) & ~3;
-    for (int c = threadIdx.x; c < Jpad; c += BLOCK) hs[c] = c < J ? h[c] : make_double2(0.0, 0.0);
+    for (int c = threadIdx.x; c < Jpad; c += BLOCK) {
+        hs[c] = c < J ? h[c] : make_double2(0.0, 0.0);
+        ssc[c] = c < J ? cs[c] : 0.0;
+    }
     __syncthreads();
     double nrm = 0.0;
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
@@ -401,6 +436,11 @@ __global__ __launch_bounds__(BLOCK) void k_update(int64_t n, int J, const c128 *
             for (int u = 0; u < 4; ++u) {
                 const int cc = min(c + u, J - 1);  // padded columns re-read a valid one; their h is 0
                 v[u] = ld_panel(&V[i + (int64_t)cc * ldv]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cc = min(c + u, J - 1);
+                if (cc >= raw0 && is_raw(ssc[cc])) v[u] = unscale(v[u], ssc[cc]);    // (wave-uniform)
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -450,7 +490,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const c128 *__restrict__ parti
 __global__ __launch_bounds__(BLOCK) void k_finish(int64_t n, int J, c128 *__restrict__ w, c128 *__restrict__ Hcol,
                                                  int64_t ldh, double tol, double eta, int normalize,
                                                  const c128 *__restrict__ red1, const c128 *__restrict__ red2,
-                                                 const c128 *__restrict__ red3, aks_ctrl *__restrict__ ctrl) {
+                                                 const c128 *__restrict__ red3, aks_ctrl *__restrict__ ctrl,
+                                                 double *__restrict__ cs) {
+    // normalize: 0 = leave w as it is; 1 = H[J, j] = beta and w /= beta (decomposition.py:65-66); 2 = H[J, j] = beta
+    // and column J stays raw with colscale[J] = beta (deferred normalisation: its readers divide)
     if (ctrl->broken) return;
     const bool twice = second_pass_needed(red1, red2, J, eta);
     const double beta = sqrt(twice ? red3[0].x : red2[J].x);
@@ -463,6 +506,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(int64_t n, int J, c128 *__rest
         }
         if (threadIdx.x == 0) {
             if (!broke && normalize) Hcol[(int64_t)J * ldh] = make_double2(beta, 0.0);  // decomposition.py:65
+            if (!broke && normalize == 2) cs[J] = beta;
             ctrl->beta_in = sqrt(red1[J].x);
             ctrl->beta = beta;
             ctrl->steps_done += 1;
@@ -470,7 +514,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(int64_t n, int J, c128 *__rest
             if (broke) { ctrl->n_iter = J; ctrl->broken = 1; }  // decomposition.py:61-63 (n_iter = j+1 = J)
         }
     }
-    if (broke || !normalize) return;
+    if (broke || normalize != 1) return;
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         c128 wv = w[i];
@@ -688,7 +732,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 template <int MT, int NS>   // NS row sub-tiles of 16 per wave (4, or 2 when MT is large)
 __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p, c128 *V, int64_t ldv,
                                                         const c128 *__restrict__ Qp, c128 *O, int64_t ldo,
-                                                        int copy_last) {
+                                                        int copy_last, const double *__restrict__ cs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     c128 *qs = reinterpret_cast<c128 *>(smem_raw);      // [mpad][PP] complex, zero padded
     constexpr int PP = MT * 8;
@@ -715,6 +759,7 @@ __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p
         for (int s = 0; s < NS; ++s) rows[s] = min(row0 + s * 16 + r16, n - 1);
         for (int c0 = 0; c0 < mpad; c0 += 4) {
             const int c = min(c0 + g, m - 1);            // padded K slots re-read a valid column; their Q rows are 0
+            const double sc = cs != nullptr ? cs[c] : 0.0;   // raw column (deferred normalisation): divide as it is read
             c128 v[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -723,6 +768,11 @@ __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p
 #else
                 v[s] = V[rows[s] + (int64_t)c * ldv];
 #endif
+            }
+            if (__builtin_amdgcn_ballot_w64(is_raw(sc)) != 0ull) {           // (skipped while all four columns are normalised)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if (is_raw(sc)) v[s] = unscale(v[s], sc);
             }
             const c128 *qrow = qs + (c0 + g) * PP;
 #pragma unroll
@@ -762,10 +812,15 @@ __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p
         // V[:, p] = V[:, m] (krylov_schur.py:81).  Column m is never a destination of the stores
         // above (they end at column p - 1 <= m - 1), so it can be read here.
         if (copy_last && g == 0) {
+            const double sm = cs != nullptr ? cs[m] : 0.0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int64_t row = row0 + s * 16 + r16;
-                if (row < n) O[row + (int64_t)p * ldo] = V[row + (int64_t)m * ldv];
+                if (row < n) {
+                    c128 vm = V[row + (int64_t)m * ldv];
+                    if (is_raw(sm)) vm = unscale(vm, sm);
+                    O[row + (int64_t)p * ldo] = vm;
+                }
             }
         }
     }
@@ -779,9 +834,15 @@ __global__ __launch_bounds__(BLOCK) void k_scale(int64_t n, c128 *__restrict__ w
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_gather(int64_t count, const int32_t *__restrict__ idx,
-                                                 const T *__restrict__ src, T *__restrict__ dst) {
+                                                 const T *__restrict__ src, T *__restrict__ dst,
+                                                 const double *__restrict__ div) {
+    const double d = div != nullptr ? *div : 0.0;          // the source column is raw: pack normalised entries
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) dst[i] = src[idx[i]];
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) {
+        T v = src[idx[i]];
+        if (is_raw(d)) v = unscale(v, d);
+        dst[i] = v;
+    }
 }
 
 // ------------------------------------------------------------------ tile-binned two-phase SpMV
@@ -834,14 +895,22 @@ __global__ __launch_bounds__(PB_P1_THREADS) void k_pb_phase1(int64_t n_cols, con
                                                             const int32_t *__restrict__ slab_end,
                                                             const VT *__restrict__ val, const uint16_t *__restrict__ lcol,
                                                             const XT *__restrict__ x, XT *__restrict__ prod,
-                                                            const aks_ctrl *__restrict__ ctrl) {
+                                                            const aks_ctrl *__restrict__ ctrl,
+                                                            const double *__restrict__ x_div) {
     if (ctrl != nullptr && ctrl->broken) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
     XT *xs = reinterpret_cast<XT *>(pb_smem);
     const int s = blockIdx.x;
     const int64_t c0 = (int64_t)s << PB_CW_BITS;
     const int cw = (int)min((int64_t)PB_CW, n_cols - c0);
-    for (int i = threadIdx.x; i < cw; i += PB_P1_THREADS) xs[i] = x[c0 + i];
+    // x may be a RAW basis column (deferred normalisation): its entries are divided by the column's scale as they are
+    // staged -- once per entry, where k_finish would have divided them in a pass of its own
+    const double xd = x_div != nullptr ? *x_div : 0.0;
+    if (is_raw(xd)) {
+        for (int i = threadIdx.x; i < cw; i += PB_P1_THREADS) xs[i] = unscale(x[c0 + i], xd);
+    } else {
+        for (int i = threadIdx.x; i < cw; i += PB_P1_THREADS) xs[i] = x[c0 + i];
+    }
     __syncthreads();
     const int k0 = slab_begin[s], k1 = (slab_end[s] + 7) & ~7;       // pad slots hold val = 0, lcol = 0
     for (int base = k0; base < k1; base += PB_P1_THREADS * PB_P1_U) {
@@ -1028,6 +1097,7 @@ struct Ws {
     aks_ws_layout lay;
     aks_ctrl *ctrl;
     c128 *red1, *red2, *red3, *partial;
+    double *colscale;          // per basis column: 0 = normalised, else the column is raw and this is its divisor
 };
 
 int bind_ws(void *d_ws, int64_t ws_bytes, int64_t n_rows, int32_t max_dim, Ws *out) {
@@ -1042,6 +1112,7 @@ int bind_ws(void *d_ws, int64_t ws_bytes, int64_t n_rows, int32_t max_dim, Ws *o
     out->red2 = reinterpret_cast<c128 *>(base + out->lay.red2_off);
     out->red3 = reinterpret_cast<c128 *>(base + out->lay.red3_off);
     out->partial = reinterpret_cast<c128 *>(base + out->lay.partial_off);
+    out->colscale = reinterpret_cast<double *>(base + out->lay.colscale_off);
     return AKS_OK;
 }
 
@@ -1058,13 +1129,13 @@ int check_panel(int64_t n_rows, int32_t J, const void *V, int64_t ldv, const voi
 
 template <int NC>
 void launch_proj_nc(dim3 grid, hipStream_t s, int64_t n, int c0, const c128 *V, int64_t ldv, const c128 *w,
-                    c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl) {
-    hipLaunchKernelGGL(k_proj<NC>, grid, dim3(BLOCK), 0, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl);
+                    c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0) {
+    hipLaunchKernelGGL(k_proj<NC>, grid, dim3(BLOCK), 0, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0);
 }
 template <int NC>
 void launch_update_proj_nc(dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
-                           const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl) {
-    hipLaunchKernelGGL(k_update_proj<NC>, grid, dim3(BLOCK), 0, s, n, V, ldv, w, h, partial, ldp, ctrl);
+                           const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0) {
+    hipLaunchKernelGGL(k_update_proj<NC>, grid, dim3(BLOCK), 0, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0);
 }
 
 #define AKS_NC_CASES(M) \
@@ -1072,9 +1143,9 @@ void launch_update_proj_nc(dim3 grid, hipStream_t s, int64_t n, const c128 *V, i
     M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31) M(32)
 
 void dispatch_proj(int nc, dim3 grid, hipStream_t s, int64_t n, int c0, const c128 *V, int64_t ldv,
-                   const c128 *w, c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl) {
+                   const c128 *w, c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0) {
     switch (nc) {
-#define M(N) case N: launch_proj_nc<N>(grid, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl); break;
+#define M(N) case N: launch_proj_nc<N>(grid, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0); break;
         AKS_NC_CASES(M)
 #undef M
         default: break;
@@ -1088,9 +1159,9 @@ void dispatch_proj(int nc, dim3 grid, hipStream_t s, int64_t n, int c0, const c1
 constexpr int FUSED_EXACT_MAX = AKS_FUSED_EXACT_MAX;
 
 void dispatch_update_proj(int nc, dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
-                          const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl) {
+                          const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0) {
     switch (nc) {
-#define M(N) case N: launch_update_proj_nc<N>(grid, s, n, V, ldv, w, h, partial, ldp, ctrl); break;
+#define M(N) case N: launch_update_proj_nc<N>(grid, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0); break;
         AKS_NC_CASES(M)
 #undef M
         default: break;
@@ -1099,8 +1170,8 @@ void dispatch_update_proj(int nc, dim3 grid, hipStream_t s, int64_t n, const c12
 
 template <int NQ>
 void launch_update_proj_split(dim3 grid, hipStream_t s, int64_t n, int J, const c128 *V, int64_t ldv, c128 *w,
-                              const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl) {
-    hipLaunchKernelGGL(k_update_proj_split<NQ>, grid, dim3(BLOCK), 0, s, n, J, V, ldv, w, h, partial, ldp, ctrl);
+                              const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0) {
+    hipLaunchKernelGGL(k_update_proj_split<NQ>, grid, dim3(BLOCK), 0, s, n, J, V, ldv, w, h, partial, ldp, ctrl, cs, raw0);
 }
 
 #define AKS_NQ_CASES(M) \
@@ -1108,9 +1179,9 @@ void launch_update_proj_split(dim3 grid, hipStream_t s, int64_t n, int J, const 
     M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31) M(32)
 
 void dispatch_update_proj_split(int J, dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
-                                const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl) {
+                                const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0) {
     switch ((J + WAVES - 1) / WAVES) {
-#define M(N) case N: launch_update_proj_split<N>(grid, s, n, J, V, ldv, w, h, partial, ldp, ctrl); break;
+#define M(N) case N: launch_update_proj_split<N>(grid, s, n, J, V, ldv, w, h, partial, ldp, ctrl, cs, raw0); break;
         AKS_NQ_CASES(M)
 #undef M
         default: break;
@@ -1119,14 +1190,14 @@ void dispatch_update_proj_split(int J, dim3 grid, hipStream_t s, int64_t n, cons
 
 // projection of all J columns in groups of <= NC_MAX columns of (nearly) equal width
 void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c128 *V, int64_t ldv,
-                        const c128 *w, c128 *red_out, c128 *zero_slot) {
+                        const c128 *w, c128 *red_out, c128 *zero_slot, int raw0) {
     const int groups = (J + NC_MAX - 1) / NC_MAX;
     const int base = J / groups, extra = J % groups;
     const dim3 grid(ws.lay.n_blocks);
     int c0 = 0;
     for (int g = 0; g < groups; ++g) {
         const int nc = base + (g < extra ? 1 : 0);
-        dispatch_proj(nc, grid, s, n, c0, V, ldv, w, ws.partial, ws.lay.ld_partial, g == 0 ? J : -1, ws.ctrl);
+        dispatch_proj(nc, grid, s, n, c0, V, ldv, w, ws.partial, ws.lay.ld_partial, g == 0 ? J : -1, ws.ctrl, ws.colscale, raw0);
         c0 += nc;
     }
     hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
@@ -1144,7 +1215,7 @@ template <typename K> int raise_lds(K kernel, size_t bytes, const char *where) {
 
 template <int MT>
 int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_t ldv, const c128 *Qp, c128 *O,
-                         int64_t ldo, int copy_last, bool init_only = false) {
+                         int64_t ldo, int copy_last, bool init_only = false, const double *cs = nullptr) {
     // rows per wave = 16 NS: 128 for p <= 16 (more loads in flight per K-step: 1.041 -> 1.011 ms at m = 20, p = 10,
     // n = 10M; the read/write mix of this kernel streams at ~5.4 TB/s = 0.95 ms), fewer as the accumulators grow
     constexpr int NS = MT <= 2 ? 8 : (MT <= 9 ? 4 : 2);      // keeps NS * MT * 8 accumulator registers below the spill point
@@ -1153,7 +1224,7 @@ int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_
     if (init_only) return raise_lds(k_truncate_mfma<MT, NS>, AKS_LDS_BYTES, "hipFuncSetAttribute(k_truncate_mfma)");
     const int64_t want = ((n + 16 * NS - 1) / (16 * NS) + WAVES - 1) / WAVES;
     const dim3 grid((unsigned)(want < 4096 ? want : 4096));
-    hipLaunchKernelGGL((k_truncate_mfma<MT, NS>), grid, dim3(BLOCK), smem, s, n, m, p, V, ldv, Qp, O, ldo, copy_last);
+    hipLaunchKernelGGL((k_truncate_mfma<MT, NS>), grid, dim3(BLOCK), smem, s, n, m, p, V, ldv, Qp, O, ldo, copy_last, cs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         hip_fail(e, "k_truncate_mfma");
@@ -1188,8 +1259,18 @@ int nccl_fail(ncclResult_t r, const char *where) {
 }
 
 // one CSR block applied with whichever form its plan selects; vectors complex128 or (real) float64
-int apply_block(const aks_csr_block &B, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real) {
+int launch_pb_any(const aks_pb_matrix *A, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
+                  const double *x_div);
+
+// (x_div: scale of a raw input column -- deferred normalisation; only the binned form can apply it, and
+// aks_arnoldi_expand defers only when the diagonal block is in that form)
+int apply_block(const aks_csr_block &B, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
+                const double *x_div = nullptr) {
     if (B.n_rows <= 0) return AKS_OK;
+    if (x_div != nullptr) {
+        if (B.pb == nullptr) return fail(AKS_ERR_ARG, "a raw input column needs the binned form");
+        return launch_pb_any(B.pb, x, y, accumulate, d_ws, stream, real, x_div);
+    }
     if (real) {
         if (B.values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
         const double *xr = static_cast<const double *>(x);
@@ -1237,7 +1318,7 @@ int check_pb(const aks_pb_matrix *A, const void *x, const void *y) {
 
 template <typename VT, typename XT>
 int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const aks_ctrl *ctrl, hipStream_t s,
-              bool init_only = false) {
+              bool init_only = false, const double *x_div = nullptr) {
     const size_t lds1 = (size_t)PB_CW * sizeof(XT);
     const size_t lds2 = (size_t)PB_RB * sizeof(XT);
     if (init_only) {
@@ -1249,7 +1330,7 @@ int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const 
     XT *prod = reinterpret_cast<XT *>(A->d_prod);       // real vectors use the first 8 nnz_pad bytes
     if (A->nnz > 0)
         hipLaunchKernelGGL((k_pb_phase1<VT, XT>), dim3((unsigned)A->n_slabs), dim3(PB_P1_THREADS), lds1, s, A->n_cols,
-                           A->d_slab_begin, A->d_slab_end, static_cast<const VT *>(A->d_val), A->d_lcol, x, prod, ctrl);
+                           A->d_slab_begin, A->d_slab_end, static_cast<const VT *>(A->d_val), A->d_lcol, x, prod, ctrl, x_div);
     const int n_chunks = (int)std::min<int64_t>(A->n_rowblocks, AKS_PB_CHUNKS);   // as the planner ordered them
     const int cpx = (n_chunks + 7) / 8;
     const uint4 *runs = reinterpret_cast<const uint4 *>(A->d_runs);
@@ -1266,6 +1347,22 @@ int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const 
         return AKS_ERR_HIP;
     }
     return AKS_OK;
+}
+
+int launch_pb_any(const aks_pb_matrix *A, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
+                  const double *x_div) {
+    int rc = check_pb(A, x, y);
+    if (rc != AKS_OK) return rc;
+    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (real) {
+        if (A->values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
+        return launch_pb<double, double>(A, static_cast<const double *>(x), static_cast<double *>(y), accumulate, ctrl, s, false, x_div);
+    }
+    const c128 *xc = static_cast<const c128 *>(x);
+    c128 *yc = static_cast<c128 *>(y);
+    return A->values_complex ? launch_pb<c128, c128>(A, xc, yc, accumulate, ctrl, s, false, x_div)
+                             : launch_pb<double, c128>(A, xc, yc, accumulate, ctrl, s, false, x_div);
 }
 
 int check_sell(const aks_sell_matrix *A, const void *x, const void *y) {
@@ -1320,6 +1417,7 @@ int aks_workspace_layout(int64_t n_rows, int32_t max_dim, aks_ws_layout *out) {
     out->red1_off = off;                 off = align_up(off + (int64_t)ld * 16, 256);
     out->red2_off = off;                 off = align_up(off + (int64_t)ld * 16, 256);
     out->red3_off = off;                 off = align_up(off + 2 * 16, 256);
+    out->colscale_off = off;             off = align_up(off + (int64_t)(AKS_MAX_DIM + 2) * 8, 256);
     out->partial_off = off;              off = align_up(off + nb * ld * 16, 256);
     out->total_bytes = off;
     out->n_blocks = (int32_t)nb;
@@ -1409,21 +1507,23 @@ int aks_csr_spmv_real(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_
     return AKS_OK;
 }
 
-int aks_gs_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, const aks_c128 *d_w,
-                   void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+// The stage entry points.  `raw0`: first basis column that may be raw (deferred normalisation); the public entry
+// points pass J -- they expect normalised columns; only aks_arnoldi_expand creates and reads raw ones.
+static int gs_project_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, const aks_c128 *d_w,
+                       void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream, int raw0) {
     int rc = check_panel(n_rows, J, d_V, ldv, d_w, max_dim);
     if (rc != AKS_OK) return rc;
     Ws ws;
     rc = bind_ws(d_ws, ws_bytes, n_rows, max_dim, &ws);
     if (rc != AKS_OK) return rc;
     enqueue_projection(static_cast<hipStream_t>(stream), ws, n_rows, J, reinterpret_cast<const c128 *>(d_V), ldv,
-                       reinterpret_cast<const c128 *>(d_w), ws.red1, ws.red3);
+                       reinterpret_cast<const c128 *>(d_w), ws.red1, ws.red3, raw0);
     AKS_CHECK_LAUNCH("aks_gs_project");
     return AKS_OK;
 }
 
-int aks_gs_update_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w,
-                          void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+static int gs_update_project_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w,
+                              void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream, int raw0) {
     int rc = check_panel(n_rows, J, d_V, ldv, d_w, max_dim);
     if (rc != AKS_OK) return rc;
     Ws ws;
@@ -1439,18 +1539,18 @@ int aks_gs_update_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_
     const bool exact = J <= exact_max && J <= NC_MAX && !(J >= 5 && J <= 12);
     if (exact)
         dispatch_update_proj(J, dim3(ws.lay.n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
-                             ws.lay.ld_partial, ws.ctrl);
+                             ws.lay.ld_partial, ws.ctrl, ws.colscale, raw0);
     else
         dispatch_update_proj_split(J, dim3(ws.lay.n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
-                                   ws.lay.ld_partial, ws.ctrl);
+                                   ws.lay.ld_partial, ws.ctrl, ws.colscale, raw0);
     hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
                        ws.lay.ld_partial, 0, ws.red2, J, nullptr, nullptr, 0.0, nullptr, ws.ctrl);
     AKS_CHECK_LAUNCH("aks_gs_update_project");
     return AKS_OK;
 }
 
-int aks_gs_update_norm(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w, double eta,
-                       void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+static int gs_update_norm_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w, double eta,
+                           void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream, int raw0) {
     int rc = check_panel(n_rows, J, d_V, ldv, d_w, max_dim);
     if (rc != AKS_OK) return rc;
     Ws ws;
@@ -1459,11 +1559,26 @@ int aks_gs_update_norm(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t l
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_update<true>, dim3(ws.lay.n_blocks), dim3(BLOCK), 0, s, n_rows, J,
                        reinterpret_cast<const c128 *>(d_V), ldv, reinterpret_cast<c128 *>(d_w), ws.red2,
-                       ws.partial, ws.lay.ld_partial, 0, ws.red1, ws.red2, eta, ws.ctrl);
+                       ws.partial, ws.lay.ld_partial, 0, ws.red1, ws.red2, eta, ws.ctrl, ws.colscale, raw0);
     hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
                        ws.lay.ld_partial, 0, ws.red3, J, ws.red1, ws.red2, eta, nullptr, ws.ctrl);
     AKS_CHECK_LAUNCH("aks_gs_update_norm");
     return AKS_OK;
+}
+
+int aks_gs_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, const aks_c128 *d_w,
+                   void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+    return gs_project_(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream, J);
+}
+
+int aks_gs_update_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w,
+                          void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+    return gs_update_project_(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream, J);
+}
+
+int aks_gs_update_norm(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w, double eta,
+                       void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+    return gs_update_norm_(n_rows, J, d_V, ldv, d_w, eta, d_ws, ws_bytes, max_dim, stream, J);
 }
 
 int aks_gs_finish(int64_t n_rows, int32_t J, aks_c128 *d_w, aks_c128 *d_Hcol, int64_t ldh, double tol,
@@ -1471,26 +1586,35 @@ int aks_gs_finish(int64_t n_rows, int32_t J, aks_c128 *d_w, aks_c128 *d_Hcol, in
     if (d_w == nullptr || d_Hcol == nullptr) return fail(AKS_ERR_ARG, "null pointer");
     if (J < 1 || J > max_dim) return fail(AKS_ERR_ARG, "J must satisfy 1 <= J <= max_dim");
     if (ldh < 1) return fail(AKS_ERR_ARG, "ldh must be positive");
+    if (normalize < 0 || normalize > 2) return fail(AKS_ERR_ARG, "normalize must be 0, 1 or 2");
     Ws ws;
     int rc = bind_ws(d_ws, ws_bytes, n_rows, max_dim, &ws);
     if (rc != AKS_OK) return rc;
-    hipLaunchKernelGGL(k_finish, dim3(ws.lay.n_blocks), dim3(BLOCK), 0, static_cast<hipStream_t>(stream), n_rows, J,
-                       reinterpret_cast<c128 *>(d_w), reinterpret_cast<c128 *>(d_Hcol), ldh, tol, eta,
-                       (int)normalize, ws.red1, ws.red2, ws.red3, ws.ctrl);
+    // (deferred normalisation: nothing of length n to do -- one block books H, beta and the column's scale)
+    hipLaunchKernelGGL(k_finish, dim3(normalize == 1 ? ws.lay.n_blocks : 1), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
+                       n_rows, J, reinterpret_cast<c128 *>(d_w), reinterpret_cast<c128 *>(d_Hcol), ldh, tol, eta,
+                       (int)normalize, ws.red1, ws.red2, ws.red3, ws.ctrl, ws.colscale);
     AKS_CHECK_LAUNCH("k_finish");
     return AKS_OK;
+}
+
+static int dgks_gs_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w, aks_c128 *d_Hcol,
+                    int64_t ldh, double tol, double eta, int32_t normalize, void *d_ws, int64_t ws_bytes,
+                    int32_t max_dim, void *stream, int raw0) {
+    int rc = gs_project_(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream, raw0);
+    if (rc != AKS_OK) return rc;
+    rc = gs_update_project_(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream, raw0);
+    if (rc != AKS_OK) return rc;
+    rc = gs_update_norm_(n_rows, J, d_V, ldv, d_w, eta, d_ws, ws_bytes, max_dim, stream, raw0);
+    if (rc != AKS_OK) return rc;
+    return aks_gs_finish(n_rows, J, d_w, d_Hcol, ldh, tol, eta, normalize, d_ws, ws_bytes, max_dim, stream);
 }
 
 int aks_dgks_gs(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w, aks_c128 *d_Hcol,
                 int64_t ldh, double tol, double eta, int32_t normalize, void *d_ws, int64_t ws_bytes,
                 int32_t max_dim, void *stream) {
-    int rc = aks_gs_project(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream);
-    if (rc != AKS_OK) return rc;
-    rc = aks_gs_update_project(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream);
-    if (rc != AKS_OK) return rc;
-    rc = aks_gs_update_norm(n_rows, J, d_V, ldv, d_w, eta, d_ws, ws_bytes, max_dim, stream);
-    if (rc != AKS_OK) return rc;
-    return aks_gs_finish(n_rows, J, d_w, d_Hcol, ldh, tol, eta, normalize, d_ws, ws_bytes, max_dim, stream);
+    if (normalize == 2) return fail(AKS_ERR_ARG, "normalize = 2 (deferred) is reserved for aks_arnoldi_expand");
+    return dgks_gs_(n_rows, J, d_V, ldv, d_w, d_Hcol, ldh, tol, eta, normalize, d_ws, ws_bytes, max_dim, stream, J);
 }
 
 // ---- tile-binned form: host planner --------------------------------------------------------
@@ -1844,13 +1968,13 @@ int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *strea
 // communicator is the same collective on every rank.  (tests/mock_rccl runs 2-4 ranks through exactly this code
 // with a stand-in that aborts on any mismatch of order, peer or size.)
 static int shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *d_ws, void *stream, int32_t flags,
-                       Probe *pr) {
+                       Probe *pr, const double *x_div = nullptr) {
     if (A == nullptr || d_x == nullptr || d_y == nullptr) return fail(AKS_ERR_ARG, "null pointer");
     const bool real = (flags & AKS_EXPAND_REAL_PACKED) != 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Comm *c = static_cast<Comm *>(A->comm);
     const bool exchange = c != nullptr && A->any_exchange != 0;
-    if (!exchange) return apply_block(A->diag, d_x, d_y, 0, d_ws, stream, real);
+    if (!exchange) return apply_block(A->diag, d_x, d_y, 0, d_ws, stream, real, x_div);
     if (A->send_counts == nullptr || A->recv_counts == nullptr) return fail(AKS_ERR_ARG, "null exchange counts");
     if ((A->n_send > 0 && (!A->d_send_idx || !A->d_sendbuf)) || (A->n_ghost > 0 && !A->d_ghostbuf))
         return fail(AKS_ERR_ARG, "null exchange buffer");
@@ -1866,11 +1990,18 @@ static int shard_apply(const aks_shard *A, const void *d_x, void *d_y, const voi
     }
     int rc = AKS_OK;
     hipEvent_t done = pr ? pr->begin(AKS_PROBE_PACK, s) : nullptr;
-    if (A->n_send > 0)
-        rc = real ? aks_gather_f64(A->n_send, A->d_send_idx, static_cast<const double *>(d_x),
-                                   static_cast<double *>(A->d_sendbuf), stream)
-                  : aks_gather_c128(A->n_send, A->d_send_idx, static_cast<const aks_c128 *>(d_x),
-                                    static_cast<aks_c128 *>(A->d_sendbuf), stream);
+    if (A->n_send > 0) {                 // (entries of a raw column leave normalised: the receivers know no scale)
+        const int64_t want = (A->n_send + BLOCK - 1) / BLOCK;
+        const dim3 grid((unsigned)(want < 4096 ? want : 4096));
+        if (real)
+            hipLaunchKernelGGL(k_gather<double>, grid, dim3(BLOCK), 0, s, A->n_send, A->d_send_idx,
+                               static_cast<const double *>(d_x), static_cast<double *>(A->d_sendbuf), x_div);
+        else
+            hipLaunchKernelGGL(k_gather<c128>, grid, dim3(BLOCK), 0, s, A->n_send, A->d_send_idx,
+                               static_cast<const c128 *>(d_x), static_cast<c128 *>(A->d_sendbuf), x_div);
+        hipError_t ge = hipGetLastError();
+        if (ge != hipSuccess) rc = hip_fail(ge, "k_gather");
+    }
     if (done) (void)hipEventRecord(done, s);
     if (rc != AKS_OK) return rc;
     hipError_t e = hipEventRecord(c->packed, s);
@@ -1898,7 +2029,7 @@ static int shard_apply(const aks_shard *A, const void *d_x, void *d_y, const voi
     e = hipEventRecord(c->arrived, c->side);
     if (e != hipSuccess) return hip_fail(e, "hipEventRecord");
     done = pr ? pr->begin(AKS_PROBE_DIAG, s) : nullptr;
-    rc = apply_block(A->diag, d_x, d_y, 0, d_ws, stream, real);          // overlaps the exchange
+    rc = apply_block(A->diag, d_x, d_y, 0, d_ws, stream, real, x_div);   // overlaps the exchange
     if (done) (void)hipEventRecord(done, s);
     if (rc != AKS_OK) return rc;
     done = pr ? pr->begin(AKS_PROBE_OFFDIAG, s) : nullptr;               // = wait for the ghosts + off-diagonal block
@@ -1936,33 +2067,83 @@ int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 
     Ws ws;
     int rc = bind_ws(d_ws, ws_bytes, n_panel, max_dim, &ws);
     if (rc != AKS_OK) return rc;
+    // Deferred normalisation: the new columns stay raw (k_finish books their scales instead of dividing), their
+    // readers divide.  Only when this rank's diagonal block is in the binned form, whose phase 1 stages every x entry
+    // exactly once -- the other forms gather an entry once per non-zero and would divide that often.
+    const bool defer = (flags & AKS_EXPAND_DEFER_SCALE) != 0 && A->diag.pb != nullptr;
+    const int norm_mode = defer ? 2 : 1;
     for (int32_t j = start_dim; j < end_dim; ++j) {
         const int32_t J = j + 1;
         aks_c128 *x = d_V + (int64_t)j * ldv;
         aks_c128 *w = d_V + (int64_t)J * ldv;
+        const int raw0 = defer ? start_dim + 1 : J;     // columns <= start_dim are normalised (precondition)
         hipEvent_t done = nullptr;
         if (!(first_w_ready && j == start_dim)) {
             done = pr ? pr->begin(AKS_PROBE_SPMV, s) : nullptr;
-            rc = shard_apply(A, x, w, d_ws, stream, flags, pr);
+            rc = shard_apply(A, x, w, d_ws, stream, flags, pr, defer && j > start_dim ? ws.colscale + j : nullptr);
             if (done) (void)hipEventRecord(done, s);
             if (rc != AKS_OK) return rc;
         }
         done = pr ? pr->begin(AKS_PROBE_ORTHO, s) : nullptr;
         if (c == nullptr) {
-            rc = aks_dgks_gs(n_panel, J, d_V, ldv, w, d_H + j, ldh, tol, eta, 1, d_ws, ws_bytes, max_dim, stream);
+            rc = dgks_gs_(n_panel, J, d_V, ldv, w, d_H + j, ldh, tol, eta, norm_mode, d_ws, ws_bytes, max_dim, stream, raw0);
         } else {
             // the stage kernels with the reductions summed over the ranks in between
-            rc = aks_gs_project(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream);
+            rc = gs_project_(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream, raw0);
             if (rc == AKS_OK) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red1), 2 * (J + 1), stream);
-            if (rc == AKS_OK) rc = aks_gs_update_project(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream);
+            if (rc == AKS_OK) rc = gs_update_project_(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream, raw0);
             if (rc == AKS_OK) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red2), 2 * (J + 1), stream);
-            if (rc == AKS_OK) rc = aks_gs_update_norm(n_panel, J, d_V, ldv, w, eta, d_ws, ws_bytes, max_dim, stream);
+            if (rc == AKS_OK) rc = gs_update_norm_(n_panel, J, d_V, ldv, w, eta, d_ws, ws_bytes, max_dim, stream, raw0);
             if (rc == AKS_OK && !lazy_third) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red3), 2, stream);
-            if (rc == AKS_OK) rc = aks_gs_finish(n_panel, J, w, d_H + j, ldh, tol, eta, 1, d_ws, ws_bytes, max_dim, stream);
+            if (rc == AKS_OK) rc = aks_gs_finish(n_panel, J, w, d_H + j, ldh, tol, eta, norm_mode, d_ws, ws_bytes, max_dim, stream);
         }
         if (done) (void)hipEventRecord(done, s);
         if (rc != AKS_OK) return rc;
     }
+    return AKS_OK;
+}
+
+int aks_shard_apply_col(const aks_shard *A, const aks_c128 *d_V, int64_t ldv, int32_t col, void *d_y, void *d_ws,
+                        int64_t ws_bytes, int32_t max_dim, void *stream, int32_t flags) {
+    if (A == nullptr || d_V == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    if (col < 0 || col > max_dim) return fail(AKS_ERR_ARG, "need 0 <= col <= max_dim");
+    const bool real = (flags & AKS_EXPAND_REAL_PACKED) != 0;
+    const int64_t n_panel = real ? (A->diag.n_rows + 1) / 2 : A->diag.n_rows;
+    Ws ws;
+    int rc = bind_ws(d_ws, ws_bytes, n_panel, max_dim, &ws);
+    if (rc != AKS_OK) return rc;
+    // (the scale is passed on only where it can be applied; a form that cannot never sees a raw column, see
+    // aks_arnoldi_expand)
+    return shard_apply(A, d_V + (int64_t)col * ldv, d_y, d_ws, stream, flags, nullptr,
+                       A->diag.pb != nullptr ? ws.colscale + col : nullptr);
+}
+
+int aks_truncate_ws(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv, const aks_c128 *d_Qp,
+                    int32_t col0, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+    if (n_rows <= 0 || d_V == nullptr || d_Qp == nullptr) return fail(AKS_ERR_ARG, "bad argument");
+    if (m < 1 || m > AKS_MAX_DIM) return fail(AKS_ERR_UNSUPPORTED, "m outside [1, AKS_MAX_DIM]");
+    if (p < 1 || p >= m + 1) return fail(AKS_ERR_ARG, "need 1 <= p <= m");
+    if (p > AKS_MAX_TRUNC) return fail(AKS_ERR_UNSUPPORTED, "p exceeds AKS_MAX_TRUNC");
+    if (ldv < n_rows) return fail(AKS_ERR_ARG, "ldv < n_rows");
+    if (col0 < 0 || col0 + m > max_dim) return fail(AKS_ERR_ARG, "need 0 <= col0 and col0 + m <= max_dim");
+    Ws ws;
+    int rc = bind_ws(d_ws, ws_bytes, n_rows, max_dim, &ws);
+    if (rc != AKS_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    c128 *V = reinterpret_cast<c128 *>(d_V);
+    const c128 *Q = reinterpret_cast<const c128 *>(d_Qp);
+    const double *cs = ws.colscale + col0;
+    rc = AKS_ERR_UNSUPPORTED;
+    switch ((p + 7) / 8) {
+#define M(N) case N: rc = launch_truncate_mfma<N>(s, n_rows, m, p, V, ldv, Q, V, ldv, 1, false, cs); break;
+        M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12)
+#undef M
+        default: return fail(AKS_ERR_UNSUPPORTED, "p exceeds AKS_MAX_TRUNC");
+    }
+    if (rc != AKS_OK) return rc;
+    // every column the kernel wrote (col0 .. col0 + p) is normalised now, and the ones behind them are dead
+    hipError_t e = hipMemsetAsync(ws.colscale + col0, 0, (size_t)(m + 1) * sizeof(double), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(colscale)");
     return AKS_OK;
 }
 
@@ -2088,7 +2269,7 @@ int aks_gather_c128(int64_t count, const int32_t *d_idx, const aks_c128 *d_src, 
     const int64_t want = (count + BLOCK - 1) / BLOCK;
     const dim3 grid((unsigned)(want < 4096 ? want : 4096));
     hipLaunchKernelGGL(k_gather<c128>, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), count, d_idx,
-                       reinterpret_cast<const c128 *>(d_src), reinterpret_cast<c128 *>(d_dst));
+                       reinterpret_cast<const c128 *>(d_src), reinterpret_cast<c128 *>(d_dst), nullptr);
     AKS_CHECK_LAUNCH("k_gather");
     return AKS_OK;
 }
@@ -2099,7 +2280,7 @@ int aks_gather_f64(int64_t count, const int32_t *d_idx, const double *d_src, dou
     const int64_t want = (count + BLOCK - 1) / BLOCK;
     const dim3 grid((unsigned)(want < 4096 ? want : 4096));
     hipLaunchKernelGGL(k_gather<double>, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), count, d_idx, d_src,
-                       d_dst);
+                       d_dst, nullptr);
     AKS_CHECK_LAUNCH("k_gather_f64");
     return AKS_OK;
 }

@@ -80,6 +80,8 @@ typedef struct aks_ws_layout {
     int32_t ld_partial;    /* m + 2                                                      */
     int32_t red_len;       /* m + 2 (c128 elements in red1 / red2)                       */
     int32_t pad_;
+    int64_t colscale_off;  /* AKS_MAX_DIM + 2 doubles: scale of basis column c, 0 = the column is normalised
+                              (deferred normalisation, AKS_EXPAND_DEFER_SCALE); zeroed by aks_workspace_init  */
 } aks_ws_layout;
 
 const char *aks_last_error(void);
@@ -327,10 +329,23 @@ int aks_shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *
  * flags: AKS_EXPAND_FROM_W  V[:, start_dim+1] already holds A V[:, start_dim] (applied ahead of time,
  *                           e.g. while the host did the restart's Schur step): the first step starts
  *                           at the orthogonalisation; identical results;
- *        AKS_EXPAND_REAL_PACKED  see "real-packed mode" below. */
+ *        AKS_EXPAND_REAL_PACKED  see "real-packed mode" below.
+ *        AKS_EXPAND_DEFER_SCALE  deferred normalisation: the reference divides every new basis vector by its norm
+ *                           at once (decomposition.py:66), a pass of 32 n bytes per step that only scales.  With
+ *                           this flag the new columns V[:, start_dim+1 .. end_dim] stay RAW -- column c holds
+ *                           beta_c v_c and the workspace's colscale[c] = beta_c -- and every reader inside the library
+ *                           divides a raw column's entries as it loads them (the same IEEE division, so every
+ *                           number that enters the arithmetic is bit for bit the one the normalised column would
+ *                           have held).  Precondition: columns 0 .. start_dim are normalised.  Honoured only while
+ *                           this rank's diagonal block is in the binned form (the other SpMV forms would divide an
+ *                           x entry once per non-zero); otherwise ignored.  The caller must follow the expansion
+ *                           with aks_truncate_ws (which reads raw columns and writes normalised ones) before
+ *                           anything but aks_arnoldi_expand / aks_shard_apply_col / aks_truncate_ws reads V.  H,
+ *                           the control block and every result are the same with and without the flag. */
 #define AKS_EXPAND_FROM_W 1
 #define AKS_EXPAND_REAL_PACKED 2
 #define AKS_EXPAND_LAZY_THIRD 4
+#define AKS_EXPAND_DEFER_SCALE 8
 int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 *d_H, int64_t ldh,
                        int32_t start_dim, int32_t end_dim, double tol, double eta, void *d_ws,
                        int64_t ws_bytes, int32_t max_dim, void *probe, void *stream, int32_t flags);
@@ -362,12 +377,24 @@ int aks_gather_f64(int64_t count, const int32_t *d_idx, const double *d_src, dou
  * dimension of this rank's rows; V columns are real-packed, ldv counts complex slots >= ceil(n_rows/2); the
  * workspace is laid out for ceil(n_rows/2) rows and set to real mode. */
 
+/* y = A V[:, col] for this rank's rows, where column `col` of the basis may be raw (its scale is taken from the
+ * workspace): the look-ahead product A V[:, end_dim] behind an expansion that deferred its normalisations. */
+int aks_shard_apply_col(const aks_shard *A, const aks_c128 *d_V, int64_t ldv, int32_t col, void *d_y, void *d_ws,
+                        int64_t ws_bytes, int32_t max_dim, void *stream, int32_t flags);
+
 /* ---- restart compression: replaces krylov_schur.py:78 and :81 --------------
  * V[:, :p] = V[:, :m] @ Qp   (in place: a wave reads all m columns of its 64 rows before it
  * overwrites any; f64 MFMA)   and   V[:, p] = V[:, m].   d_Qp is m x p complex128, row-major
  * (ld = p).  Limits: p <= AKS_MAX_TRUNC and ceil(m/4)*4 * ceil(p/8)*8 * 16 B <= 160 KiB (Qp in LDS). */
 int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv,
                  const aks_c128 *d_Qp, void *stream);
+
+/* The same for a basis whose columns may be raw.  d_V points at the FIRST column of the (sub-)basis, which is
+ * column col0 of the whole basis (0, or l with l locked columns in front): entries of raw columns are divided by
+ * their scales (workspace colscale[col0 + c]) as they are read, the columns written are normalised, and the scales
+ * of columns col0 .. col0 + m are cleared afterwards (stream-ordered). */
+int aks_truncate_ws(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv, const aks_c128 *d_Qp,
+                    int32_t col0, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream);
 
 /* ---- Ritz vectors: replaces  ritz_vectors = V_m @ S  (decomposition.py:125) and
  * eivecs = V[:, :nev] @ Y  (explicit_restarts.py:167) --------------------------------

@@ -321,6 +321,12 @@ class FakeHip:
                              stream)
         return 0
 
+    def aks_shard_apply_col(self, A, V, ldv, col, y, ws, ws_bytes, max_dim, stream, flags):
+        return self.aks_shard_apply(A, _addr(V) + 16 * ldv * col, y, ws, stream, flags)     # (the stand-in never defers)
+
+    def aks_truncate_ws(self, n, m, p, V, ldv, Qp, col0, ws, ws_bytes, max_dim, stream):
+        return self.aks_truncate(n, m, p, V, ldv, Qp, stream)
+
     # ---- restart compression ---------------------------------------------------------------
     def aks_truncate(self, n, m, p, V, ldv, Qp, stream):
         self.calls.append("truncate")

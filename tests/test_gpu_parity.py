@@ -333,6 +333,40 @@ def test_partial_schur_with_binned_spmv(amd):
                            residual_matrix=A)
 
 
+@pytest.mark.parametrize("mode", ["complex", "real", "locking", "graph"])
+def test_deferred_normalisation_is_bitwise_neutral(amd, monkeypatch, mode):
+    """With the operator in the binned form the Krylov-Schur drivers leave new basis columns RAW (AKS_EXPAND_DEFER_SCALE:
+    no 32 n byte normalisation pass per step); every reader divides by the column's scale on the fly -- the same
+    IEEE division.  Q, T and History must be the bits of the run that normalises at once (AKS_DEFER_SCALE=0)."""
+    from arnoldi_amd.engine import CsrOperator
+
+    g8 = load_golden("g8_random_planted")
+    A = _planted_like_golden(int(g8["n"]))
+    kw = dict(max_dim=20, sort_function=oracle.arg_largest_magnitude)
+    if mode == "real":
+        kw["arithmetic"] = "real"
+    if mode == "locking":
+        kw["locking"] = True
+    monkeypatch.setenv("AKS_GRAPH", "1" if mode == "graph" else "0")
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("AKS_DEFER_SCALE", flag)
+        np.random.seed(0)
+        st = {}
+        Q, T, h = amd.partial_schur(CsrOperator(A, spmv_form="binned", real=(mode == "real")), 5, stats=st, **kw)
+        assert (st["deferred_normalisations"] > 0) == (flag == "1")
+        out.append((Q, T, h.restarts.copy(), h.matvecs.copy(), st["restarts"]))
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+    if mode == "complex":                                     # ... and those are the reference's restart counts
+        np.testing.assert_array_equal(out[1][2], g8["s0_hist_restarts"])
+    # a form that cannot divide while it gathers never defers
+    np.random.seed(0)
+    st = {}
+    amd.partial_schur(CsrOperator(A, spmv_form="csr"), 5, stats=st, max_dim=20, sort_function=oracle.arg_largest_magnitude)
+    assert st["deferred_normalisations"] == 0
+
+
 def test_two_host_threads_solve_concurrently(amd):
     """The library keeps no mutable global state (threading row): two solves driven from two host
     threads at the same time, each on its own stream -- one through the binned form (128 KiB of dynamic LDS per
@@ -767,6 +801,14 @@ def test_row_sharded_c_driven_path_ranks_share_the_gpu(amd, tmp_path, ranks):
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     check_dist_verdicts(run_dist_worker(tmp_path, ranks, "gloo", "cuda", extra=["--native-mock"]), native=True)
+    if ranks == 2:
+        # the same with every block in the binned form: the expansions then defer their normalisations, so the ghost
+        # entries of raw columns are divided as they are packed and the look-ahead product reads a raw column
+        os.environ["AKS_SPMV_FORM"] = "binned"
+        try:
+            check_dist_verdicts(run_dist_worker(tmp_path, ranks, "gloo", "cuda", extra=["--native-mock"]), native=True)
+        finally:
+            del os.environ["AKS_SPMV_FORM"]
 
 
 def test_rccl_collectives_one_rank(amd, tmp_path):
