@@ -50,7 +50,7 @@ class Ctrl(C.Structure):
         ("beta_in", C.c_double),
         ("beta", C.c_double),
         ("real_mode", C.c_int32),
-        ("reserved_i", C.c_int32),
+        ("deferred", C.c_int32),
         ("reserved", C.c_double * 3),
     ]
 

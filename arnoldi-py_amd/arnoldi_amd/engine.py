@@ -247,6 +247,7 @@ class ArnoldiContext:
         # deferred normalisation of new basis columns (see expand): AKS_DEFER_SCALE=0 switches it off
         self.allow_defer = os.environ.get("AKS_DEFER_SCALE", "1") != "0"
         self._raw_from = None       # first raw column of the basis, if an expansion left any
+        self._raw_scale = {}        # column -> its scale beta (the host's copy of the workspace's colscale)
         self.deferred_expansions = 0
         self.discarded_second_passes = self.discarded_steps = self.discarded_applies = 0   # work of repeated expansions
         self.last_ctrl = None
@@ -284,7 +285,7 @@ class ArnoldiContext:
         self._look_valid = False
         native = isinstance(op, CsrOperator) and op.c_driven and not self.force_chained
         defer = bool(defer_scale and native and self.allow_defer and op.spmv_form == "binned")
-        if self._raw_from is not None and start >= self._raw_from:
+        if self._raw_from is not None and (start > self._raw_from or (start == self._raw_from and not defer)):
             raise _hip.HipLibraryError("expansion from a raw column: the basis must be truncated first")
         multi = self.comm is not None and self.comm.active
         # Multi-rank: the norm after a second DGKS pass needs a third all-reduce.  While no step has needed a
@@ -333,8 +334,19 @@ class ArnoldiContext:
             self._look_col = 1 - self._look_col
             self._look_valid = not ctrl.broken
         n_iter = int(ctrl.n_iter) if ctrl.broken else end
-        if defer:
-            self._raw_from = start + 1      # columns start+1 .. n_iter hold beta v until the next truncation
+        if defer and n_iter > start and not int(ctrl.deferred):
+            # the library did not honour the flag (its own check of the block's form, or a stand-in): the columns are
+            # normalised -- which is only consistent if the start column was
+            if self._raw_from is not None:
+                raise _hip.HipLibraryError("the expansion normalised its columns although it started from a raw one")
+            defer = False
+        if defer and n_iter > start:
+            # columns start+1 .. n_iter hold beta_c v_c until the next truncation (beta_c = H[c, c-1]); column `start`
+            # itself may be the raw column the previous truncation carried over (its scale is already recorded)
+            if self._raw_from is None or self._raw_from > start:
+                self._raw_from = start + 1
+            for c in range(start + 1, n_iter + (0 if ctrl.broken else 1)):
+                self._raw_scale[c] = float(Hd[c, c - 1].real)
             self.deferred_expansions += 1
         self.matvecs += n_iter - start
         if not np.iscomplexobj(H):
@@ -432,19 +444,30 @@ class ArnoldiContext:
         return exchange + (2 if self.lazy_third else 3)
 
     # -- seam 2 ------------------------------------------------------------------
+    def _fold_scales(self, Q, col0, m, p):
+        """Rows of the restart coefficients that multiply RAW columns are divided by those columns' scales (the
+        columns hold beta v), and the book-keeping moves on: column ``col0 + p`` becomes a bit copy of column
+        ``col0 + m`` and inherits its scale."""
+        Q = np.array(Q, dtype=C128, copy=True).reshape(m, p)
+        if self._raw_from is not None:
+            for c in range(max(self._raw_from, col0), col0 + m):
+                Q[c - col0, :] /= self._raw_scale[c]
+            carried = self._raw_scale.get(col0 + m) if col0 + m >= self._raw_from else None
+            self._raw_scale = {} if carried is None else {col0 + p: carried}
+            self._raw_from = None if carried is None else col0 + p
+        return Q
+
     def truncate(self, Qp, m, p):
-        Qd = torch.from_numpy(np.ascontiguousarray(Qp, dtype=C128)).to(self.basis.device)
-        dev.truncate(self.basis, m, p, Qd, self.ws)         # (reads raw columns, writes normalised ones)
-        self._raw_from = None
+        Qd = torch.from_numpy(np.ascontiguousarray(self._fold_scales(Qp, 0, m, p))).to(self.basis.device)
+        dev.truncate(self.basis, m, p, Qd, self.ws)         # (raw columns x scaled coefficients: normalised results)
 
     def truncate_active(self, Zp, l, m, p):
         """Restart compression behind ``l`` locked columns (krylov_schur_locking.py):
         ``V[:, l:p] = V[:, l:m] @ Zp`` and ``V[:, p] = V[:, m]`` -- ``aks_truncate`` on the sub-basis that
         starts at column ``l``; the locked columns are neither read nor written."""
         b = self.basis
-        Zd = torch.from_numpy(np.ascontiguousarray(Zp, dtype=C128).reshape(m - l, p - l)).to(b.device)
+        Zd = torch.from_numpy(np.ascontiguousarray(self._fold_scales(Zp, l, m - l, p - l))).to(b.device)
         dev.truncate(b, m - l, p - l, Zd, self.ws, col0=l)
-        self._raw_from = None
 
     # -- data movement --------------------------------------------------------------
     def set_start_vector(self, v_full):

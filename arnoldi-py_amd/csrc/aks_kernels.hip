@@ -507,6 +507,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(int64_t n, int J, c128 *__rest
         if (threadIdx.x == 0) {
             if (!broke && normalize) Hcol[(int64_t)J * ldh] = make_double2(beta, 0.0);  // decomposition.py:65
             if (!broke && normalize == 2) cs[J] = beta;
+            ctrl->deferred = normalize == 2 ? 1 : 0;
             ctrl->beta_in = sqrt(red1[J].x);
             ctrl->beta = beta;
             ctrl->steps_done += 1;
@@ -732,7 +733,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 template <int MT, int NS>   // NS row sub-tiles of 16 per wave (4, or 2 when MT is large)
 __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p, c128 *V, int64_t ldv,
                                                         const c128 *__restrict__ Qp, c128 *O, int64_t ldo,
-                                                        int copy_last, const double *__restrict__ cs) {
+                                                        int copy_last) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     c128 *qs = reinterpret_cast<c128 *>(smem_raw);      // [mpad][PP] complex, zero padded
     constexpr int PP = MT * 8;
@@ -759,7 +760,6 @@ __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p
         for (int s = 0; s < NS; ++s) rows[s] = min(row0 + s * 16 + r16, n - 1);
         for (int c0 = 0; c0 < mpad; c0 += 4) {
             const int c = min(c0 + g, m - 1);            // padded K slots re-read a valid column; their Q rows are 0
-            const double sc = cs != nullptr ? cs[c] : 0.0;   // raw column (deferred normalisation): divide as it is read
             c128 v[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -768,11 +768,6 @@ __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p
 #else
                 v[s] = V[rows[s] + (int64_t)c * ldv];
 #endif
-            }
-            if (__builtin_amdgcn_ballot_w64(is_raw(sc)) != 0ull) {           // (skipped while all four columns are normalised)
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    if (is_raw(sc)) v[s] = unscale(v[s], sc);
             }
             const c128 *qrow = qs + (c0 + g) * PP;
 #pragma unroll
@@ -812,17 +807,22 @@ __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p
         // V[:, p] = V[:, m] (krylov_schur.py:81).  Column m is never a destination of the stores
         // above (they end at column p - 1 <= m - 1), so it can be read here.
         if (copy_last && g == 0) {
-            const double sm = cs != nullptr ? cs[m] : 0.0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int64_t row = row0 + s * 16 + r16;
-                if (row < n) {
-                    c128 vm = V[row + (int64_t)m * ldv];
-                    if (is_raw(sm)) vm = unscale(vm, sm);
-                    O[row + (int64_t)p * ldo] = vm;
-                }
+                if (row < n) O[row + (int64_t)p * ldo] = V[row + (int64_t)m * ldv];
             }
         }
+    }
+}
+
+// after a restart compression of columns [0, m] into [0, p]: the p new columns are normalised; column p is a bit
+// copy of column m and inherits its scale; columns behind it are dead
+__global__ void k_colscale_after_truncate(double *__restrict__ cs, int m, int p) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double sm = cs[m];
+        for (int c = 0; c <= m; ++c) cs[c] = 0.0;
+        cs[p] = sm;
     }
 }
 
@@ -1215,7 +1215,7 @@ template <typename K> int raise_lds(K kernel, size_t bytes, const char *where) {
 
 template <int MT>
 int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_t ldv, const c128 *Qp, c128 *O,
-                         int64_t ldo, int copy_last, bool init_only = false, const double *cs = nullptr) {
+                         int64_t ldo, int copy_last, bool init_only = false) {
     // rows per wave = 16 NS: 128 for p <= 16 (more loads in flight per K-step: 1.041 -> 1.011 ms at m = 20, p = 10,
     // n = 10M; the read/write mix of this kernel streams at ~5.4 TB/s = 0.95 ms), fewer as the accumulators grow
     constexpr int NS = MT <= 2 ? 8 : (MT <= 9 ? 4 : 2);      // keeps NS * MT * 8 accumulator registers below the spill point
@@ -1224,7 +1224,7 @@ int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_
     if (init_only) return raise_lds(k_truncate_mfma<MT, NS>, AKS_LDS_BYTES, "hipFuncSetAttribute(k_truncate_mfma)");
     const int64_t want = ((n + 16 * NS - 1) / (16 * NS) + WAVES - 1) / WAVES;
     const dim3 grid((unsigned)(want < 4096 ? want : 4096));
-    hipLaunchKernelGGL((k_truncate_mfma<MT, NS>), grid, dim3(BLOCK), smem, s, n, m, p, V, ldv, Qp, O, ldo, copy_last, cs);
+    hipLaunchKernelGGL((k_truncate_mfma<MT, NS>), grid, dim3(BLOCK), smem, s, n, m, p, V, ldv, Qp, O, ldo, copy_last);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         hip_fail(e, "k_truncate_mfma");
@@ -2076,11 +2076,11 @@ int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 
         const int32_t J = j + 1;
         aks_c128 *x = d_V + (int64_t)j * ldv;
         aks_c128 *w = d_V + (int64_t)J * ldv;
-        const int raw0 = defer ? start_dim + 1 : J;     // columns <= start_dim are normalised (precondition)
+        const int raw0 = defer ? start_dim : J;         // columns < start_dim are normalised (precondition)
         hipEvent_t done = nullptr;
         if (!(first_w_ready && j == start_dim)) {
             done = pr ? pr->begin(AKS_PROBE_SPMV, s) : nullptr;
-            rc = shard_apply(A, x, w, d_ws, stream, flags, pr, defer && j > start_dim ? ws.colscale + j : nullptr);
+            rc = shard_apply(A, x, w, d_ws, stream, flags, pr, defer ? ws.colscale + j : nullptr);
             if (done) (void)hipEventRecord(done, s);
             if (rc != AKS_OK) return rc;
         }
@@ -2132,18 +2132,16 @@ int aks_truncate_ws(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t
     hipStream_t s = static_cast<hipStream_t>(stream);
     c128 *V = reinterpret_cast<c128 *>(d_V);
     const c128 *Q = reinterpret_cast<const c128 *>(d_Qp);
-    const double *cs = ws.colscale + col0;
     rc = AKS_ERR_UNSUPPORTED;
     switch ((p + 7) / 8) {
-#define M(N) case N: rc = launch_truncate_mfma<N>(s, n_rows, m, p, V, ldv, Q, V, ldv, 1, false, cs); break;
+#define M(N) case N: rc = launch_truncate_mfma<N>(s, n_rows, m, p, V, ldv, Q, V, ldv, 1); break;
         M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12)
 #undef M
         default: return fail(AKS_ERR_UNSUPPORTED, "p exceeds AKS_MAX_TRUNC");
     }
     if (rc != AKS_OK) return rc;
-    // every column the kernel wrote (col0 .. col0 + p) is normalised now, and the ones behind them are dead
-    hipError_t e = hipMemsetAsync(ws.colscale + col0, 0, (size_t)(m + 1) * sizeof(double), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(colscale)");
+    hipLaunchKernelGGL(k_colscale_after_truncate, dim3(1), dim3(64), 0, s, ws.colscale + col0, (int)m, (int)p);
+    AKS_CHECK_LAUNCH("k_colscale_after_truncate");
     return AKS_OK;
 }
 

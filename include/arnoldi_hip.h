@@ -64,7 +64,7 @@ typedef struct aks_ctrl {
     double beta_in;        /* ||w|| before orthogonalisation, last step (ortho.py:92)    */
     double beta;           /* ||w|| after orthogonalisation, last step (ortho.py:98/105) */
     int32_t real_mode;     /* 1: real-packed panel (aks_workspace_set_real); read by the reductions */
-    int32_t reserved_i;
+    int32_t deferred;      /* 1: the last step left its new column raw (AKS_EXPAND_DEFER_SCALE was honoured)  */
     double reserved[3];
 } aks_ctrl;
 
@@ -336,12 +336,13 @@ int aks_shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *
  *                           beta_c v_c and the workspace's colscale[c] = beta_c -- and every reader inside the library
  *                           divides a raw column's entries as it loads them (the same IEEE division, so every
  *                           number that enters the arithmetic is bit for bit the one the normalised column would
- *                           have held).  Precondition: columns 0 .. start_dim are normalised.  Honoured only while
+ *                           have held).  Precondition: columns 0 .. start_dim - 1 are normalised (column start_dim
+ *                           may be the raw column a restart compression carried over).  Honoured only while
  *                           this rank's diagonal block is in the binned form (the other SpMV forms would divide an
  *                           x entry once per non-zero); otherwise ignored.  The caller must follow the expansion
- *                           with aks_truncate_ws (which reads raw columns and writes normalised ones) before
- *                           anything but aks_arnoldi_expand / aks_shard_apply_col / aks_truncate_ws reads V.  H,
- *                           the control block and every result are the same with and without the flag. */
+ *                           with aks_truncate_ws (scaled coefficients, see there) before anything but
+ *                           aks_arnoldi_expand / aks_shard_apply_col / aks_truncate_ws reads V.  H and the control
+ *                           block of an expansion are bit for bit the same with and without the flag. */
 #define AKS_EXPAND_FROM_W 1
 #define AKS_EXPAND_REAL_PACKED 2
 #define AKS_EXPAND_LAZY_THIRD 4
@@ -389,10 +390,14 @@ int aks_shard_apply_col(const aks_shard *A, const aks_c128 *d_V, int64_t ldv, in
 int aks_truncate(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv,
                  const aks_c128 *d_Qp, void *stream);
 
-/* The same for a basis whose columns may be raw.  d_V points at the FIRST column of the (sub-)basis, which is
- * column col0 of the whole basis (0, or l with l locked columns in front): entries of raw columns are divided by
- * their scales (workspace colscale[col0 + c]) as they are read, the columns written are normalised, and the scales
- * of columns col0 .. col0 + m are cleared afterwards (stream-ordered). */
+/* The same for a basis whose columns c >= some c0 are raw (an expansion with AKS_EXPAND_DEFER_SCALE).  The CALLER folds
+ * the scales into the coefficients: row c of d_Qp must hold Qp[c, :] / beta_c for a raw column c (beta_c = H[c, c-1],
+ * known to the host) -- the kernel then multiplies raw entries by scaled coefficients, no division on the device
+ * (this is the one place where deferring changes the arithmetic: (beta v) (q / beta) instead of v q, a rounding-level
+ * difference once per restart).  V[:, p] = V[:, m] is a bit copy: column p inherits the scale of column m, i.e. the
+ * next expansion starts from a raw column.  d_V points at the FIRST column of the (sub-)basis, which is column col0 of
+ * the whole basis (0, or l with l locked columns in front); the scales of columns col0 .. col0 + m are updated
+ * accordingly (stream-ordered). */
 int aks_truncate_ws(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv, const aks_c128 *d_Qp,
                     int32_t col0, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream);
 
