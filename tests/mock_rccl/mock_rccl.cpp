@@ -28,7 +28,7 @@ namespace {
 
 constexpr int MAX_RANKS = 8;
 constexpr size_t AR_CAP = 8192;                 // doubles per all-reduce
-constexpr size_t BOX_CAP = 4u << 20;            // bytes per (source, destination) mailbox
+constexpr size_t BOX_CAP = 16u << 20;           // bytes per (source, destination) mailbox (the segment is sparse)
 constexpr double TIMEOUT_S = 60.0;
 
 struct Shared {

@@ -804,7 +804,7 @@ def test_row_sharded_two_ranks_share_the_gpu(amd, tmp_path):
     check_dist_verdicts(run_dist_worker(tmp_path, 2, "gloo", "cuda"))
 
 
-@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("ranks", [2, 3, 4])
 def test_row_sharded_c_driven_path_ranks_share_the_gpu(amd, tmp_path, ranks):
     """The C-DRIVEN multi-rank path -- aks_arnoldi_expand issuing the ghost exchange (grouped send / recv on the
     side stream, peer offsets from send_counts / recv_counts) and the stage all-reduces itself, the lazy third
@@ -827,6 +827,35 @@ def test_row_sharded_c_driven_path_ranks_share_the_gpu(amd, tmp_path, ranks):
             check_dist_verdicts(run_dist_worker(tmp_path, ranks, "gloo", "cuda", extra=["--native-mock"]), native=True)
         finally:
             del os.environ["AKS_SPMV_FORM"]
+
+
+def test_bench_multi_rank_line_on_the_c_driven_path(amd):
+    """``bench.py --gpus 2`` as the driver starts it, rehearsed on ONE GPU: two ranks share it, the library's own
+    communicator (C-driven ghost exchange + stage all-reduces) runs over tests/mock_rccl, gloo carries the set-up.
+    The line must come from the C path and carry the per-SpMV device-time split of rank 0."""
+    import json
+    import subprocess
+    import sys
+
+    from test_host_logic import ROOT
+
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    env = dict(os.environ, AKS_LIB_PATH=os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"),
+               AKS_COMM_OVER_GLOO="1", AKS_BENCH_BACKEND="gloo", AKS_GRAPH="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "400000", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and "issued from C" in out["config"]["path"] and out["value"] > 0
+    ex = out["config"]["exchange"]
+    split = ex["spmv_device_ms_rank0"]
+    assert ex["ghost_bytes_received_per_spmv_rank0"] > 0 and ex["collectives_per_arnoldi_step"] == 3
+    assert all(split[k] is not None and split[k] > 0 for k in ("pack", "exchange", "diag_block", "ghost_wait_plus_offdiag_block"))
 
 
 def test_rccl_collectives_one_rank(amd, tmp_path):
