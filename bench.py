@@ -596,8 +596,12 @@ def native_preflight(world, rank, local_rank, timeout_s=300):
     dist.init_process_group("gloo")
     port = [free_port() if rank == 0 else None]
     dist.broadcast_object_list(port, src=0)
-    env = dict(os.environ, MASTER_PORT=str(port[0]), RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world))
+    env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port[0]),
+               RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world))
     env.pop("AKS_DIST_PATH", None)
+    for k in [k for k in env if k.startswith("TORCHELASTIC_") or k.startswith("TORCH_NCCL_ASYNC")]:
+        env.pop(k)        # under torch.distributed.run the ranks are clients of the agent's store; the children's rank 0
+                          # has to host a store of its own on the fresh port
     verdict = {"ok": False}
     t0 = time.perf_counter()
     proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--leg", "preflight"], env=env,
