@@ -38,6 +38,7 @@
 // workgroup barriers in k_pb_phase2): results are bitwise reproducible.  Panel streams that are
 // read once (the Krylov basis in the Gram-Schmidt and compression kernels) use non-temporal loads.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -74,6 +75,16 @@ int hip_fail(hipError_t e, const char *where) {
         hipError_t e_ = hipGetLastError();                       \
         if (e_ != hipSuccess) return hip_fail(e_, where);        \
     } while (0)
+
+// A kernel launch that carries a start and / or a stop event (bench.py's probe): the events take the kernel's own
+// begin / end time stamps -- no marker packets in front of and behind the kernel, which cost a 20-us launch 10 % and
+// sit inside the timed region.
+struct EvPair { hipEvent_t start = nullptr, stop = nullptr; };
+template <typename K, typename... Args>
+inline void launch_timed(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, Args... args) {
+    if (ev0 == nullptr && ev1 == nullptr) hipLaunchKernelGGL(kernel, grid, block, smem, s, args...);
+    else hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)smem, s, ev0, ev1, 0u, args...);
+}
 
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
@@ -1129,8 +1140,8 @@ int check_panel(int64_t n_rows, int32_t J, const void *V, int64_t ldv, const voi
 
 template <int NC>
 void launch_proj_nc(dim3 grid, hipStream_t s, int64_t n, int c0, const c128 *V, int64_t ldv, const c128 *w,
-                    c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0) {
-    hipLaunchKernelGGL(k_proj<NC>, grid, dim3(BLOCK), 0, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0);
+                    c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0, hipEvent_t ev0) {
+    launch_timed(k_proj<NC>, grid, dim3(BLOCK), 0, s, ev0, (hipEvent_t) nullptr, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0);
 }
 template <int NC>
 void launch_update_proj_nc(dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
@@ -1143,9 +1154,10 @@ void launch_update_proj_nc(dim3 grid, hipStream_t s, int64_t n, const c128 *V, i
     M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31) M(32)
 
 void dispatch_proj(int nc, dim3 grid, hipStream_t s, int64_t n, int c0, const c128 *V, int64_t ldv,
-                   const c128 *w, c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0) {
+                   const c128 *w, c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0,
+                   hipEvent_t ev0) {
     switch (nc) {
-#define M(N) case N: launch_proj_nc<N>(grid, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0); break;
+#define M(N) case N: launch_proj_nc<N>(grid, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0, ev0); break;
         AKS_NC_CASES(M)
 #undef M
         default: break;
@@ -1190,14 +1202,15 @@ void dispatch_update_proj_split(int J, dim3 grid, hipStream_t s, int64_t n, cons
 
 // projection of all J columns in groups of <= NC_MAX columns of (nearly) equal width
 void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c128 *V, int64_t ldv,
-                        const c128 *w, c128 *red_out, c128 *zero_slot, int raw0) {
+                        const c128 *w, c128 *red_out, c128 *zero_slot, int raw0, hipEvent_t ev0 = nullptr) {
     const int groups = (J + NC_MAX - 1) / NC_MAX;
     const int base = J / groups, extra = J % groups;
     const dim3 grid(ws.lay.n_blocks);
     int c0 = 0;
     for (int g = 0; g < groups; ++g) {
         const int nc = base + (g < extra ? 1 : 0);
-        dispatch_proj(nc, grid, s, n, c0, V, ldv, w, ws.partial, ws.lay.ld_partial, g == 0 ? J : -1, ws.ctrl, ws.colscale, raw0);
+        dispatch_proj(nc, grid, s, n, c0, V, ldv, w, ws.partial, ws.lay.ld_partial, g == 0 ? J : -1, ws.ctrl, ws.colscale, raw0,
+                      g == 0 ? ev0 : nullptr);
         c0 += nc;
     }
     hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
@@ -1244,6 +1257,14 @@ struct Probe {
         (void)hipEventRecord(start[used], s);
         return stop[used++];
     }
+    EvPair reserve(int32_t t) {          // a pair handed to launch_timed instead of being recorded around the launch
+        EvPair e;
+        if (used >= (int32_t)start.size()) return e;
+        tag[used] = t;
+        e.start = start[used];
+        e.stop = stop[used++];
+        return e;
+    }
 };
 
 struct Comm {
@@ -1260,32 +1281,23 @@ int nccl_fail(ncclResult_t r, const char *where) {
 
 // one CSR block applied with whichever form its plan selects; vectors complex128 or (real) float64
 int launch_pb_any(const aks_pb_matrix *A, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
-                  const double *x_div);
+                  const double *x_div, EvPair ev);
 
 // (x_div: scale of a raw input column -- deferred normalisation; only the binned form can apply it, and
 // aks_arnoldi_expand defers only when the diagonal block is in that form)
+int sell_spmv_any(const aks_sell_matrix *A, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
+                  EvPair ev);
+int csr_spmv_any(const aks_csr_block &B, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
+                 EvPair ev);
+
 int apply_block(const aks_csr_block &B, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
-                const double *x_div = nullptr) {
+                const double *x_div = nullptr, EvPair ev = EvPair()) {
     if (B.n_rows <= 0) return AKS_OK;
-    if (x_div != nullptr) {
-        if (B.pb == nullptr) return fail(AKS_ERR_ARG, "a raw input column needs the binned form");
-        return launch_pb_any(B.pb, x, y, accumulate, d_ws, stream, real, x_div);
-    }
-    if (real) {
-        if (B.values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
-        const double *xr = static_cast<const double *>(x);
-        double *yr = static_cast<double *>(y);
-        if (B.sell != nullptr) return aks_sell_spmv_real(B.sell, xr, yr, accumulate, d_ws, stream);
-        if (B.pb != nullptr) return aks_pb_spmv_real(B.pb, xr, yr, accumulate, d_ws, stream);
-        return aks_csr_spmv_real(B.n_rows, B.d_indptr, B.d_indices, static_cast<const double *>(B.d_values), B.d_tiles,
-                                 B.n_tiles, B.lanes_per_row, xr, yr, accumulate, d_ws, stream);
-    }
-    const aks_c128 *xc = static_cast<const aks_c128 *>(x);
-    aks_c128 *yc = static_cast<aks_c128 *>(y);
-    if (B.sell != nullptr) return aks_sell_spmv(B.sell, xc, yc, accumulate, d_ws, stream);
-    if (B.pb != nullptr) return aks_pb_spmv(B.pb, xc, yc, accumulate, d_ws, stream);
-    return aks_csr_spmv(B.n_rows, B.d_indptr, B.d_indices, B.d_values, B.values_complex, B.d_tiles, B.n_tiles,
-                        B.lanes_per_row, xc, yc, accumulate, d_ws, stream);
+    if (x_div != nullptr && B.pb == nullptr) return fail(AKS_ERR_ARG, "a raw input column needs the binned form");
+    if (real && B.values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
+    if (B.sell != nullptr) return sell_spmv_any(B.sell, x, y, accumulate, d_ws, stream, real, ev);
+    if (B.pb != nullptr) return launch_pb_any(B.pb, x, y, accumulate, d_ws, stream, real, x_div, ev);
+    return csr_spmv_any(B, x, y, accumulate, d_ws, stream, real, ev);
 }
 
 // ---- tile-binned SpMV: host-side plan and launcher
@@ -1318,7 +1330,7 @@ int check_pb(const aks_pb_matrix *A, const void *x, const void *y) {
 
 template <typename VT, typename XT>
 int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const aks_ctrl *ctrl, hipStream_t s,
-              bool init_only = false, const double *x_div = nullptr) {
+              bool init_only = false, const double *x_div = nullptr, EvPair ev = EvPair()) {
     const size_t lds1 = (size_t)PB_CW * sizeof(XT);
     const size_t lds2 = (size_t)PB_RB * sizeof(XT);
     if (init_only) {
@@ -1329,17 +1341,18 @@ int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const 
     }
     XT *prod = reinterpret_cast<XT *>(A->d_prod);       // real vectors use the first 8 nnz_pad bytes
     if (A->nnz > 0)
-        hipLaunchKernelGGL((k_pb_phase1<VT, XT>), dim3((unsigned)A->n_slabs), dim3(PB_P1_THREADS), lds1, s, A->n_cols,
-                           A->d_slab_begin, A->d_slab_end, static_cast<const VT *>(A->d_val), A->d_lcol, x, prod, ctrl, x_div);
+        launch_timed(k_pb_phase1<VT, XT>, dim3((unsigned)A->n_slabs), dim3(PB_P1_THREADS), lds1, s, ev.start, (hipEvent_t) nullptr,
+                     A->n_cols, A->d_slab_begin, A->d_slab_end, static_cast<const VT *>(A->d_val), A->d_lcol, x, prod, ctrl, x_div);
+    const hipEvent_t ev2 = A->nnz > 0 ? nullptr : ev.start;       // (phase 2 alone carries both events if phase 1 is skipped)
     const int n_chunks = (int)std::min<int64_t>(A->n_rowblocks, AKS_PB_CHUNKS);   // as the planner ordered them
     const int cpx = (n_chunks + 7) / 8;
     const uint4 *runs = reinterpret_cast<const uint4 *>(A->d_runs);
     if (accumulate)
-        hipLaunchKernelGGL((k_pb_phase2<XT, true>), dim3((unsigned)(cpx * 8)), dim3(PB_W * 64), lds2, s, A->n_rows,
-                           A->n_rowblocks, n_chunks, cpx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
+        launch_timed(k_pb_phase2<XT, true>, dim3((unsigned)(cpx * 8)), dim3(PB_W * 64), lds2, s, ev2, ev.stop, A->n_rows,
+                     A->n_rowblocks, n_chunks, cpx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
     else
-        hipLaunchKernelGGL((k_pb_phase2<XT, false>), dim3((unsigned)(cpx * 8)), dim3(PB_W * 64), lds2, s, A->n_rows,
-                           A->n_rowblocks, n_chunks, cpx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
+        launch_timed(k_pb_phase2<XT, false>, dim3((unsigned)(cpx * 8)), dim3(PB_W * 64), lds2, s, ev2, ev.stop, A->n_rows,
+                     A->n_rowblocks, n_chunks, cpx, A->d_rb_run_ptr, runs, A->d_lrow, prod, y, ctrl);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         hip_fail(e, "aks_pb_spmv");
@@ -1350,19 +1363,19 @@ int launch_pb(const aks_pb_matrix *A, const XT *x, XT *y, int accumulate, const 
 }
 
 int launch_pb_any(const aks_pb_matrix *A, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
-                  const double *x_div) {
+                  const double *x_div, EvPair ev) {
     int rc = check_pb(A, x, y);
     if (rc != AKS_OK) return rc;
     const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (real) {
         if (A->values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
-        return launch_pb<double, double>(A, static_cast<const double *>(x), static_cast<double *>(y), accumulate, ctrl, s, false, x_div);
+        return launch_pb<double, double>(A, static_cast<const double *>(x), static_cast<double *>(y), accumulate, ctrl, s, false, x_div, ev);
     }
     const c128 *xc = static_cast<const c128 *>(x);
     c128 *yc = static_cast<c128 *>(y);
-    return A->values_complex ? launch_pb<c128, c128>(A, xc, yc, accumulate, ctrl, s, false, x_div)
-                             : launch_pb<double, c128>(A, xc, yc, accumulate, ctrl, s, false, x_div);
+    return A->values_complex ? launch_pb<c128, c128>(A, xc, yc, accumulate, ctrl, s, false, x_div, ev)
+                             : launch_pb<double, c128>(A, xc, yc, accumulate, ctrl, s, false, x_div, ev);
 }
 
 int check_sell(const aks_sell_matrix *A, const void *x, const void *y) {
@@ -1376,14 +1389,70 @@ int check_sell(const aks_sell_matrix *A, const void *x, const void *y) {
 }
 
 template <typename VT, typename XT>
-int launch_sell(const aks_sell_matrix *A, const XT *x, XT *y, int accumulate, const aks_ctrl *ctrl, hipStream_t s) {
+int launch_sell(const aks_sell_matrix *A, const XT *x, XT *y, int accumulate, const aks_ctrl *ctrl, hipStream_t s,
+                EvPair ev = EvPair()) {
     const dim3 grid((unsigned)(((A->n_slices + WAVES - 1) / WAVES + 7) / 8 * 8));    // whole groups of 8: the XCD order
     const VT *val = static_cast<const VT *>(A->d_val);
     if (accumulate)
-        hipLaunchKernelGGL((k_sell<VT, XT, true>), grid, dim3(BLOCK), 0, s, A->n_rows, A->n_slices, A->d_slice_ptr, A->d_col, val, x, y, ctrl);
+        launch_timed(k_sell<VT, XT, true>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, A->n_rows, A->n_slices, A->d_slice_ptr, A->d_col, val, x, y, ctrl);
     else
-        hipLaunchKernelGGL((k_sell<VT, XT, false>), grid, dim3(BLOCK), 0, s, A->n_rows, A->n_slices, A->d_slice_ptr, A->d_col, val, x, y, ctrl);
+        launch_timed(k_sell<VT, XT, false>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, A->n_rows, A->n_slices, A->d_slice_ptr, A->d_col, val, x, y, ctrl);
     AKS_CHECK_LAUNCH("aks_sell_spmv");
+    return AKS_OK;
+}
+
+int sell_spmv_any(const aks_sell_matrix *A, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
+                  EvPair ev) {
+    int rc = check_sell(A, x, y);
+    if (rc != AKS_OK) return rc;
+    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (real) {
+        if (A->values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
+        return launch_sell<double, double>(A, static_cast<const double *>(x), static_cast<double *>(y), accumulate, ctrl, s, ev);
+    }
+    const c128 *xc = static_cast<const c128 *>(x);
+    c128 *yc = static_cast<c128 *>(y);
+    return A->values_complex ? launch_sell<c128, c128>(A, xc, yc, accumulate, ctrl, s, ev)
+                             : launch_sell<double, c128>(A, xc, yc, accumulate, ctrl, s, ev);
+}
+
+int csr_spmv_any(const aks_csr_block &B, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
+                 EvPair ev) {
+    if (B.n_rows <= 0 || B.n_tiles <= 0) return fail(AKS_ERR_ARG, "empty matrix");
+    if (!B.d_indptr || !B.d_indices || !B.d_values || !B.d_tiles || !x || !y) return fail(AKS_ERR_ARG, "null pointer");
+    if (x == y) return fail(AKS_ERR_ARG, "x and y must not alias");
+    int lpr = B.lanes_per_row;
+    if (lpr <= 0) lpr = 1;
+    if (lpr > 64 || (lpr & (lpr - 1)) != 0) return fail(AKS_ERR_ARG, "lanes_per_row must be a power of two <= 64");
+    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((B.n_tiles + WAVES - 1) / WAVES));
+    if (real) {
+        const double *v = static_cast<const double *>(B.d_values), *xr = static_cast<const double *>(x);
+        double *yr = static_cast<double *>(y);
+        if (accumulate)
+            launch_timed(k_spmv<double, double, true>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, B.n_tiles, B.d_indptr, B.d_indices, v, B.d_tiles, lpr, xr, yr, ctrl);
+        else
+            launch_timed(k_spmv<double, double, false>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, B.n_tiles, B.d_indptr, B.d_indices, v, B.d_tiles, lpr, xr, yr, ctrl);
+    } else {
+        const c128 *xc = static_cast<const c128 *>(x);
+        c128 *yc = static_cast<c128 *>(y);
+        if (B.values_complex) {
+            const c128 *v = static_cast<const c128 *>(B.d_values);
+            if (accumulate)
+                launch_timed(k_spmv<c128, c128, true>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, B.n_tiles, B.d_indptr, B.d_indices, v, B.d_tiles, lpr, xc, yc, ctrl);
+            else
+                launch_timed(k_spmv<c128, c128, false>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, B.n_tiles, B.d_indptr, B.d_indices, v, B.d_tiles, lpr, xc, yc, ctrl);
+        } else {
+            const double *v = static_cast<const double *>(B.d_values);
+            if (accumulate)
+                launch_timed(k_spmv<double, c128, true>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, B.n_tiles, B.d_indptr, B.d_indices, v, B.d_tiles, lpr, xc, yc, ctrl);
+            else
+                launch_timed(k_spmv<double, c128, false>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, B.n_tiles, B.d_indptr, B.d_indices, v, B.d_tiles, lpr, xc, yc, ctrl);
+        }
+    }
+    AKS_CHECK_LAUNCH("k_spmv");
     return AKS_OK;
 }
 
@@ -1459,65 +1528,34 @@ int64_t aks_csr_plan_tiles(const int32_t *indptr, int64_t n_rows, int32_t tile_n
 int aks_csr_spmv(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const void *d_values,
                  int32_t values_complex, const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row,
                  const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate, const void *d_ws, void *stream) {
-    if (n_rows <= 0 || n_tiles <= 0) return fail(AKS_ERR_ARG, "empty matrix");
-    if (!d_indptr || !d_indices || !d_values || !d_tiles || !d_x || !d_y) return fail(AKS_ERR_ARG, "null pointer");
-    if (d_x == d_y) return fail(AKS_ERR_ARG, "x and y must not alias");
-    int lpr = lanes_per_row;
-    if (lpr <= 0) lpr = 1;
-    if (lpr > 64 || (lpr & (lpr - 1)) != 0) return fail(AKS_ERR_ARG, "lanes_per_row must be a power of two <= 64");
-    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((n_tiles + WAVES - 1) / WAVES));
-    const c128 *x = reinterpret_cast<const c128 *>(d_x);
-    c128 *y = reinterpret_cast<c128 *>(d_y);
-    if (values_complex) {
-        const c128 *v = static_cast<const c128 *>(d_values);
-        if (accumulate)
-            hipLaunchKernelGGL((k_spmv<c128, c128, true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
-        else
-            hipLaunchKernelGGL((k_spmv<c128, c128, false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
-    } else {
-        const double *v = static_cast<const double *>(d_values);
-        if (accumulate)
-            hipLaunchKernelGGL((k_spmv<double, c128, true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
-        else
-            hipLaunchKernelGGL((k_spmv<double, c128, false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, v, d_tiles, lpr, x, y, ctrl);
-    }
-    AKS_CHECK_LAUNCH("k_spmv");
-    return AKS_OK;
+    aks_csr_block B;
+    memset(&B, 0, sizeof B);
+    B.n_rows = n_rows; B.d_indptr = d_indptr; B.d_indices = d_indices; B.d_values = d_values; B.d_tiles = d_tiles;
+    B.n_tiles = n_tiles; B.values_complex = values_complex; B.lanes_per_row = lanes_per_row;
+    return csr_spmv_any(B, d_x, d_y, accumulate, d_ws, stream, false, EvPair());
 }
 
 int aks_csr_spmv_real(int64_t n_rows, const int32_t *d_indptr, const int32_t *d_indices, const double *d_values,
                       const int32_t *d_tiles, int64_t n_tiles, int32_t lanes_per_row, const double *d_x,
                       double *d_y, int32_t accumulate, const void *d_ws, void *stream) {
-    if (n_rows <= 0 || n_tiles <= 0) return fail(AKS_ERR_ARG, "empty matrix");
-    if (!d_indptr || !d_indices || !d_values || !d_tiles || !d_x || !d_y) return fail(AKS_ERR_ARG, "null pointer");
-    if (d_x == d_y) return fail(AKS_ERR_ARG, "x and y must not alias");
-    int lpr = lanes_per_row;
-    if (lpr <= 0) lpr = 1;
-    if (lpr > 64 || (lpr & (lpr - 1)) != 0) return fail(AKS_ERR_ARG, "lanes_per_row must be a power of two <= 64");
-    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((n_tiles + WAVES - 1) / WAVES));
-    if (accumulate)
-        hipLaunchKernelGGL((k_spmv<double, double, true>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, d_values, d_tiles, lpr, d_x, d_y, ctrl);
-    else
-        hipLaunchKernelGGL((k_spmv<double, double, false>), grid, dim3(BLOCK), 0, s, n_tiles, d_indptr, d_indices, d_values, d_tiles, lpr, d_x, d_y, ctrl);
-    AKS_CHECK_LAUNCH("k_spmv (real vectors)");
-    return AKS_OK;
+    aks_csr_block B;
+    memset(&B, 0, sizeof B);
+    B.n_rows = n_rows; B.d_indptr = d_indptr; B.d_indices = d_indices; B.d_values = d_values; B.d_tiles = d_tiles;
+    B.n_tiles = n_tiles; B.values_complex = 0; B.lanes_per_row = lanes_per_row;
+    return csr_spmv_any(B, d_x, d_y, accumulate, d_ws, stream, true, EvPair());
 }
 
 // The stage entry points.  `raw0`: first basis column that may be raw (deferred normalisation); the public entry
 // points pass J -- they expect normalised columns; only aks_arnoldi_expand creates and reads raw ones.
 static int gs_project_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, const aks_c128 *d_w,
-                       void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream, int raw0) {
+                       void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream, int raw0, hipEvent_t ev0 = nullptr) {
     int rc = check_panel(n_rows, J, d_V, ldv, d_w, max_dim);
     if (rc != AKS_OK) return rc;
     Ws ws;
     rc = bind_ws(d_ws, ws_bytes, n_rows, max_dim, &ws);
     if (rc != AKS_OK) return rc;
     enqueue_projection(static_cast<hipStream_t>(stream), ws, n_rows, J, reinterpret_cast<const c128 *>(d_V), ldv,
-                       reinterpret_cast<const c128 *>(d_w), ws.red1, ws.red3, raw0);
+                       reinterpret_cast<const c128 *>(d_w), ws.red1, ws.red3, raw0, ev0);
     AKS_CHECK_LAUNCH("aks_gs_project");
     return AKS_OK;
 }
@@ -1581,8 +1619,9 @@ int aks_gs_update_norm(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t l
     return gs_update_norm_(n_rows, J, d_V, ldv, d_w, eta, d_ws, ws_bytes, max_dim, stream, J);
 }
 
-int aks_gs_finish(int64_t n_rows, int32_t J, aks_c128 *d_w, aks_c128 *d_Hcol, int64_t ldh, double tol,
-                  double eta, int32_t normalize, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+static int gs_finish_(int64_t n_rows, int32_t J, aks_c128 *d_w, aks_c128 *d_Hcol, int64_t ldh, double tol,
+                      double eta, int32_t normalize, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream,
+                      hipEvent_t ev1) {
     if (d_w == nullptr || d_Hcol == nullptr) return fail(AKS_ERR_ARG, "null pointer");
     if (J < 1 || J > max_dim) return fail(AKS_ERR_ARG, "J must satisfy 1 <= J <= max_dim");
     if (ldh < 1) return fail(AKS_ERR_ARG, "ldh must be positive");
@@ -1591,23 +1630,28 @@ int aks_gs_finish(int64_t n_rows, int32_t J, aks_c128 *d_w, aks_c128 *d_Hcol, in
     int rc = bind_ws(d_ws, ws_bytes, n_rows, max_dim, &ws);
     if (rc != AKS_OK) return rc;
     // (deferred normalisation: nothing of length n to do -- one block books H, beta and the column's scale)
-    hipLaunchKernelGGL(k_finish, dim3(normalize == 1 ? ws.lay.n_blocks : 1), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
-                       n_rows, J, reinterpret_cast<c128 *>(d_w), reinterpret_cast<c128 *>(d_Hcol), ldh, tol, eta,
-                       (int)normalize, ws.red1, ws.red2, ws.red3, ws.ctrl, ws.colscale);
+    launch_timed(k_finish, dim3(normalize == 1 ? ws.lay.n_blocks : 1), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
+                 (hipEvent_t) nullptr, ev1, n_rows, J, reinterpret_cast<c128 *>(d_w), reinterpret_cast<c128 *>(d_Hcol), ldh, tol, eta,
+                 (int)normalize, ws.red1, ws.red2, ws.red3, ws.ctrl, ws.colscale);
     AKS_CHECK_LAUNCH("k_finish");
     return AKS_OK;
 }
 
+int aks_gs_finish(int64_t n_rows, int32_t J, aks_c128 *d_w, aks_c128 *d_Hcol, int64_t ldh, double tol,
+                  double eta, int32_t normalize, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream) {
+    return gs_finish_(n_rows, J, d_w, d_Hcol, ldh, tol, eta, normalize, d_ws, ws_bytes, max_dim, stream, nullptr);
+}
+
 static int dgks_gs_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w, aks_c128 *d_Hcol,
                     int64_t ldh, double tol, double eta, int32_t normalize, void *d_ws, int64_t ws_bytes,
-                    int32_t max_dim, void *stream, int raw0) {
-    int rc = gs_project_(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream, raw0);
+                    int32_t max_dim, void *stream, int raw0, EvPair ev = EvPair()) {
+    int rc = gs_project_(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream, raw0, ev.start);
     if (rc != AKS_OK) return rc;
     rc = gs_update_project_(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream, raw0);
     if (rc != AKS_OK) return rc;
     rc = gs_update_norm_(n_rows, J, d_V, ldv, d_w, eta, d_ws, ws_bytes, max_dim, stream, raw0);
     if (rc != AKS_OK) return rc;
-    return aks_gs_finish(n_rows, J, d_w, d_Hcol, ldh, tol, eta, normalize, d_ws, ws_bytes, max_dim, stream);
+    return gs_finish_(n_rows, J, d_w, d_Hcol, ldh, tol, eta, normalize, d_ws, ws_bytes, max_dim, stream, ev.stop);
 }
 
 int aks_dgks_gs(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w, aks_c128 *d_Hcol,
@@ -1813,23 +1857,12 @@ void aks_pb_plan_destroy(void *plan) { delete static_cast<PbPlan *>(plan); }
 
 int aks_pb_spmv(const aks_pb_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate, const void *d_ws,
                 void *stream) {
-    int rc = check_pb(A, d_x, d_y);
-    if (rc != AKS_OK) return rc;
-    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const c128 *x = reinterpret_cast<const c128 *>(d_x);
-    c128 *y = reinterpret_cast<c128 *>(d_y);
-    return A->values_complex ? launch_pb<c128, c128>(A, x, y, accumulate, ctrl, s)
-                             : launch_pb<double, c128>(A, x, y, accumulate, ctrl, s);
+    return launch_pb_any(A, d_x, d_y, accumulate, d_ws, stream, false, nullptr, EvPair());
 }
 
 int aks_pb_spmv_real(const aks_pb_matrix *A, const double *d_x, double *d_y, int32_t accumulate, const void *d_ws,
                      void *stream) {
-    int rc = check_pb(A, d_x, d_y);
-    if (rc != AKS_OK) return rc;
-    if (A->values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
-    return launch_pb<double, double>(A, d_x, d_y, accumulate, static_cast<const aks_ctrl *>(d_ws),
-                                     static_cast<hipStream_t>(stream));
+    return launch_pb_any(A, d_x, d_y, accumulate, d_ws, stream, true, nullptr, EvPair());
 }
 
 int aks_workspace_set_real(void *d_ws, int32_t real_packed, void *stream) {
@@ -1889,23 +1922,12 @@ int aks_sell_plan_fill(const int32_t *indptr, const int32_t *indices, const void
 
 int aks_sell_spmv(const aks_sell_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate, const void *d_ws,
                   void *stream) {
-    int rc = check_sell(A, d_x, d_y);
-    if (rc != AKS_OK) return rc;
-    const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const c128 *x = reinterpret_cast<const c128 *>(d_x);
-    c128 *y = reinterpret_cast<c128 *>(d_y);
-    return A->values_complex ? launch_sell<c128, c128>(A, x, y, accumulate, ctrl, s)
-                             : launch_sell<double, c128>(A, x, y, accumulate, ctrl, s);
+    return sell_spmv_any(A, d_x, d_y, accumulate, d_ws, stream, false, EvPair());
 }
 
 int aks_sell_spmv_real(const aks_sell_matrix *A, const double *d_x, double *d_y, int32_t accumulate, const void *d_ws,
                        void *stream) {
-    int rc = check_sell(A, d_x, d_y);
-    if (rc != AKS_OK) return rc;
-    if (A->values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
-    return launch_sell<double, double>(A, d_x, d_y, accumulate, static_cast<const aks_ctrl *>(d_ws),
-                                       static_cast<hipStream_t>(stream));
+    return sell_spmv_any(A, d_x, d_y, accumulate, d_ws, stream, true, EvPair());
 }
 
 // ---- communicator: RCCL + a side stream for the ghost exchange ------------------------------
@@ -1974,7 +1996,9 @@ static int shard_apply(const aks_shard *A, const void *d_x, void *d_y, const voi
     hipStream_t s = static_cast<hipStream_t>(stream);
     Comm *c = static_cast<Comm *>(A->comm);
     const bool exchange = c != nullptr && A->any_exchange != 0;
-    if (!exchange) return apply_block(A->diag, d_x, d_y, 0, d_ws, stream, real, x_div);
+    if (!exchange)       // one block: the probe's event pair rides on its kernel launch(es)
+        return apply_block(A->diag, d_x, d_y, 0, d_ws, stream, real, x_div, pr ? pr->reserve(AKS_PROBE_SPMV) : EvPair());
+    hipEvent_t whole = pr ? pr->begin(AKS_PROBE_SPMV, s) : nullptr;     // sharded: pack .. off-diagonal block
     if (A->send_counts == nullptr || A->recv_counts == nullptr) return fail(AKS_ERR_ARG, "null exchange counts");
     if ((A->n_send > 0 && (!A->d_send_idx || !A->d_sendbuf)) || (A->n_ghost > 0 && !A->d_ghostbuf))
         return fail(AKS_ERR_ARG, "null exchange buffer");
@@ -2037,6 +2061,7 @@ static int shard_apply(const aks_shard *A, const void *d_x, void *d_y, const voi
     if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
     if (A->off.n_rows > 0) rc = apply_block(A->off, A->d_ghostbuf, d_y, 1, d_ws, stream, real);
     if (done) (void)hipEventRecord(done, s);
+    if (whole) (void)hipEventRecord(whole, s);
     return rc;
 }
 
@@ -2062,7 +2087,6 @@ int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 
     const int64_t n_panel = real ? (n_rows + 1) / 2 : n_rows;
     if (ldv < n_panel) return fail(AKS_ERR_ARG, "ldv too small");
     Probe *pr = static_cast<Probe *>(probe);
-    hipStream_t s = static_cast<hipStream_t>(stream);
     Comm *c = static_cast<Comm *>(A->comm);
     Ws ws;
     int rc = bind_ws(d_ws, ws_bytes, n_panel, max_dim, &ws);
@@ -2077,27 +2101,24 @@ int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 
         aks_c128 *x = d_V + (int64_t)j * ldv;
         aks_c128 *w = d_V + (int64_t)J * ldv;
         const int raw0 = defer ? start_dim : J;         // columns < start_dim are normalised (precondition)
-        hipEvent_t done = nullptr;
         if (!(first_w_ready && j == start_dim)) {
-            done = pr ? pr->begin(AKS_PROBE_SPMV, s) : nullptr;
-            rc = shard_apply(A, x, w, d_ws, stream, flags, pr, defer ? ws.colscale + j : nullptr);
-            if (done) (void)hipEventRecord(done, s);
+            rc = shard_apply(A, x, w, d_ws, stream, flags, pr, defer ? ws.colscale + j : nullptr);   // (books AKS_PROBE_SPMV)
             if (rc != AKS_OK) return rc;
         }
-        done = pr ? pr->begin(AKS_PROBE_ORTHO, s) : nullptr;
+        // (the probe's pair for the orthogonalisation rides on its first and its last kernel)
+        const EvPair eo = pr ? pr->reserve(AKS_PROBE_ORTHO) : EvPair();
         if (c == nullptr) {
-            rc = dgks_gs_(n_panel, J, d_V, ldv, w, d_H + j, ldh, tol, eta, norm_mode, d_ws, ws_bytes, max_dim, stream, raw0);
+            rc = dgks_gs_(n_panel, J, d_V, ldv, w, d_H + j, ldh, tol, eta, norm_mode, d_ws, ws_bytes, max_dim, stream, raw0, eo);
         } else {
             // the stage kernels with the reductions summed over the ranks in between
-            rc = gs_project_(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream, raw0);
+            rc = gs_project_(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream, raw0, eo.start);
             if (rc == AKS_OK) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red1), 2 * (J + 1), stream);
             if (rc == AKS_OK) rc = gs_update_project_(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream, raw0);
             if (rc == AKS_OK) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red2), 2 * (J + 1), stream);
             if (rc == AKS_OK) rc = gs_update_norm_(n_panel, J, d_V, ldv, w, eta, d_ws, ws_bytes, max_dim, stream, raw0);
             if (rc == AKS_OK && !lazy_third) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red3), 2, stream);
-            if (rc == AKS_OK) rc = aks_gs_finish(n_panel, J, w, d_H + j, ldh, tol, eta, norm_mode, d_ws, ws_bytes, max_dim, stream);
+            if (rc == AKS_OK) rc = gs_finish_(n_panel, J, w, d_H + j, ldh, tol, eta, norm_mode, d_ws, ws_bytes, max_dim, stream, eo.stop);
         }
-        if (done) (void)hipEventRecord(done, s);
         if (rc != AKS_OK) return rc;
     }
     return AKS_OK;

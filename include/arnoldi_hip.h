@@ -415,9 +415,12 @@ int aks_scale(int64_t n_rows, aks_c128 *d_w, double alpha_re, double alpha_im, v
 
 /* ---- device-time probes (measurement only; bench.py's roofline figures) --------
  * A probe owns `capacity` hipEvent pairs.  When one is handed to
- * aks_arnoldi_expand, every SpMV launch is bracketed by a pair with tag
- * AKS_PROBE_SPMV and every orthogonalisation (project .. finish) by a pair with
- * tag AKS_PROBE_ORTHO, recorded on the launch stream.  aks_probe_read waits for
+ * aks_arnoldi_expand, every SpMV gets a pair with tag AKS_PROBE_SPMV and every
+ * orthogonalisation (project .. finish) a pair with tag AKS_PROBE_ORTHO.  The
+ * events ride on the kernel launches themselves (hipExtLaunchKernelGGL: start =
+ * begin of the first kernel of the group, stop = end of its last kernel), so
+ * no marker packets sit between the kernels of the timed region; only a
+ * sharded SpMV with a ghost exchange is bracketed by recorded events.  aks_probe_read waits for
  * the last recorded event and returns the number of pairs with `tag` and the
  * sum of their elapsed times in milliseconds. */
 #define AKS_PROBE_SPMV 0
