@@ -275,8 +275,10 @@ class ArnoldiContext:
         Krylov-Schur drivers): the new columns may then stay RAW -- the device keeps their norms as scales and every
         kernel that reads them divides on the fly, instead of a 32 n byte normalisation pass per step
         (AKS_EXPAND_DEFER_SCALE; honoured by the C-driven path when the diagonal block is in the binned form).
-        H and all results are bit for bit the same; until the truncation the columns ``> start`` must not be
-        read by anything else (``local_columns`` / ``gather_columns`` refuse)."""
+        H is bit for bit the same (the on-the-fly division is the one the normalisation pass performs); the
+        truncation that follows multiplies raw columns by coefficients scaled on the host (``_fold_scales``), a
+        rounding-level difference.  Until then the columns ``> start`` must not be read by anything else
+        (``local_columns`` / ``gather_columns`` refuse)."""
         b, ws, op = self.basis, self.ws, self.op
         # The reference's arnoldi_decomposition keeps no state between calls: a breakdown in the
         # last step of one expansion (n_iter == max_dim, accepted by the driver) must not turn the
