@@ -50,3 +50,23 @@ def test_bench_refuses_a_half_launched_world():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--gpus", "2", "--rows", "5000"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr
+
+
+def test_bench_takes_a_matrix_file(tmp_path):
+    """``bench.py --matrix FILE``: a supplied file (SuiteSparse .mat / MatrixMarket / .npz through
+    arnoldi_amd.harness.load_matrix) becomes the workload -- how af_shell10 (BASELINE config 3; not obtainable
+    offline) would be measured."""
+    import scipy.io
+    import scipy.sparse as sp
+
+    sys.path.insert(0, os.path.join(ROOT, "arnoldi-py_amd"))
+    from arnoldi_amd import matrices
+
+    A = sp.csr_matrix(matrices.banded_csr(3000, 9, 7))
+    path = os.path.join(tmp_path, "band3000.mtx")
+    scipy.io.mmwrite(path, A)
+    res = _run(["--matrix", path, "--nev", "4", "--max-dim", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["config"]["n"] == 3000 and out["config"]["nnz_rank0"] == A.nnz
+    assert "band3000.mtx" in out["config"]["workload"] and out["config"]["nev"] == 4 and out["config"]["max_dim"] == 12
