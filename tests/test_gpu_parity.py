@@ -951,6 +951,36 @@ def test_stress_grid_against_oracle(amd, nev, ncv, p, which):
     np.testing.assert_allclose(Q.conj().T @ Q, np.eye(nev), atol=1e-11)
 
 
+@pytest.mark.parametrize("which", ["LM", "LR"])
+@pytest.mark.parametrize("nev,ncv,p", [(3, 20, 10), (10, 20, 16), (20, 40, 30), (50, 80, 65), (75, 100, 85)])
+def test_stress_grid_with_deferred_normalisation(amd, monkeypatch, nev, ncv, p, which):
+    """The same grid with the operator forced into the binned form, so that every expansion defers its normalisations
+    (raw columns, scales folded into the restart coefficients, the start column of every re-expansion raw; panels up to
+    J = 100 through the grouped projection and the column-split / un-fused update kernels): the reference's restart
+    counts and History, eigenvalues, residual bound -- hundreds of restarts each on the Laplacian."""
+    from arnoldi_amd import matrices
+
+    monkeypatch.setenv("AKS_SPMV_FORM", "binned")
+    if which == "LM":
+        A, sort_o, tol = matrices.laplace2d(30, 31), oracle.arg_largest_magnitude, None
+    else:
+        A, sort_o, tol = matrices.mark(44), oracle.arg_largest_real, 1e-8
+    kw = dict(max_dim=ncv, p=p, stopping_criterion=tol, max_restarts=4000)
+    np.random.seed(nev + ncv)
+    Qo, To, ho = oracle.krylov_schur(A, nev, sort_function=sort_o, **kw)
+    np.random.seed(nev + ncv)
+    st = {}
+    Q, T, h = amd.partial_schur(A, nev, sort_function=sort_o, stats=st, **kw)
+    assert st["spmv_form"] == "binned" and st["deferred_normalisations"] == st["restarts"]
+    np.testing.assert_array_equal(h.restarts, ho.restarts)
+    np.testing.assert_array_equal(h.matvecs, ho.matvecs)
+    np.testing.assert_allclose(np.diag(T), np.diag(To), rtol=1e-7, atol=1e-10)
+    _, _, rel = oracle.eig_residuals(A, Q, T)
+    _, _, rel_o = oracle.eig_residuals(A, Qo, To)
+    assert rel.max() <= max(1.05 * rel_o.max(), 1e-12), (rel.max(), rel_o.max())
+    np.testing.assert_allclose(Q.conj().T @ Q, np.eye(nev), atol=1e-11)
+
+
 def test_stress_grid_case_under_graph_capture(amd, monkeypatch):
     """Regression for round 1's abort (gpurun_out/t8.log): the stress-grid case (LM, (3, 20, 10)) -- hundreds of
     restarts on the 30 x 31 Laplacian, every step with a second Gram-Schmidt pass -- with the re-expansion
