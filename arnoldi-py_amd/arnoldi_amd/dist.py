@@ -105,11 +105,16 @@ atexit.register(_close_all)
 def comm_for(group=None):
     """The Comm of a process group (the default group if None), created once per group: every
     ``partial_schur`` without an explicit ``comm`` used to build a new one -- and with it a new RCCL
-    communicator (bootstrap, device buffers) that nothing destroyed."""
-    key = group if group is not None else "default"
-    c = _default_comms.get(key)
-    if c is None or (dist.is_initialized() and c.size != dist.get_world_size(group)):
-        c = _default_comms[key] = Comm(group)
+    communicator (bootstrap, device buffers) that nothing destroyed.  A group that has been destroyed and
+    initialised again is a different group: its Comm is made afresh (and the old one closed)."""
+    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+    entry = _default_comms.get("default" if group is None else id(group))
+    if entry is not None and entry[0] is pg:
+        return entry[1]
+    if entry is not None:
+        entry[1].close()
+    c = Comm(group)
+    _default_comms["default" if group is None else id(group)] = (pg, c)
     return c
 
 
