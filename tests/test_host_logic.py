@@ -432,6 +432,29 @@ def check_dist_verdicts(verdicts, native=False):
     assert all(v == verdicts[0] or v["mark50"]["restarts"] == verdicts[0]["mark50"]["restarts"] for v in verdicts)
 
 
+def test_one_comm_per_process_group():
+    """dist.comm_for: repeated solves on one process group share one Comm (hence one RCCL communicator); a group that
+    was destroyed and initialised again gets a new one (a new communicator per solve, never destroyed)."""
+    import torch.distributed as dist
+    from arnoldi_amd.dist import comm_for
+
+    def init():
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+
+    init()
+    try:
+        a = comm_for()
+        assert comm_for() is a and a.size == 1 and a.native() is None       # gloo: no RCCL handle, chained path
+    finally:
+        dist.destroy_process_group()
+    init()
+    try:
+        b = comm_for()
+        assert b is not a and comm_for() is b
+    finally:
+        dist.destroy_process_group()
+
+
 def test_row_sharded_solve_four_ranks_gloo(tmp_path):
     """world_size = 4: interior ranks exchange with two neighbours, empty messages to the others."""
     check_dist_verdicts(run_dist_worker(tmp_path, 4, "gloo", "cpu"))
