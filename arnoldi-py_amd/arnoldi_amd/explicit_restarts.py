@@ -16,7 +16,7 @@ import numpy as np
 from .decomposition import RitzDecomposition
 from .engine import ArnoldiContext, as_operator, default_comm
 from .history import History  # noqa: F401  (re-exported: ``from arnoldi.explicit_restarts import History``)
-from .utils import arg_largest_magnitude, rand_normalized_vector
+from .utils import arg_largest_magnitude, host_blas_threads, rand_normalized_vector
 
 WORK_DTYPE = np.complex128
 
@@ -53,6 +53,7 @@ def _column_block(ctx, j):
     return blk
 
 
+@host_blas_threads()       # host LAPACK on m x m matrices between device waits: one BLAS thread (utils.py)
 def naive_explicit_restarts(A, m=None, *, stopping_criterion=None, max_restarts=10, comm=None, device=None):
     """One eigenpair by m-step Arnoldi restarted from the dominant Ritz vector
     (explicit_restarts.py:31-61).  Returns ``(ritz, has_converged, restarts_used)``.
@@ -90,6 +91,7 @@ def naive_explicit_restarts(A, m=None, *, stopping_criterion=None, max_restarts=
     return ritz, False, max_restarts
 
 
+@host_blas_threads()
 def explicit_restarts_with_deflation(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts=100,
                                      sort_function=None, comm=None, device=None, gather=True, stats=None,
                                      arithmetic="complex"):

@@ -13,7 +13,7 @@ import scipy.linalg
 
 from .engine import ArnoldiContext, as_operator, default_comm
 from .history import History
-from .utils import arg_largest_magnitude, rand_normalized_vector, reorder_schur
+from .utils import arg_largest_magnitude, host_blas_threads, rand_normalized_vector, reorder_schur
 
 WORK_DTYPE = np.complex128  # krylov_schur.py:38: complex128 whatever A.dtype is
 
@@ -197,17 +197,18 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
         solver = KrylovSchurSolver(A, nev, max_dim, p, tol, sort_function, v0=v0, comm=comm, device=device)
 
     converged = False
-    solver.start()
-    for restart in range(max_restarts):
-        if solver.m != max_dim:
-            if on_breakdown != "deflate":
-                raise ValueError("Happy breakdown not supported yet")   # krylov_schur.py:57-59
-            converged = solver.contract_invariant(restart)
-            break
-        converged = solver.contract(restart)
-        if converged:
-            break
-        solver.expand()
+    with host_blas_threads():          # the m x m host LAPACK between two device waits: one BLAS thread (utils.py)
+        solver.start()
+        for restart in range(max_restarts):
+            if solver.m != max_dim:
+                if on_breakdown != "deflate":
+                    raise ValueError("Happy breakdown not supported yet")   # krylov_schur.py:57-59
+                converged = solver.contract_invariant(restart)
+                break
+            converged = solver.contract(restart)
+            if converged:
+                break
+            solver.expand()
 
     if stats is not None:
         ctx = solver.ctx

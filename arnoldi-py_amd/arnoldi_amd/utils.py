@@ -7,6 +7,9 @@ Interface mirror of src/arnoldi/utils.py: ``rand_normalized_vector`` (:7-13),
 """
 from __future__ import annotations
 
+import contextlib
+import os
+
 import numpy as np
 import scipy.linalg
 from scipy.linalg import lapack
@@ -18,6 +21,30 @@ __all__ = [
     "ordered_schur",
     "reorder_schur",
 ]
+
+
+@contextlib.contextmanager
+def host_blas_threads():
+    """The host side of a restart is LAPACK on an ``m x m`` matrix (m <= 128: Schur form, reordering, a few
+    products) between two waits for the device.  A threaded BLAS makes that *slower*, and not by a little: its
+    pool (one thread per visible CPU -- 256 on the 8-GPU hosts) is woken for a few microseconds of work and then
+    spins, which on a box with a CPU quota stalls the thread that waits for the GPU.  Measured on MI355X hosts
+    (profiles/r03_host_gap.txt, random CSR n = 1.25M, same build, process after process): 4.1 - 4.6 ms per restart
+    with the default pools, 2.39 ms with one thread -- the whole difference sits in the wait for H or in the
+    Schur call.  The solvers therefore run their loop inside this context: BLAS pools limited to ONE thread
+    (threadpoolctl, restored on exit).  ``AKS_HOST_BLAS_THREADS=keep`` leaves the pools alone, an integer sets
+    another limit.  Without threadpoolctl nothing is changed."""
+    want = os.environ.get("AKS_HOST_BLAS_THREADS", "1")
+    if want == "keep":
+        yield
+        return
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        yield
+        return
+    with threadpool_limits(limits=int(want), user_api="blas"):
+        yield
 
 
 def rand_normalized_vector(n, dtype=np.float64):

@@ -292,6 +292,15 @@ def cpu_baseline(args):
 
 # ------------------------------------------------------------------------------------------- one measurement
 def measure(args, comm, world, rank):
+    """The restarts run as ``partial_schur`` runs them: host BLAS limited to one thread for the m x m Schur step
+    (arnoldi_amd.utils.host_blas_threads; the CPU baseline is a process of its own and keeps its threads)."""
+    from arnoldi_amd.utils import host_blas_threads
+
+    with host_blas_threads():
+        return _measure(args, comm, world, rank)
+
+
+def _measure(args, comm, world, rank):
     """Build the operator for args.workload, run warmup + steps restarts, return (dict, context for extras)."""
     import torch
     from arnoldi_amd import _hip

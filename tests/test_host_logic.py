@@ -257,6 +257,36 @@ def test_driver_control_flow_against_golden(fake):
            max_restarts=1000)
 
 
+def test_host_blas_runs_single_threaded_inside_a_solve(fake, monkeypatch):
+    """utils.host_blas_threads: the m x m LAPACK step of a restart runs with the BLAS pools limited to one thread
+    (a pool of one thread per visible CPU, woken for a 20 x 20 Schur form, doubled the time of a restart at the
+    8-GPU shard sizes on some runs: profiles/r03_host_gap.txt), the pools are restored afterwards, and
+    AKS_HOST_BLAS_THREADS=keep leaves them alone."""
+    threadpoolctl = pytest.importorskip("threadpoolctl")
+    import arnoldi_amd
+    from arnoldi_amd.krylov_schur import KrylovSchurSolver
+
+    def blas_threads():
+        return [m["num_threads"] for m in threadpoolctl.threadpool_info() if m["user_api"] == "blas"]
+
+    before = blas_threads()
+    if not before or max(before) == 1:
+        pytest.skip("the BLAS of this interpreter has one thread anyway")
+    seen = []
+    contract = KrylovSchurSolver.contract
+    monkeypatch.setattr(KrylovSchurSolver, "contract", lambda self, r: (seen.append(blas_threads()), contract(self, r))[1])
+    A = csr_from(load_golden("g1_matrices"), "mark50")
+    for mode, expect in ((None, [1] * len(before)), ("keep", before), ("2", [min(2, b) for b in before])):
+        monkeypatch.delenv("AKS_HOST_BLAS_THREADS", raising=False)
+        if mode is not None:
+            monkeypatch.setenv("AKS_HOST_BLAS_THREADS", mode)
+        del seen[:]
+        np.random.seed(0)
+        arnoldi_amd.partial_schur(A, 5, max_dim=20, stopping_criterion=1e-8, sort_function=oracle.arg_largest_real)
+        assert seen and all(s == expect for s in seen), (mode, seen[:2], expect)
+        assert blas_threads() == before
+
+
 def test_driver_errors_and_defaults(fake):
     import arnoldi_amd
     from arnoldi_amd.matrices import random_csr
