@@ -7,6 +7,8 @@
                     ghost plan, all-to-all, all-reduces, stage chaining) -- runs anywhere.
 ``--device cuda`` : the real HIP kernels; every rank uses GPU 0 and ``gloo`` carries the collectives
                     through host memory (how two ranks are rehearsed on the one-GPU box).
+``--backend nccl --device cuda`` : RCCL itself, rank r on GPU r (needs as many GPUs as ranks): the C-driven path
+                    as bench.py --gpus N runs it.
 Each case solves the same problem as a single-process CPU oracle run and writes its verdict.
 """
 import argparse
@@ -39,13 +41,18 @@ def main():
         os.environ["AKS_COMM_OVER_GLOO"] = "1"
         os.environ["AKS_GRAPH"] = "0"          # the stand-in synchronises streams: nothing to capture
 
-    dist.init_process_group(args.backend)
+    if args.backend == "nccl":     # RCCL proper: one GPU per rank (a box with >= world_size GPUs)
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(args.backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     if args.device == "cpu":
         import fake_hip
 
         fake_hip.install()
-    else:
+    elif args.backend != "nccl":
         torch.cuda.set_device(0)
 
     import oracle

@@ -829,6 +829,23 @@ def test_row_sharded_c_driven_path_ranks_share_the_gpu(amd, tmp_path, ranks):
             del os.environ["AKS_SPMV_FORM"]
 
 
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_row_sharded_c_driven_path_over_rccl(amd, tmp_path, ranks):
+    """The same cases through RCCL ITSELF, rank r on GPU r: only runs on a box that has the GPUs (the one-GPU boxes of
+    the development pool skip it; ADVICE r02 asked for it so that the first multi-GPU machine that runs the suite
+    records the evidence).  History equal to the oracle's on every case, including the Laplacian whose first expansion
+    is redone with the third all-reduce on all ranks."""
+    import torch
+
+    from test_host_logic import check_dist_verdicts, run_dist_worker
+
+    if torch.cuda.device_count() < ranks:
+        pytest.skip(f"needs {ranks} GPUs (RCCL does not put two ranks on one device)")
+    verdicts = run_dist_worker(tmp_path, ranks, "nccl", "cuda", timeout=900)
+    assert all(v["laplace2d"]["lazy_redos"] == 1 for v in verdicts)
+    check_dist_verdicts(verdicts, native=True)
+
+
 def test_bench_multi_rank_line_on_the_c_driven_path(amd):
     """``bench.py --gpus 2`` as the driver starts it, rehearsed on ONE GPU: two ranks share it, the library's own
     communicator (C-driven ghost exchange + stage all-reduces) runs over tests/mock_rccl, gloo carries the set-up.
