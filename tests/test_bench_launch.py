@@ -37,6 +37,28 @@ def test_bench_starts_its_own_ranks():
     assert out["data"].startswith("rehearsal")              # a CPU stand-in never reports as a measurement
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's own launch for N > 1: ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher's environment): one line, from rank 0."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--gpus", "2", "--rows", "20000", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "row-sharded x2" and out["value"] > 0
+
+
 def test_bench_reports_a_failed_rank():
     # nev > max_dim - 1: every rank trips the reference's assertion; the launcher must come back non-zero
     res = _run(["--gpus", "2", "--rows", "5000", "--steps", "1", "--warmup", "0", "--nev", "5", "--max-dim", "4",
