@@ -153,6 +153,33 @@ def main(out_path):
                                                     and np.array_equal(graph["0"][2], graph["1"][2])),
                               "graphs_eager": graph["0"][3], "graphs_replayed": graph["1"][3],
                               "native_comm": graph["1"][4]}
+    # the other solvers on the same communicator (their collectives go through RCCL as well: the C-driven expansion
+    # plus torch 'nccl' all-reduces for residual norms, Ritz combinations and the deflation's Gram-Schmidt)
+    from arnoldi_amd.explicit_restarts import explicit_restarts_with_deflation
+
+    others = {}
+    M = matrices.mark(30)
+    kw30 = dict(max_dim=30, stopping_criterion=1e-8, sort_function=oracle.arg_largest_real)
+    for arith in ("complex", "real"):
+        np.random.seed(1)
+        vals, vecs, h5 = explicit_restarts_with_deflation(M, 4, comm=comm, arithmetic=arith, **kw30)
+        np.random.seed(1)
+        vo, xo, ho = oracle.explicit_restarts_with_deflation(M, 4, **kw30)
+        res5 = np.linalg.norm(M @ vecs - vecs * vals, axis=0)
+        others["deflation_" + arith] = {
+            "eig_err": float(np.abs(np.sort_complex(np.asarray(vals, complex)) - np.sort_complex(vo)).max()),
+            "res": float(res5.max()), "res_oracle": float(np.linalg.norm(M @ xo - vo * xo, axis=0).max()),
+            "hist_equal": bool(np.array_equal(h5.restarts, ho.restarts))}
+    for name, extra in (("real", dict(arithmetic="real")), ("locking", dict(locking=True)),
+                        ("real_locking", dict(arithmetic="real", locking=True))):
+        np.random.seed(0)
+        st6 = {}
+        Q6, T6, h6 = partial_schur(A, 5, sort_function=oracle.arg_largest_real, comm=comm, stats=st6, **kw, **extra)
+        _, _, rel6 = oracle.eig_residuals(A, Q6, T6)
+        ev6 = np.sort_complex(np.linalg.eigvals(T6))
+        others[name] = {"eig_err": float(np.abs(ev6 - np.sort_complex(np.diag(To).astype(complex))).max()),
+                        "rel": float(rel6.max()), "native_comm": bool(st6["solver"].op.native_comm)}
+    res["other_solvers"] = others
     # the library's own all-reduce entry point on a float64 view inside a byte buffer
     view.copy_(torch.arange(42, dtype=torch.float64, device="cuda"))
     _hip.check(_hip.load().aks_comm_allreduce_sum(comm.native(), dev._ptr(view), 42, dev._stream()), "allreduce")

@@ -908,6 +908,14 @@ def test_rccl_collectives_one_rank(amd, tmp_path):
     # re-expansions are replayed, bit for bit the eager one
     gc_ = r["graph_with_comm"]
     assert gc_["bit_identical"] and gc_["native_comm"] and gc_["graphs_eager"] == 0 and gc_["graphs_replayed"] >= 1, gc_
+    # the other solvers with their collectives on RCCL: explicit restarts with deflation (complex and real), real
+    # arithmetic, locking, both
+    o = r["other_solvers"]
+    assert o["deflation_complex"]["hist_equal"] and o["deflation_complex"]["eig_err"] < 1e-9
+    for k in ("deflation_complex", "deflation_real"):
+        assert o[k]["eig_err"] < 1e-7 and o[k]["res"] <= max(2 * o[k]["res_oracle"], 1e-7), (k, o[k])
+    for k in ("real", "locking", "real_locking"):
+        assert o[k]["native_comm"] and o[k]["eig_err"] < 1e-7 and o[k]["rel"] < 1e-7, (k, o[k])
 
 
 def test_graph_replay_gives_identical_results(amd, monkeypatch):
