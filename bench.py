@@ -500,6 +500,41 @@ def pmc_traffic(res, args, world=1):
         return None, f"pmc summary unreadable: {e}"
 
 
+GS_FAMILIES = ("k_proj", "k_update_proj", "k_update_proj_split", "k_update", "k_reduce", "k_finish")
+
+
+def pmc_ortho_traffic(res, args, world=1):
+    """HBM bytes of one Gram-Schmidt step (this run's mix of panel widths) from the same committed counter passes as
+    ``pmc_traffic``.  The profiled command runs the initial expansion (J = 1..m) and a few re-expansions (J = p+1..m);
+    the counters are summed per kernel family over ALL of them, so what the file gives is the ratio of counted to
+    algorithmic bytes over that sequence; the ratio is applied to this run's algorithmic bytes per step.  Returns
+    (bytes, ratio, note)."""
+    if pmc_traffic(res, args, world)[0] is None or not res["ortho"]:
+        return None, None, None
+    name = "pmc_summary.json" if args.workload == "random" else f"pmc_summary_{args.workload}.json"
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        m, p, n_panel, fs = res["m"], res["p"], res["n_panel"], res["frac_second"]
+        steps = pmc["k_finish"]["launches"]
+        if steps < m or (steps - m) % (m - p):
+            return None, None, f"profiles/{name}: {steps} steps are not an initial expansion plus whole re-expansions"
+        re_exp = (steps - m) // (m - p)
+
+        def alg(J):
+            return fs * ortho_algorithmic_bytes(n_panel, J, True) + (1 - fs) * ortho_algorithmic_bytes(n_panel, J, False)
+
+        expected = sum(alg(J) for J in range(1, m + 1)) + re_exp * sum(alg(J) for J in range(p + 1, m + 1))
+        counted = sum(pmc[f]["launches"] * pmc[f]["hbm_bytes_per_launch_fetch_x2"] for f in GS_FAMILIES if f in pmc)
+        ratio = counted / expected
+        per_step = res["per_cycle"] / max(m - p, 1)
+        return int(ratio * per_step), round(ratio, 4), (
+            f"rocprofv3 --pmc, same build: {counted / 1e9:.2f} GB counted over the {steps} Gram-Schmidt steps of the "
+            f"profiled command against {expected / 1e9:.2f} GB algorithmic (ratio {ratio:.3f}), applied to this run's "
+            f"algorithmic bytes per step")
+    except Exception as e:  # noqa: BLE001
+        return None, None, f"pmc summary unreadable: {e}"
+
+
 def leg_summary(res, args):
     """What an extra leg (child process) reports back."""
     traffic, note = pmc_traffic(res, args)
@@ -511,6 +546,9 @@ def leg_summary(res, args):
            "ortho_achieved_GBs": res["ortho"]["achieved"] if res["ortho"] else None,
            "ortho_frac": res["ortho"]["frac"] if res["ortho"] else None,
            "second_pass_fraction": round(res["frac_second"], 3), "setup_s": round(res["setup_s"], 2)}
+    o_traffic, o_ratio, _ = pmc_ortho_traffic(res, args)
+    if o_traffic is not None:
+        out["ortho_traffic_bytes_per_step"], out["ortho_traffic_over_algorithmic"] = o_traffic, o_ratio
     if res["graph_rate"] is not None:
         # Shards of <= 4M rows: the product's default (AKS_GRAPH=auto) replays the re-expansion as a hipGraph, one
         # launch per restart; that is the leg's rate.  The probed pass above has to launch kernel by kernel (a HIP
@@ -763,6 +801,10 @@ def run_rank(args, argv):
             },
             "roofline_ortho": res["ortho"],
         }
+        if res["ortho"]:
+            o_traffic, o_ratio, o_note = pmc_ortho_traffic(res, args, world)
+            res["ortho"].update(traffic=o_traffic, traffic_over_algorithmic=o_ratio, traffic_source=o_note,
+                                algorithmic_bytes_per_step=int(res["per_cycle"] / max(m - p, 1)))
         n_loc, per_cycle, elapsed = res["n_panel"], res["per_cycle"], res["elapsed"]
         rr = {"algorithmic_GB_per_restart": round(((m - p) * spmv_bytes + per_cycle + 16 * n_loc * (m + p) + 32 * n_loc) / 1e9, 2),
               "second_pass_fraction": round(res["frac_second"], 3)}
