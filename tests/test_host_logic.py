@@ -287,6 +287,32 @@ def test_host_blas_runs_single_threaded_inside_a_solve(fake, monkeypatch):
         assert blas_threads() == before
 
 
+def test_operator_formats_and_value_types(fake):
+    """What the reference accepts as ``A`` (operator protocol): CSR / CSC / COO / dense, float32 /
+    float64 / complex64 values.  The default tolerance follows ``A.dtype`` (krylov_schur.py:16-17: float32 =>
+    3.45e-4), the work arrays are complex128 whatever the input; an integer matrix fails as in the reference."""
+    import arnoldi_amd
+    import scipy.sparse as sp
+    from arnoldi_amd import matrices
+
+    base = matrices.mark(30)
+    shifted = (base + 0.1j * sp.diags_array(np.linspace(0, 1, base.shape[0]))).tocsr()
+    LR = oracle.arg_largest_real
+    for name, A in (("float32", base.astype(np.float32)), ("complex64", shifted.astype(np.complex64)),
+                    ("csc", base.tocsc()), ("coo", base.tocoo()), ("dense float32", base.toarray().astype(np.float32))):
+        np.random.seed(0)
+        st = {}
+        Q, T, h = arnoldi_amd.partial_schur(A, 4, max_dim=12, sort_function=LR, stats=st, max_restarts=300)
+        np.random.seed(0)
+        Qo, To, ho = oracle.krylov_schur(A, 4, max_dim=12, sort_function=LR, max_restarts=300)
+        assert st["tol"] == np.sqrt(np.finfo(A.dtype).eps), name
+        np.testing.assert_array_equal(h.restarts, ho.restarts, err_msg=name)
+        np.testing.assert_allclose(np.diag(T), np.diag(To), rtol=1e-9, atol=1e-12, err_msg=name)
+        assert Q.dtype == np.complex128 and T.dtype == np.complex128
+    with pytest.raises(ValueError, match="not inexact"):
+        arnoldi_amd.partial_schur(base.astype(np.int64), 4, max_dim=12)
+
+
 def test_driver_errors_and_defaults(fake):
     import arnoldi_amd
     from arnoldi_amd.matrices import random_csr
