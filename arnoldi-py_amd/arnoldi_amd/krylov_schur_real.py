@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import numpy as np
 import scipy.linalg
-from scipy.linalg.lapack import dtrexc
+from scipy.linalg.lapack import dtrexc, strexc
 
 from .engine import ArnoldiContext, as_operator
 from .history import History
@@ -65,13 +65,14 @@ def reorder_real_schur(T, Z, sort_function):
     current = list(range(len(blocks)))
     T = np.asfortranarray(T)
     Z = np.asfortranarray(Z)
+    swap = strexc if T.dtype == np.float32 else dtrexc
     for target, bid in enumerate(wanted):
         src = current.index(bid)
         if src == target:
             continue
         ifst = 1 + sum(sizes[b] for b in current[:src])
         ilst = 1 + sum(sizes[b] for b in current[:target])
-        T, Z, info = dtrexc(T, Z, ifst, ilst)
+        T, Z, info = swap(T, Z, ifst, ilst)
         if info < 0:
             raise np.linalg.LinAlgError(f"dtrexc: illegal argument {-info}")
         # info == 1: two blocks too close to swap (T is still a valid Schur form, partially reordered)

@@ -95,11 +95,22 @@ def ordered_schur(a, output="real", *, sort_function=None):
     """Schur decomposition ``a = Z T Z^H`` whose eigenvalues appear on ``diag(T)`` in the
     order given by ``sort_function`` (default: largest magnitude first).
 
-    Only ``output="complex"`` is implemented, like the reference (utils.py:64-65).
+    ``output="complex"`` is the reference's (utils.py:32-67).  ``output="real"`` -- "not implemented yet" there
+    (utils.py:64-65; its test is an xfail, tests/test_utils.py:51-87) -- gives the REAL Schur form of a real matrix:
+    orthogonal ``Z``, quasi-triangular ``T`` with 1x1 and 2x2 diagonal blocks in the order of ``sort_function``
+    (a conjugate pair takes the better rank of its two members and moves as one block; ``?trexc``), the form the
+    real-arithmetic solver works with (krylov_schur_real.py).
     """
     if sort_function is None:
         sort_function = arg_largest_magnitude
-    T, Z = scipy.linalg.schur(a, output=output)
-    if output != "complex":
-        raise ValueError("output!='complex' not implemented yet")
-    return reorder_schur(T, Z, sort_function(np.diag(T)))
+    if output == "complex":
+        T, Z = scipy.linalg.schur(a, output=output)
+        return reorder_schur(T, Z, sort_function(np.diag(T)))
+    if output != "real":
+        raise ValueError("output must be 'complex' or 'real'")
+    if np.iscomplexobj(a):
+        raise ValueError("output='real' needs a real matrix")
+    from .krylov_schur_real import reorder_real_schur
+
+    T, Z = scipy.linalg.schur(a, output="real")
+    return reorder_real_schur(T, Z, sort_function)

@@ -165,8 +165,43 @@ def test_ordered_schur_golden_and_reference_test():
         T, Z = ordered_schur(g["hess_a"], output="complex", sort_function=fn)
         np.testing.assert_allclose(T, g[f"hess_{tag}_T"], rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(Z, g[f"hess_{tag}_Z"], rtol=1e-12, atol=1e-13)
-    with pytest.raises(ValueError, match="not implemented"):
-        ordered_schur(np.eye(3), output="real")
+    with pytest.raises(ValueError, match="needs a real matrix"):
+        ordered_schur(np.eye(3) + 1j, output="real")
+    with pytest.raises(ValueError, match="'complex' or 'real'"):
+        ordered_schur(np.eye(3), output="quasi")
+
+
+@pytest.mark.parametrize("dtype", ["f", "d"])
+def test_ordered_schur_real_form(dtype):
+    """The reference's own test of ``ordered_schur(output="real")`` (tests/test_utils.py:51-87), an xfail there
+    ("real mode not implemented yet"), restated and passing: real orthogonal Q, quasi-triangular T of the input's
+    type, ``Q T Q^T = A``, conjugate pairs as 2x2 blocks in the order of the sort function."""
+    from arnoldi_amd.krylov_schur_real import real_blocks
+    from arnoldi_amd.utils import ordered_schur
+
+    r_T = np.array([[1.0, 1.5, 0.8, 0.1, 0.4],
+                    [0.0, 2.0, 1.2, 1.0, 0.5],
+                    [0.0, -0.3, 2.0, 1.0, 0.3],
+                    [0.0, 0.0, 0.0, 4.0, 1.0],
+                    [0.0, 0.0, 0.0, -2.0, 4.0]]).astype(dtype)
+    complex_dtype = np.result_type(dtype, 1j)
+    r_eivals = np.array([4 + 1j * np.sqrt(2), 4 - 1j * np.sqrt(2), 2 + 1j * np.sqrt(1.2 * 0.3),
+                         2 - 1j * np.sqrt(1.2 * 0.3), 1]).astype(complex_dtype)
+    rng = np.random.RandomState(7)
+    r_Q, _ = np.linalg.qr(rng.randn(*r_T.shape).astype(dtype))
+    A = r_Q.T @ r_T @ r_Q
+    tol = 3000 * np.finfo(np.float32).eps if dtype == "f" else 2000 * np.finfo(np.float64).eps
+    T, Q = ordered_schur(A, output="real", sort_function=lambda v: np.argsort(-np.abs(v)))
+    assert T.dtype == np.dtype(dtype) and Q.dtype == np.dtype(dtype)
+    np.testing.assert_allclose(Q @ T @ Q.T.conj(), A, rtol=tol, atol=tol)
+    np.testing.assert_allclose(np.linalg.eigvals(T), r_eivals, rtol=tol, atol=tol)
+    assert real_blocks(T) == [(0, 2), (2, 2), (4, 1)]
+    np.testing.assert_allclose(Q.T @ Q, np.eye(5), atol=tol)
+    # smallest first: the real eigenvalue, then the pairs by modulus
+    T2, Q2 = ordered_schur(A, output="real", sort_function=lambda v: np.argsort(np.abs(v)))
+    assert real_blocks(T2) == [(0, 1), (1, 2), (3, 2)]
+    np.testing.assert_allclose(np.linalg.eigvals(T2), r_eivals[[4, 2, 3, 0, 1]], rtol=tol, atol=tol)
+    np.testing.assert_allclose(Q2 @ T2 @ Q2.T, A, rtol=tol, atol=tol)
 
 
 def test_start_vector_stream_and_history():
