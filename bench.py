@@ -81,6 +81,9 @@ def parse_args(argv=None):
                     help="force the Python-chained stage path on one GPU (the multi-GPU code path)")
     ap.add_argument("--arithmetic", choices=["complex", "real"], default="complex",
                     help="complex = the drop-in path (headline); real = partial_schur(arithmetic='real')")
+    ap.add_argument("--probe-every", type=int, default=1,
+                    help="record the HIP-event pairs around the SpMV / Gram-Schmidt launches in every K-th restart of "
+                         "the timed region (1 = every restart)")
     ap.add_argument("--leg", choices=["measure", "cpu", "preflight"], default=None,
                     help="(internal) run one extra leg and print its JSON object")
     return ap.parse_args(argv)
@@ -365,6 +368,8 @@ def _measure(args, comm, world, rank):
     t0 = time.perf_counter()
     for i in range(args.steps):
         solver.contract(args.warmup + i)
+        if probe is not None:
+            ctx.probe = probe if i % max(args.probe_every, 1) == 0 else None
         solver.expand()
     sync()
     elapsed = time.perf_counter() - t0
