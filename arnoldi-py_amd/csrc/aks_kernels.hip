@@ -1200,12 +1200,29 @@ void dispatch_update_proj_split(int J, dim3 grid, hipStream_t s, int64_t n, cons
     }
 }
 
+// Workgroups of the exact-width panel kernels (k_proj<NC>, k_update_proj<NC>).  These hold a whole row of the panel in
+// registers (two waves per SIMD fit at most) and stream best with ONE workgroup per CU: measured against the 1024
+// workgroups the other kernels use, -2...-5 % per launch for every width from 4 to 40 at n = 10M and -3...-10 % at
+// n = 1.25M (profiles/r03_rowblocks_ab2.txt; 1.5 workgroups per CU: slower; narrower than 4 columns a single wave per
+// SIMD has too few bytes in flight).  The column-split kernel wants the many workgroups (+60 % with one per CU).
+#ifndef AKS_PANEL_ONE_PER_CU
+#define AKS_PANEL_ONE_PER_CU 1
+#endif
+static int panel_blocks(const Ws &ws, int width) {
+    int dev = 0, cus = 0;
+    if (!AKS_PANEL_ONE_PER_CU || width < 4 || hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return ws.lay.n_blocks;
+    return cus < ws.lay.n_blocks ? cus : ws.lay.n_blocks;
+}
+
 // projection of all J columns in groups of <= NC_MAX columns of (nearly) equal width
 void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c128 *V, int64_t ldv,
                         const c128 *w, c128 *red_out, c128 *zero_slot, int raw0, hipEvent_t ev0 = nullptr) {
     const int groups = (J + NC_MAX - 1) / NC_MAX;
     const int base = J / groups, extra = J % groups;
-    const dim3 grid(ws.lay.n_blocks);
+    const int n_blocks = panel_blocks(ws, base);          // (every group writes the same rows of `partial`)
+    const dim3 grid(n_blocks);
     int c0 = 0;
     for (int g = 0; g < groups; ++g) {
         const int nc = base + (g < extra ? 1 : 0);
@@ -1213,7 +1230,7 @@ void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c12
                       g == 0 ? ev0 : nullptr);
         c0 += nc;
     }
-    hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
+    hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
                        ws.lay.ld_partial, 0, red_out, J, nullptr, nullptr, 0.0, zero_slot, ws.ctrl);
 }
 
@@ -1575,13 +1592,14 @@ static int gs_update_project_(int64_t n_rows, int32_t J, const aks_c128 *d_V, in
     // wins for 13 <= J <= 20.  (-DAKS_FUSED_EXACT_MAX=.. moves the upper switch point for A/B builds.)
     constexpr int exact_max = FUSED_EXACT_MAX;
     const bool exact = J <= exact_max && J <= NC_MAX && !(J >= 5 && J <= 12);
+    const int n_blocks = exact ? panel_blocks(ws, J) : ws.lay.n_blocks;
     if (exact)
-        dispatch_update_proj(J, dim3(ws.lay.n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
+        dispatch_update_proj(J, dim3(n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
                              ws.lay.ld_partial, ws.ctrl, ws.colscale, raw0);
     else
-        dispatch_update_proj_split(J, dim3(ws.lay.n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
+        dispatch_update_proj_split(J, dim3(n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
                                    ws.lay.ld_partial, ws.ctrl, ws.colscale, raw0);
-    hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
+    hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
                        ws.lay.ld_partial, 0, ws.red2, J, nullptr, nullptr, 0.0, nullptr, ws.ctrl);
     AKS_CHECK_LAUNCH("aks_gs_update_project");
     return AKS_OK;
