@@ -1208,12 +1208,12 @@ void dispatch_update_proj_split(int J, dim3 grid, hipStream_t s, int64_t n, cons
 #ifndef AKS_PANEL_ONE_PER_CU
 #define AKS_PANEL_ONE_PER_CU 1
 #endif
-static int panel_blocks(const Ws &ws, int width) {
+static int panel_blocks(const Ws &ws, int width, int per_cu = 1) {
     int dev = 0, cus = 0;
     if (!AKS_PANEL_ONE_PER_CU || width < 4 || hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         return ws.lay.n_blocks;
-    return cus < ws.lay.n_blocks ? cus : ws.lay.n_blocks;
+    return per_cu * cus < ws.lay.n_blocks ? per_cu * cus : ws.lay.n_blocks;
 }
 
 // projection of all J columns in groups of <= NC_MAX columns of (nearly) equal width
@@ -1253,7 +1253,10 @@ int launch_truncate_mfma(hipStream_t s, int64_t n, int m, int p, c128 *V, int64_
     if (smem > AKS_LDS_BYTES) return fail(AKS_ERR_UNSUPPORTED, "Qp does not fit the 160 KiB LDS");
     if (init_only) return raise_lds(k_truncate_mfma<MT, NS>, AKS_LDS_BYTES, "hipFuncSetAttribute(k_truncate_mfma)");
     const int64_t want = ((n + 16 * NS - 1) / (16 * NS) + WAVES - 1) / WAVES;
-    const dim3 grid((unsigned)(want < 4096 ? want : 4096));
+#ifndef AKS_TRUNC_BLOCKS
+#define AKS_TRUNC_BLOCKS 2048     // against 4096: -1 % (m = 20, p = 10) ... -3 % (m = 41, p = 25) at n = 10M, -3 ... -5 % at
+#endif                            // n = 1.25M; 256: +20 % (profiles/r03_trunc_grid_ab.txt)
+    const dim3 grid((unsigned)(want < AKS_TRUNC_BLOCKS ? want : AKS_TRUNC_BLOCKS));
     hipLaunchKernelGGL((k_truncate_mfma<MT, NS>), grid, dim3(BLOCK), smem, s, n, m, p, V, ldv, Qp, O, ldo, copy_last);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -1613,10 +1616,17 @@ static int gs_update_norm_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64
     rc = bind_ws(d_ws, ws_bytes, n_rows, max_dim, &ws);
     if (rc != AKS_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_update<true>, dim3(ws.lay.n_blocks), dim3(BLOCK), 0, s, n_rows, J,
+    // two workgroups per CU: -0.9 % / -1.7 % per Gram-Schmidt step on the 3-D / 2-D Laplacian, whose every step runs this
+    // kernel, against 1024 workgroups; one per CU: +6 % (profiles/r03_update_grid_ab.txt)
+#ifdef AKS_UPDATE_BLOCKS
+    const int n_blocks = AKS_UPDATE_BLOCKS < ws.lay.n_blocks ? AKS_UPDATE_BLOCKS : ws.lay.n_blocks;   // (A/B builds)
+#else
+    const int n_blocks = panel_blocks(ws, 4, 2);
+#endif
+    hipLaunchKernelGGL(k_update<true>, dim3(n_blocks), dim3(BLOCK), 0, s, n_rows, J,
                        reinterpret_cast<const c128 *>(d_V), ldv, reinterpret_cast<c128 *>(d_w), ws.red2,
                        ws.partial, ws.lay.ld_partial, 0, ws.red1, ws.red2, eta, ws.ctrl, ws.colscale, raw0);
-    hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(BLOCK), 0, s, ws.partial, ws.lay.n_blocks,
+    hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
                        ws.lay.ld_partial, 0, ws.red3, J, ws.red1, ws.red2, eta, nullptr, ws.ctrl);
     AKS_CHECK_LAUNCH("aks_gs_update_norm");
     return AKS_OK;
