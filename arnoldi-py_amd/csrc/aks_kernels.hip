@@ -89,7 +89,10 @@ inline void launch_timed(K kernel, dim3 grid, dim3 block, size_t smem, hipStream
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 constexpr int MAX_ROW_BLOCKS = 1024;
-constexpr int NC_MAX = 32;        // widest exact-width projection kernel (accumulators only)
+#ifndef AKS_NC_MAX
+#define AKS_NC_MAX 40             // (one launch instead of two groups for J = 33..40: -3 %, profiles/r03_proj40_ab.txt)
+#endif
+constexpr int NC_MAX = AKS_NC_MAX;        // widest exact-width projection kernel (accumulators only)
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -1159,6 +1162,9 @@ void dispatch_proj(int nc, dim3 grid, hipStream_t s, int64_t n, int c0, const c1
     switch (nc) {
 #define M(N) case N: launch_proj_nc<N>(grid, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0, ev0); break;
         AKS_NC_CASES(M)
+#if AKS_NC_MAX > 32
+        M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40)
+#endif
 #undef M
         default: break;
     }
@@ -1166,15 +1172,17 @@ void dispatch_proj(int nc, dim3 grid, hipStream_t s, int64_t n, int c0, const c1
 
 // exact-width fused kernel up to FUSED_EXACT_MAX columns, column-split fused kernel beyond
 #ifndef AKS_FUSED_EXACT_MAX
-#define AKS_FUSED_EXACT_MAX 20
+#define AKS_FUSED_EXACT_MAX 40
 #endif
 constexpr int FUSED_EXACT_MAX = AKS_FUSED_EXACT_MAX;
 
+#define AKS_NC_CASES_WIDE(M) M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40)
 void dispatch_update_proj(int nc, dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
                           const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0) {
     switch (nc) {
 #define M(N) case N: launch_update_proj_nc<N>(grid, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0); break;
         AKS_NC_CASES(M)
+        AKS_NC_CASES_WIDE(M)
 #undef M
         default: break;
     }
@@ -1590,11 +1598,16 @@ static int gs_update_project_(int64_t n_rows, int32_t J, const aks_c128 *d_V, in
     hipStream_t s = static_cast<hipStream_t>(stream);
     const c128 *V = reinterpret_cast<const c128 *>(d_V);
     c128 *w = reinterpret_cast<c128 *>(d_w);
-    // Measured at n = 10M (profiles/ab_kernels.py): the column-split kernel wins for 5 <= J <= 12 (more waves
-    // in flight) and for J > 20 (the exact-width kernel drops to one wave per SIMD); the exact-width kernel
-    // wins for 13 <= J <= 20.  (-DAKS_FUSED_EXACT_MAX=.. moves the upper switch point for A/B builds.)
+    // With one workgroup per CU (panel_blocks) the exact-width kernel wins at every width it exists for (J <= 40):
+    // against the column-split kernel -4...-7 % for J = 21..32 and -13...0 % for J = 5..12 at n = 10M, -1...-3 % at
+    // n = 1.25M (profiles/r03_exact_split_ab.txt).  Under the 1024-workgroup geometry of rounds 1-2 the split kernel
+    // had won for 5 <= J <= 12 and J > 20 (one wave per SIMD was then a loss, now it is the point).  The split kernel
+    // serves J > 40.  (-DAKS_FUSED_EXACT_MAX=.. / -DAKS_FUSED_SPLIT_LOW=1 restore the old switch points for A/B builds.)
     constexpr int exact_max = FUSED_EXACT_MAX;
-    const bool exact = J <= exact_max && J <= NC_MAX && !(J >= 5 && J <= 12);
+#ifndef AKS_FUSED_SPLIT_LOW
+#define AKS_FUSED_SPLIT_LOW 0
+#endif
+    const bool exact = J <= exact_max && J <= 40 && !(AKS_FUSED_SPLIT_LOW && J >= 5 && J <= 12);
     const int n_blocks = exact ? panel_blocks(ws, J) : ws.lay.n_blocks;
     if (exact)
         dispatch_update_proj(J, dim3(n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
