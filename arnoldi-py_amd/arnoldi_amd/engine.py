@@ -140,6 +140,17 @@ class CsrOperator:
     def nnz(self):
         return self.diag.nnz + (self.off.nnz if self.off is not None else 0)
 
+    def form_defers(self):
+        """Whether the library honours AKS_EXPAND_DEFER_SCALE for this operator's diagonal block (its own rule,
+        ``block_defers`` in csrc/aks_kernels.hip): the binned form, or the sliced form with a mean padded row length
+        of at most 8.  (The control block's ``deferred`` word says what an expansion actually did.)"""
+        if self.spmv_form == "binned":
+            return True
+        if self.spmv_form == "sliced":
+            d = self.diag.sliced.desc
+            return int(d.n_slices) > 0 and int(d.nnz_pad) <= 8 * 64 * int(d.n_slices)
+        return False
+
     def algorithmic_bytes(self):
         return (self.diag.algorithmic_bytes(self.real)
                 + (self.off.algorithmic_bytes(self.real) if self.off is not None else 0))
@@ -246,6 +257,12 @@ class ArnoldiContext:
         self.lazy_redos = 0
         # deferred normalisation of new basis columns (see expand): AKS_DEFER_SCALE=0 switches it off
         self.allow_defer = os.environ.get("AKS_DEFER_SCALE", "1") != "0"
+        # ... for expansions of at most this many steps: a raw column is divided again by every panel kernel that
+        # reads it until the restart -- (2..3) x (steps left) times per entry against ONE 32-byte pass saved.  Measured
+        # through whole restarts (profiles/r03_defer_sell_ab.txt, r03_defer_size_ab.txt): 10 steps per restart
+        # (k = 5, m = 20): +2.8 % random CSR, +3 % Markov; 25 steps with a second pass in each (2-D Laplace, m = 40):
+        # -0.5 ... -2.8 % at every size.
+        self.defer_max_steps = int(os.environ.get("AKS_DEFER_MAX_STEPS", "12"))
         self._raw_from = None       # first raw column of the basis, if an expansion left any
         self._raw_scale = {}        # column -> its scale beta (the host's copy of the workspace's colscale)
         self.deferred_expansions = 0
@@ -274,7 +291,8 @@ class ArnoldiContext:
         ``defer_scale``: the caller's next operation on the basis is ``truncate`` / ``truncate_active`` (the
         Krylov-Schur drivers): the new columns may then stay RAW -- the device keeps their norms as scales and every
         kernel that reads them divides on the fly, instead of a 32 n byte normalisation pass per step
-        (AKS_EXPAND_DEFER_SCALE; honoured by the C-driven path when the diagonal block is in the binned form).
+        (AKS_EXPAND_DEFER_SCALE; honoured by the C-driven path when the diagonal block is in the binned form, or in the
+        sliced form with short rows: ``CsrOperator.form_defers``).
         H is bit for bit the same (the on-the-fly division is the one the normalisation pass performs); the
         truncation that follows multiplies raw columns by coefficients scaled on the host (``_fold_scales``), a
         rounding-level difference.  Until then the columns ``> start`` must not be read by anything else
@@ -286,7 +304,8 @@ class ArnoldiContext:
         w_ready = bool(consume_lookahead and self._look_valid and end > start)
         self._look_valid = False
         native = isinstance(op, CsrOperator) and op.c_driven and not self.force_chained
-        defer = bool(defer_scale and native and self.allow_defer and op.spmv_form == "binned")
+        defer = bool(defer_scale and native and self.allow_defer and op.form_defers()
+                     and (end - start <= self.defer_max_steps or self._raw_from is not None))
         if self._raw_from is not None and (start > self._raw_from or (start == self._raw_from and not defer)):
             raise _hip.HipLibraryError("expansion from a raw column: the basis must be truncated first")
         multi = self.comm is not None and self.comm.active

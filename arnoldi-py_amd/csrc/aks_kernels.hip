@@ -689,8 +689,13 @@ template <typename VT, typename XT, bool ACC>
 __global__ __launch_bounds__(BLOCK) void k_sell(int64_t n_rows, int64_t n_slices, const int64_t *__restrict__ slice_ptr,
                                                const int32_t *__restrict__ col, const VT *__restrict__ val,
                                                const XT *__restrict__ x, XT *__restrict__ y,
-                                               const aks_ctrl *__restrict__ ctrl) {
+                                               const aks_ctrl *__restrict__ ctrl, const double *__restrict__ x_div) {
     if (ctrl != nullptr && ctrl->broken) return;
+    // x may be a RAW basis column (deferred normalisation, only offered for short rows: sell_defers): every gathered
+    // entry is divided by the column's scale -- the division k_finish would have done once per entry, here once per
+    // non-zero, which a kernel that waits for memory has the cycles for as long as rows are short
+    const double xd = x_div != nullptr ? *x_div : 0.0;
+    const bool raw = is_raw(xd);
     const int lane = threadIdx.x & 63;
     const int64_t per_xcd = (gridDim.x + 7) >> 3;
     const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -711,6 +716,10 @@ __global__ __launch_bounds__(BLOCK) void k_sell(int64_t n_rows, int64_t n_slices
         for (int u = 0; u < SELL_U; ++u) { cc[u] = ld_sell(&c[(int64_t)(k + u) * 64]); vv[u] = ld_sell(&v[(int64_t)(k + u) * 64]); }
 #pragma unroll
         for (int u = 0; u < SELL_U; ++u) xx[u] = x[max(cc[u], 0)];
+        if (raw) {
+#pragma unroll
+            for (int u = 0; u < SELL_U; ++u) xx[u] = unscale(xx[u], xd);
+        }
 #pragma unroll
         for (int u = 0; u < SELL_U; ++u)
             if (cc[u] >= 0) acc = xt_add(acc, cmul(vv[u], xx[u]));
@@ -718,7 +727,8 @@ __global__ __launch_bounds__(BLOCK) void k_sell(int64_t n_rows, int64_t n_slices
     for (; k < W; ++k) {
         const int cc = ld_sell(&c[(int64_t)k * 64]);
         const VT vv = ld_sell(&v[(int64_t)k * 64]);
-        const XT xx = x[max(cc, 0)];
+        XT xx = x[max(cc, 0)];
+        if (raw) xx = unscale(xx, xd);
         if (cc >= 0) acc = xt_add(acc, cmul(vv, xx));
     }
     const int64_t row = slice * 64 + lane;
@@ -1311,19 +1321,29 @@ int nccl_fail(ncclResult_t r, const char *where) {
 int launch_pb_any(const aks_pb_matrix *A, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
                   const double *x_div, EvPair ev);
 
-// (x_div: scale of a raw input column -- deferred normalisation; only the binned form can apply it, and
-// aks_arnoldi_expand defers only when the diagonal block is in that form)
+// (x_div: scale of a raw input column -- deferred normalisation.  The binned form applies it once per x entry, the
+// sliced form once per non-zero and therefore only for short rows; aks_arnoldi_expand defers only when the diagonal
+// block is in one of these two shapes: block_defers)
 int sell_spmv_any(const aks_sell_matrix *A, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
-                  EvPair ev);
+                  const double *x_div, EvPair ev);
+#ifndef AKS_SELL_DEFER_WIDTH
+#define AKS_SELL_DEFER_WIDTH 8    // mean padded row length up to which the sliced form divides raw x entries on the fly
+#endif
+static bool block_defers(const aks_csr_block &B) {
+    if (B.pb != nullptr) return true;
+    return B.sell != nullptr && B.sell->n_slices > 0 &&
+           B.sell->nnz_pad <= (int64_t)AKS_SELL_DEFER_WIDTH * 64 * B.sell->n_slices;
+}
 int csr_spmv_any(const aks_csr_block &B, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
                  EvPair ev);
 
 int apply_block(const aks_csr_block &B, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
                 const double *x_div = nullptr, EvPair ev = EvPair()) {
     if (B.n_rows <= 0) return AKS_OK;
-    if (x_div != nullptr && B.pb == nullptr) return fail(AKS_ERR_ARG, "a raw input column needs the binned form");
+    if (x_div != nullptr && !block_defers(B))
+        return fail(AKS_ERR_ARG, "a raw input column needs the binned form or the sliced form with short rows");
     if (real && B.values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
-    if (B.sell != nullptr) return sell_spmv_any(B.sell, x, y, accumulate, d_ws, stream, real, ev);
+    if (B.sell != nullptr) return sell_spmv_any(B.sell, x, y, accumulate, d_ws, stream, real, x_div, ev);
     if (B.pb != nullptr) return launch_pb_any(B.pb, x, y, accumulate, d_ws, stream, real, x_div, ev);
     return csr_spmv_any(B, x, y, accumulate, d_ws, stream, real, ev);
 }
@@ -1418,31 +1438,31 @@ int check_sell(const aks_sell_matrix *A, const void *x, const void *y) {
 
 template <typename VT, typename XT>
 int launch_sell(const aks_sell_matrix *A, const XT *x, XT *y, int accumulate, const aks_ctrl *ctrl, hipStream_t s,
-                EvPair ev = EvPair()) {
+                const double *x_div = nullptr, EvPair ev = EvPair()) {
     const dim3 grid((unsigned)(((A->n_slices + WAVES - 1) / WAVES + 7) / 8 * 8));    // whole groups of 8: the XCD order
     const VT *val = static_cast<const VT *>(A->d_val);
     if (accumulate)
-        launch_timed(k_sell<VT, XT, true>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, A->n_rows, A->n_slices, A->d_slice_ptr, A->d_col, val, x, y, ctrl);
+        launch_timed(k_sell<VT, XT, true>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, A->n_rows, A->n_slices, A->d_slice_ptr, A->d_col, val, x, y, ctrl, x_div);
     else
-        launch_timed(k_sell<VT, XT, false>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, A->n_rows, A->n_slices, A->d_slice_ptr, A->d_col, val, x, y, ctrl);
+        launch_timed(k_sell<VT, XT, false>, grid, dim3(BLOCK), 0, s, ev.start, ev.stop, A->n_rows, A->n_slices, A->d_slice_ptr, A->d_col, val, x, y, ctrl, x_div);
     AKS_CHECK_LAUNCH("aks_sell_spmv");
     return AKS_OK;
 }
 
 int sell_spmv_any(const aks_sell_matrix *A, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
-                  EvPair ev) {
+                  const double *x_div, EvPair ev) {
     int rc = check_sell(A, x, y);
     if (rc != AKS_OK) return rc;
     const aks_ctrl *ctrl = static_cast<const aks_ctrl *>(d_ws);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (real) {
         if (A->values_complex) return fail(AKS_ERR_ARG, "real vectors need real matrix values");
-        return launch_sell<double, double>(A, static_cast<const double *>(x), static_cast<double *>(y), accumulate, ctrl, s, ev);
+        return launch_sell<double, double>(A, static_cast<const double *>(x), static_cast<double *>(y), accumulate, ctrl, s, x_div, ev);
     }
     const c128 *xc = static_cast<const c128 *>(x);
     c128 *yc = static_cast<c128 *>(y);
-    return A->values_complex ? launch_sell<c128, c128>(A, xc, yc, accumulate, ctrl, s, ev)
-                             : launch_sell<double, c128>(A, xc, yc, accumulate, ctrl, s, ev);
+    return A->values_complex ? launch_sell<c128, c128>(A, xc, yc, accumulate, ctrl, s, x_div, ev)
+                             : launch_sell<double, c128>(A, xc, yc, accumulate, ctrl, s, x_div, ev);
 }
 
 int csr_spmv_any(const aks_csr_block &B, const void *x, void *y, int accumulate, const void *d_ws, void *stream, bool real,
@@ -1963,12 +1983,12 @@ int aks_sell_plan_fill(const int32_t *indptr, const int32_t *indices, const void
 
 int aks_sell_spmv(const aks_sell_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, int32_t accumulate, const void *d_ws,
                   void *stream) {
-    return sell_spmv_any(A, d_x, d_y, accumulate, d_ws, stream, false, EvPair());
+    return sell_spmv_any(A, d_x, d_y, accumulate, d_ws, stream, false, nullptr, EvPair());
 }
 
 int aks_sell_spmv_real(const aks_sell_matrix *A, const double *d_x, double *d_y, int32_t accumulate, const void *d_ws,
                        void *stream) {
-    return sell_spmv_any(A, d_x, d_y, accumulate, d_ws, stream, true, EvPair());
+    return sell_spmv_any(A, d_x, d_y, accumulate, d_ws, stream, true, nullptr, EvPair());
 }
 
 // ---- communicator: RCCL + a side stream for the ghost exchange ------------------------------
@@ -2134,8 +2154,9 @@ int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 
     if (rc != AKS_OK) return rc;
     // Deferred normalisation: the new columns stay raw (k_finish books their scales instead of dividing), their
     // readers divide.  Only when this rank's diagonal block is in the binned form, whose phase 1 stages every x entry
-    // exactly once -- the other forms gather an entry once per non-zero and would divide that often.
-    const bool defer = (flags & AKS_EXPAND_DEFER_SCALE) != 0 && A->diag.pb != nullptr;
+    // exactly once, or in the sliced form with short rows (mean padded length <= AKS_SELL_DEFER_WIDTH): the sliced
+    // and CSR-stream kernels gather an entry once per non-zero and divide that often.
+    const bool defer = (flags & AKS_EXPAND_DEFER_SCALE) != 0 && block_defers(A->diag);
     const int norm_mode = defer ? 2 : 1;
     for (int32_t j = start_dim; j < end_dim; ++j) {
         const int32_t J = j + 1;
@@ -2177,7 +2198,7 @@ int aks_shard_apply_col(const aks_shard *A, const aks_c128 *d_V, int64_t ldv, in
     // (the scale is passed on only where it can be applied; a form that cannot never sees a raw column, see
     // aks_arnoldi_expand)
     return shard_apply(A, d_V + (int64_t)col * ldv, d_y, d_ws, stream, flags, nullptr,
-                       A->diag.pb != nullptr ? ws.colscale + col : nullptr);
+                       block_defers(A->diag) ? ws.colscale + col : nullptr);
 }
 
 int aks_truncate_ws(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t ldv, const aks_c128 *d_Qp,

@@ -338,8 +338,9 @@ int aks_shard_apply(const aks_shard *A, const void *d_x, void *d_y, const void *
  *                           number that enters the arithmetic is bit for bit the one the normalised column would
  *                           have held).  Precondition: columns 0 .. start_dim - 1 are normalised (column start_dim
  *                           may be the raw column a restart compression carried over).  Honoured only while
- *                           this rank's diagonal block is in the binned form (the other SpMV forms would divide an
- *                           x entry once per non-zero); otherwise ignored.  The caller must follow the expansion
+ *                           this rank's diagonal block is in the binned form (an x entry is divided once) or in the
+ *                           sliced form with a mean padded row length of at most 8 (divided once per non-zero: cheap
+ *                           next to the 32 n byte pass only for short rows); otherwise ignored.  The caller must follow the expansion
  *                           with aks_truncate_ws (scaled coefficients, see there) before anything but
  *                           aks_arnoldi_expand / aks_shard_apply_col / aks_truncate_ws reads V.  H and the control
  *                           block of an expansion are bit for bit the same with and without the flag. */

@@ -371,6 +371,7 @@ def test_deferred_normalisation_changes_nothing_but_rounding(amd, monkeypatch, m
         Hs = []
         for flag in (False, True):
             ctx = ArnoldiContext(CsrOperator(A, spmv_form="binned"), 20)
+            ctx.defer_max_steps = 20                             # (default: expansions of <= 12 steps)
             np.random.seed(0)
             ctx.set_start_vector(rand_normalized_vector(A.shape[0], C128))
             H = np.zeros((21, 20), C128)
@@ -383,6 +384,66 @@ def test_deferred_normalisation_changes_nothing_but_rounding(amd, monkeypatch, m
     st = {}
     amd.partial_schur(CsrOperator(A, spmv_form="csr"), 5, stats=st, max_dim=20, sort_function=oracle.arg_largest_magnitude)
     assert st["deferred_normalisations"] == 0
+
+
+def test_deferred_normalisation_in_the_sliced_form_for_short_rows(amd, monkeypatch):
+    """The sliced form divides a raw x entry once per non-zero, so it defers only where rows are short (mean padded
+    length <= 8: Markov chains, the Laplacians): same History and restart count as the run that normalises at once,
+    eigenvalues to 1e-11, residuals within the 1.05 bound, H of one expansion bit for bit; a band of 35 entries per
+    row keeps the normalisation pass.  (Either form defers only expansions of at most ``defer_max_steps`` = 12 steps by
+    default: a raw column is divided again by every kernel that reads it.)"""
+    from arnoldi_amd.engine import ArnoldiContext, CsrOperator
+    from arnoldi_amd.matrices import laplace2d, mark
+    from arnoldi_amd.utils import arg_largest_real, rand_normalized_vector
+
+    monkeypatch.setenv("AKS_GRAPH", "0")
+    cases = (("markov", mark(120), dict(max_dim=20, stopping_criterion=1e-8, sort_function=arg_largest_real), 5),
+             ("laplace", laplace2d(60, 61), dict(max_dim=20, sort_function=oracle.arg_largest_magnitude), 5))
+    for name, A, kw, nev in cases:
+        for real in (False, True):
+            if real:
+                kw = dict(kw, arithmetic="real")
+            out = []
+            for flag in ("0", "1"):
+                monkeypatch.setenv("AKS_DEFER_SCALE", flag)
+                np.random.seed(0)
+                st = {}
+                Q, T, h = amd.partial_schur(CsrOperator(A, spmv_form="sliced", real=real), nev, stats=st, **kw)
+                assert st["spmv_form"] == "sliced" and (st["deferred_normalisations"] > 0) == (flag == "1"), (name, real, flag)
+                _, _, rel = oracle.eig_residuals(A, Q, T)
+                out.append((np.diag(T), h.restarts.copy(), h.matvecs.copy(), st["restarts"], rel.max()))
+            np.testing.assert_array_equal(out[0][1], out[1][1])
+            np.testing.assert_array_equal(out[0][2], out[1][2])
+            assert out[0][3] == out[1][3]
+            np.testing.assert_allclose(np.sort_complex(out[1][0]), np.sort_complex(out[0][0]), rtol=1e-11, atol=1e-12)
+            assert out[1][4] <= max(1.05 * out[0][4], 1e-13), (name, real, out[0][4], out[1][4])
+        Hs = []
+        for flag in (False, True):
+            ctx = ArnoldiContext(CsrOperator(A, spmv_form="sliced"), 20)
+            ctx.defer_max_steps = 20
+            np.random.seed(0)
+            ctx.set_start_vector(rand_normalized_vector(A.shape[0], C128))
+            H = np.zeros((21, 20), C128)
+            assert ctx.expand(H, 0, 20, 1e-8, defer_scale=flag) == 20
+            assert (ctx.deferred_expansions == 1) == flag
+            Hs.append(H)
+        np.testing.assert_array_equal(Hs[0], Hs[1])
+    # 25 steps per restart (m = 40, p = 15): not deferred by default -- too many kernels would divide each raw column
+    monkeypatch.setenv("AKS_DEFER_SCALE", "1")
+    np.random.seed(0)
+    st = {}
+    amd.partial_schur(CsrOperator(laplace2d(60, 61), spmv_form="sliced"), 10, max_dim=40, stats=st,
+                      sort_function=oracle.arg_largest_magnitude)
+    assert st["deferred_normalisations"] == 0
+    # long rows: the sliced form keeps the normalisation pass
+    from arnoldi_amd.matrices import banded_csr
+
+    B = banded_csr(20000, 35, 7)
+    np.random.seed(0)
+    ctx = ArnoldiContext(CsrOperator(B, spmv_form="sliced"), 20)
+    ctx.defer_max_steps = 20
+    ctx.set_start_vector(rand_normalized_vector(B.shape[0], C128))
+    assert ctx.expand(np.zeros((21, 20), C128), 0, 20, 1e-8, defer_scale=True) == 20 and ctx.deferred_expansions == 0
 
 
 def test_two_host_threads_solve_concurrently(amd):
@@ -986,6 +1047,7 @@ def test_stress_grid_with_deferred_normalisation(amd, monkeypatch, nev, ncv, p, 
     from arnoldi_amd import matrices
 
     monkeypatch.setenv("AKS_SPMV_FORM", "binned")
+    monkeypatch.setenv("AKS_DEFER_MAX_STEPS", "1000")     # (the default defers only expansions of <= 12 steps)
     if which == "LM":
         A, sort_o, tol = matrices.laplace2d(30, 31), oracle.arg_largest_magnitude, None
     else:
