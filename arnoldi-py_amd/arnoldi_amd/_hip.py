@@ -10,7 +10,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_DIM = 128          # AKS_MAX_DIM
 MAX_TRUNC = 96         # AKS_MAX_TRUNC
 SPMV_TILE_NNZ = 256    # AKS_SPMV_TILE_NNZ
@@ -51,7 +51,8 @@ class Ctrl(C.Structure):
         ("beta", C.c_double),
         ("real_mode", C.c_int32),
         ("deferred", C.c_int32),
-        ("reserved", C.c_double * 3),
+        ("ticket", C.c_uint32 * 4),
+        ("reserved", C.c_double),
     ]
 
 

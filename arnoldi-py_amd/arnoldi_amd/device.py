@@ -199,7 +199,10 @@ class DeviceCSR:
         <= 1.25 x nnz); the CSR-stream kernel otherwise.  By default a candidate is taken as it is -- every
         measurement so far has it ahead (binned 2x on random graphs, sliced 1.1-1.35x on stencils, bands and
         the Markov chain) -- so the choice, and with it the summation order of a row and the BITS of a solve,
-        is a function of the matrix alone, identical from run to run and from rank to rank.
+        is a function of the matrix BLOCK alone: identical from run to run.  (In a row-sharded solve every rank
+        tunes its own diagonal and off-diagonal block, so the forms -- and with them the summation order and whether
+        normalisations are deferred -- follow the sharding; results of different shardings agree to rounding, not
+        bit for bit.)
         ``measure=True`` (or AKS_SPMV_TUNE=measure) times the candidate against the CSR-stream kernel on this
         device instead and keeps it only if it is >= 10 % (binned) / 5 % (sliced) faster: the answer then
         depends on a timing (``tune_ms`` records it).
@@ -500,8 +503,10 @@ def dgks_gs_device(basis, J, w, hcol, ldh, tol, ws, eta=ETA_DGKS, normalize=True
 
 def truncate(basis, m, p, Qp_dev, ws=None, col0=0):
     """``V[:, col0:col0+p] = V[:, col0:col0+m] @ Qp ; V[:, col0+p] = V[:, col0+m]`` in place.  With ``ws``: through
-    ``aks_truncate_ws`` -- columns left raw by an expansion that deferred its normalisations are divided by their
-    scales as they are read, and the scales are cleared."""
+    ``aks_truncate_ws``, which only BOOKS the scales of raw columns (clears them; column ``col0+p`` inherits the scale
+    of column ``col0+m``): the kernel itself is ``aks_truncate``'s and divides nothing -- for columns left raw by an
+    expansion that deferred its normalisations the CALLER must have divided the matching rows of ``Qp`` by those
+    columns' scales (``ArnoldiContext._fold_scales``; include/arnoldi_hip.h says the same)."""
     first = basis.V.data_ptr() + 16 * basis.ldv * col0
     if ws is None:
         rc = _hip.load().aks_truncate(basis.n_rows, m, p, first, basis.ldv, _ptr(Qp_dev), _stream())

@@ -19,7 +19,6 @@ AKS_DIST_PATH=python.
 from __future__ import annotations
 
 import atexit
-import weakref
 
 import numpy as np
 import scipy.sparse as sp
@@ -44,6 +43,18 @@ def row_offsets(n, world, indptr=None):
     cuts = np.searchsorted(w, targets, side="left")
     offs = np.concatenate([[0], cuts, [n]]).astype(np.int64)
     return np.maximum.accumulate(offs)
+
+
+def slab_offsets(dims, world):
+    """Row offsets of a grid operator (x fastest) cut along its LAST dimension into ``world`` slabs of whole planes
+    (lines in 2-D), as even as the plane count allows -- SURVEY 8(e): "Laplace: z-slabs".  A rank then exchanges
+    exactly one plane with each neighbour.  Falls back to even rows when there are fewer planes than ranks."""
+    dims = tuple(int(d) for d in dims)
+    plane = int(np.prod(dims[:-1])) if len(dims) > 1 else 1
+    n = plane * dims[-1]
+    if dims[-1] < world:
+        return row_offsets(n, world)
+    return row_offsets(dims[-1], world) * plane
 
 
 class GhostPlan:
@@ -87,7 +98,8 @@ def split_local_rows(A_rows, offsets, rank):
 
 
 # --------------------------------------------------------------------------- communicator
-_live_comms = weakref.WeakSet()   # Comms that own an RCCL communicator: destroyed at interpreter exit at the latest
+_live_comms = set()          # Comms that own an RCCL communicator (strong references: a communicator is never left to the
+                             # garbage collector): destroyed by close() or at interpreter exit
 _default_comms = {}          # process group -> Comm, so that repeated solves share one communicator
 
 
@@ -229,10 +241,14 @@ class Comm:
         _live_comms.discard(self)
 
     def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        # NOT destroyed here: ncclCommDestroy is a collective among the ranks of a node, and the garbage
+        # collector runs at a different point on every rank -- possibly in the middle of a hipGraph capture.  The
+        # communicator goes with close(), with comm_for()'s replacement of a re-initialised group's Comm, or at exit.
+        if getattr(self, "_native", None) is not None:
+            import warnings
+
+            warnings.warn("arnoldi_amd.dist.Comm collected with a live RCCL communicator: call close() "
+                          "(it stays alive until the interpreter exits)", ResourceWarning, stacklevel=2)
 
     # -- small host-side exchanges used while building plans -----------------
     def allgather_int64(self, values):
@@ -308,6 +324,14 @@ class Comm:
     def alltoallv_finish(handle):
         if handle is not None:
             handle.wait()
+
+    def max_float(self, x):
+        """Largest ``x`` over the ranks (bench.py: the slowest rank's wall time)."""
+        if self.size == 1:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self._wire_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
 
     def barrier(self):
         if self.size > 1:

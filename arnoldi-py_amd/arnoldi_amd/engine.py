@@ -132,6 +132,12 @@ class CsrOperator:
         # in C whenever this rank's collectives can be issued from C: one GPU, or RCCL
         self.c_driven = self.comm is None or not self.comm.active or self.native_comm
 
+    def check_comm(self):
+        """The shard carries the raw handle of the Comm's RCCL communicator: once that Comm has been closed the
+        handle dangles, so every C call that would use it is refused here."""
+        if self.native_comm and self.comm._native is None:
+            raise _hip.HipLibraryError("the communicator this operator was built on has been closed")
+
     @property
     def shape(self):
         return (self.n, self.n)
@@ -159,6 +165,7 @@ class CsrOperator:
         """y = A x for this shard's rows; x, y are columns of V (local rows; real-packed if ``real``)."""
         real = self.real
         if self.c_driven:
+            self.check_comm()
             rc = _hip.load().aks_shard_apply(C.byref(self.shard), dev._ptr(x), dev._ptr(y),
                                              dev._ptr(ws.buf) if ws is not None else C.c_void_p(0), dev._stream(),
                                              _hip.EXPAND_REAL_PACKED if real else 0)
@@ -241,6 +248,7 @@ class ArnoldiContext:
         self.basis = dev.KrylovBasis(op.n_local, max_dim, device, real=self.real)
         self.ws = dev.Workspace(self.basis.n_rows, max_dim, device, real=self.real)
         self.matvecs = 0
+        self._hess_mask = np.arange(self.max_dim + 1)[:, None] <= np.arange(self.max_dim)[None, :] + 1   # rows i <= j + 1
         self.probe = None   # optional _hip.Probe (bench.py): device time of SpMV / ortho launches
         self.spmv_events = None  # optional list (bench.py, Python-chained path): torch event pairs
         self.force_chained = False  # run the Python-chained stage path even on one GPU (tests, bench)
@@ -268,6 +276,8 @@ class ArnoldiContext:
         self.deferred_expansions = 0
         self.discarded_second_passes = self.discarded_steps = self.discarded_applies = 0   # work of repeated expansions
         self.last_ctrl = None
+        self._coef_stage = self._coef_dev = None      # pinned / device buffers of the restart coefficients
+        self._coef_turn = 0
         self._look = None           # scratch columns; [_look_col] holds A V[:, end] of the last expansion
         self._look_col = 0
         self._look_valid = False
@@ -332,6 +342,7 @@ class ArnoldiContext:
                 self._expand_chained(start, end, tol, eta, w_ready, lazy, multi)
             fetch = dev.fetch_H_and_ctrl(b, ws)             # queued before the look-ahead, waited for after it
             if want_look and defer:                          # column `end` is raw: its scale comes from the workspace
+                op.check_comm()
                 rc = _hip.load().aks_shard_apply_col(
                     C.byref(op.shard), dev._ptr(b.V), b.ldv, end, dev._ptr(self._look.col(1 - self._look_col)),
                     dev._ptr(ws.buf), ws.nbytes, ws.max_dim, dev._stream(), _hip.EXPAND_REAL_PACKED if self.real else 0)
@@ -372,9 +383,16 @@ class ArnoldiContext:
         self.matvecs += n_iter - start
         if not np.iscomplexobj(H):
             Hd = Hd.real                                  # real-packed mode: a real Hessenberg matrix
-        for j in range(start, n_iter):
-            rows = j + 1 if (ctrl.broken and j == n_iter - 1) else j + 2
-            H[:rows, j] = Hd[:rows, j]
+        # the reference's in-place writes: column j gets rows 0 .. j+1 (0 .. j when the step broke down:
+        # decomposition.py:61-63 returns before H[j+1, j] is written) -- one masked copy instead of a Python loop
+        # over the columns (the host's share of a restart matters at the 8-GPU shard sizes)
+        if n_iter > start:
+            rows = min(H.shape[0], self.max_dim + 1)
+            mask = self._hess_mask[:rows, start:n_iter]
+            if ctrl.broken:
+                mask = mask.copy()
+                mask[n_iter, n_iter - 1 - start] = False
+            np.copyto(H[:rows, start:n_iter], Hd[:rows, start:n_iter], where=mask)
         self.last_ctrl = ctrl
         return n_iter
 
@@ -384,6 +402,8 @@ class ArnoldiContext:
         b, ws, op = self.basis, self.ws, self.op
         flags = ((_hip.EXPAND_FROM_W if w_ready else 0) | (_hip.EXPAND_REAL_PACKED if self.real else 0)
                  | (_hip.EXPAND_LAZY_THIRD if lazy else 0) | (_hip.EXPAND_DEFER_SCALE if defer else 0))
+
+        op.check_comm()
 
         def enqueue():
             rc = _hip.load().aks_arnoldi_expand(
@@ -471,15 +491,38 @@ class ArnoldiContext:
         ``col0 + m`` and inherits its scale."""
         Q = np.array(Q, dtype=C128, copy=True).reshape(m, p)
         if self._raw_from is not None:
-            for c in range(max(self._raw_from, col0), col0 + m):
-                Q[c - col0, :] /= self._raw_scale[c]
+            first = max(self._raw_from, col0)
+            if first < col0 + m:
+                scales = np.array([self._raw_scale[c] for c in range(first, col0 + m)])
+                Q[first - col0:, :] /= scales[:, None]
             carried = self._raw_scale.get(col0 + m) if col0 + m >= self._raw_from else None
             self._raw_scale = {} if carried is None else {col0 + p: carried}
             self._raw_from = None if carried is None else col0 + p
         return Q
 
+    def _upload_coefficients(self, Q):
+        """The restart coefficients (m x p complex128, a few KB) to the device: through one of two alternating pinned
+        staging buffers with an asynchronous copy, so that the truncation kernel is enqueued right behind it -- a
+        pageable ``.to(device)`` is a synchronous staged copy and put ~30 us of idle device time in front of every
+        restart compression (profiles/r03_small_trace.txt: __amd_rocclr_copyBuffer -> k_truncate_mfma).  A staging
+        buffer is reused two restarts later; the H read-back of the expansion in between has been waited for by then,
+        which orders the host behind the copy that used it."""
+        b = self.basis
+        Q = np.ascontiguousarray(Q, dtype=C128)
+        if not b.V.is_cuda:                                   # CPU tensors (tests/fake_hip.py)
+            return torch.from_numpy(Q).to(b.device)
+        if self._coef_stage is None or self._coef_stage[0].numel() < Q.size:
+            cap = max(Q.size, self.max_dim * self.max_dim)
+            self._coef_stage = [torch.empty(cap, dtype=torch.complex128, pin_memory=True) for _ in range(2)]
+            self._coef_dev = [torch.empty(cap, dtype=torch.complex128, device=b.device) for _ in range(2)]
+        self._coef_turn ^= 1
+        stage, out = self._coef_stage[self._coef_turn], self._coef_dev[self._coef_turn]
+        stage[: Q.size].numpy()[:] = Q.reshape(-1)
+        out[: Q.size].copy_(stage[: Q.size], non_blocking=True)
+        return out[: Q.size]
+
     def truncate(self, Qp, m, p):
-        Qd = torch.from_numpy(np.ascontiguousarray(self._fold_scales(Qp, 0, m, p))).to(self.basis.device)
+        Qd = self._upload_coefficients(self._fold_scales(Qp, 0, m, p))
         dev.truncate(self.basis, m, p, Qd, self.ws)         # (raw columns x scaled coefficients: normalised results)
 
     def truncate_active(self, Zp, l, m, p):
@@ -487,17 +530,23 @@ class ArnoldiContext:
         ``V[:, l:p] = V[:, l:m] @ Zp`` and ``V[:, p] = V[:, m]`` -- ``aks_truncate`` on the sub-basis that
         starts at column ``l``; the locked columns are neither read nor written."""
         b = self.basis
-        Zd = torch.from_numpy(np.ascontiguousarray(self._fold_scales(Zp, l, m - l, p - l))).to(b.device)
+        Zd = self._upload_coefficients(self._fold_scales(Zp, l, m - l, p - l))
         dev.truncate(b, m - l, p - l, Zd, self.ws, col0=l)
 
     # -- data movement --------------------------------------------------------------
     def set_start_vector(self, v_full):
         self.basis.set_col(0, v_full[self.op.r0: self.op.r1])
 
-    def local_columns(self, j0, j1):
+    def _need_normalised(self, j1, what):
+        """Every entry point that READS basis columns below ``j1`` outside the expansion / truncation pair goes through
+        here: columns left raw by an expansion with deferred normalisation hold ``beta v`` until the basis has been
+        truncated, and only the library's own readers know their scales (one check, every reader)."""
         if self._raw_from is not None and j1 > self._raw_from:
-            raise _hip.HipLibraryError("columns of an expansion with deferred normalisation are raw until the basis "
-                                       "has been truncated")
+            raise _hip.HipLibraryError(f"{what}: columns >= {self._raw_from} of an expansion with deferred normalisation "
+                                       "are raw until the basis has been truncated")
+
+    def local_columns(self, j0, j1):
+        self._need_normalised(j1, "local_columns")
         return self.basis.get_cols(j0, j1)
 
     def gather_columns(self, j0, j1):
@@ -516,6 +565,7 @@ class ArnoldiContext:
         ``vecs = Q S``, ``residual_norms`` does the rest."""
         k = T.shape[0]
         vals, S = np.linalg.eig(T)
+        self._need_normalised(k, "true_residuals")
         if self.real:
             res = self._residual_norms_real(k, S, vals)
             return vals, res, res / np.abs(vals)
@@ -574,6 +624,7 @@ class ArnoldiContext:
         b, ws, lib = self.basis, self.ws, _hip.load()
         self._clear_ctrl()
         w = b.V.data_ptr() + 16 * b.ldv * j
+        self._need_normalised(max(k, j + 1), "mgs")
         args = (dev._ptr(ws.buf), ws.nbytes, ws.max_dim, dev._stream())
         multi = self._multi()
         for i in range(max(k, 1)):
@@ -598,6 +649,7 @@ class ArnoldiContext:
         recomputes.)"""
         b = self.basis
         Sd = torch.from_numpy(np.ascontiguousarray(np.asarray(s, dtype=C128).reshape(m - k, 1))).to(b.device)
+        self._need_normalised(m, "ritz_vector_into_first")
         rc = _hip.load().aks_truncate(b.n_rows, m - k, 1, b.V.data_ptr() + 16 * b.ldv * k, b.ldv,
                                       dev._ptr(Sd), dev._stream())
         _hip.check(rc, "aks_truncate")
@@ -609,6 +661,7 @@ class ArnoldiContext:
         S = np.ascontiguousarray(np.asarray(S, dtype=C128).reshape(m - k, -1))
         q = S.shape[1]
         assert 1 <= q <= m - k
+        self._need_normalised(m, "ritz_vectors_into_first")
         Sd = torch.from_numpy(S).to(b.device)
         rc = _hip.load().aks_truncate(b.n_rows, m - k, q, b.V.data_ptr() + 16 * b.ldv * k, b.ldv,
                                       dev._ptr(Sd), dev._stream())
@@ -624,6 +677,7 @@ class ArnoldiContext:
         one operator application into a scratch column and one ``ncols``-column projection."""
         b, ws = self.basis, self.ws
         ncols = k + 1 if ncols is None else int(ncols)
+        self._need_normalised(max(k + 1, ncols), "rayleigh_column")
         self._clear_ctrl()
         y = self._scratch_col()
         self.op.apply(b.col(k), y, ws)
@@ -646,6 +700,8 @@ class ArnoldiContext:
                              "residuals of complex eigenpairs (pairs of real-packed columns) come from "
                              "residual_norms_real_pairs() / true_residuals()")
         b, ws, lib = self.basis, self.ws, _hip.load()
+        if block is self.basis:
+            self._need_normalised(j0 + len(values), "residual_norms")
         self._clear_ctrl()
         lam = torch.from_numpy(values).to(b.device).view(torch.float64)
         y = self._scratch_col()
@@ -664,6 +720,7 @@ class ArnoldiContext:
 
     def combine(self, j0, m, S, out=None):
         """``V[:, j0:j0+m] @ S`` into a new (or the given) ``DeviceColumns`` block, out of place."""
+        self._need_normalised(j0 + m, "combine")
         return dev.combine_columns(self.basis, j0, m, S, out)
 
     def gather_block(self, block):

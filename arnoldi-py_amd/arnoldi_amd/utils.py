@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import contextlib
 import os
+import threading
+import warnings
 
 import numpy as np
 import scipy.linalg
@@ -23,6 +25,27 @@ __all__ = [
 ]
 
 
+_blas_lock = threading.Lock()
+_blas_users = 0            # solves currently inside host_blas_threads(), over all host threads
+_blas_limit = None         # the one threadpool_limits object they share
+_blas_warned = False
+
+
+def _blas_thread_setting():
+    """AKS_HOST_BLAS_THREADS: "keep" -> None, a positive integer -> that limit, unset -> 1; anything else is
+    rejected here, once, with a clear message (not as an int() traceback inside every solver)."""
+    want = os.environ.get("AKS_HOST_BLAS_THREADS", "1").strip()
+    if want == "keep":
+        return None
+    try:
+        k = int(want)
+    except ValueError:
+        k = 0
+    if k < 1:
+        raise ValueError(f"AKS_HOST_BLAS_THREADS={want!r}: expected 'keep' or a positive integer")
+    return k
+
+
 @contextlib.contextmanager
 def host_blas_threads():
     """The host side of a restart is LAPACK on an ``m x m`` matrix (m <= 128: Schur form, reordering, a few
@@ -33,18 +56,40 @@ def host_blas_threads():
     with the default pools, 2.39 ms with one thread -- the whole difference sits in the wait for H or in the
     Schur call.  The solvers therefore run their loop inside this context: BLAS pools limited to ONE thread
     (threadpoolctl, restored on exit).  ``AKS_HOST_BLAS_THREADS=keep`` leaves the pools alone, an integer sets
-    another limit.  Without threadpoolctl nothing is changed."""
-    want = os.environ.get("AKS_HOST_BLAS_THREADS", "1")
-    if want == "keep":
+    another limit.
+
+    The BLAS pool is one per PROCESS while solves may run on several host threads at once (device.py keeps its
+    stream per thread), so the limit is reference-counted: the first solve to enter sets it, the last one to leave
+    restores the pools -- interleaved enters and exits can no longer leave the pool stuck at one thread
+    (ADVICE r03).  threadpoolctl is an optional dependency: without it nothing is changed and a warning says so
+    once, because small problems then run up to 2x slower on many-core hosts."""
+    global _blas_users, _blas_limit, _blas_warned
+    limit = _blas_thread_setting()
+    if limit is None:
         yield
         return
     try:
         from threadpoolctl import threadpool_limits
     except ImportError:
+        if not _blas_warned:
+            _blas_warned = True
+            warnings.warn("threadpoolctl is not installed: the host BLAS pools keep their threads inside a solve "
+                          "(up to 2x slower restarts on small problems, profiles/r03_host_gap.txt)", RuntimeWarning,
+                          stacklevel=3)
         yield
         return
-    with threadpool_limits(limits=int(want), user_api="blas"):
+    with _blas_lock:
+        if _blas_users == 0:
+            _blas_limit = threadpool_limits(limits=limit, user_api="blas")
+        _blas_users += 1
+    try:
         yield
+    finally:
+        with _blas_lock:
+            _blas_users -= 1
+            if _blas_users == 0 and _blas_limit is not None:
+                _blas_limit.restore_original_limits()
+                _blas_limit = None
 
 
 def rand_normalized_vector(n, dtype=np.float64):

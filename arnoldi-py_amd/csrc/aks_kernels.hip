@@ -169,12 +169,60 @@ __device__ __forceinline__ void transpose_reduce_step(double (&v)[KP], int lane)
     }
 }
 
+// ---- second stage of the reductions inside the producing kernel (round 4) ------------------------------------------
+// Rounds 1-3 summed the per-workgroup partial rows with a kernel of their own (k_reduce, one workgroup per column):
+// three extra launches per Arnoldi step, ~10 % of the device's busy time at the 8-GPU shard sizes (1.25M rows,
+// profiles/r03_small_trace.txt).  Now the LAST workgroup of a panel kernel to finish does it: every workgroup stores
+// its partial row write-through (sc1), drains (s_waitcnt vmcnt(0)), and one lane draws a ticket with an agent-scope
+// atomic add; the workgroup that draws gridDim.x - 1 reads all rows back with sc1 loads (they bypass its L1, which
+// no other CU's store ever refreshes) and sums them in EXACTLY k_reduce's order -- thread t takes rows t, t + 256, ...
+// in increasing order, then the wave butterfly (the transpose form below is the same balanced tree: partners differ
+// in lane bit 5, then 4, ..., and addition commutes), then the four wave totals in wave order starting from 0.0 -- so
+// H and every other number are bit for bit what the separate kernel produced.  (Hand-off form: MI355X_MICROARCH.md,
+// "Workgroup dispatch, XCD placement & inter-workgroup visibility", valid-forms table row 1: one lane's agent-scope
+// add per storing workgroup after every storing wave's drain and a workgroup barrier, the last arriver told by the
+// value its add returned, every handed-off byte stored and loaded sc1.)  The ticket words live in the control block;
+// the last arriver zeroes its word again, aks_workspace_init zeroes them all.  -DAKS_TAIL_REDUCE=0 rebuilds the
+// separate-kernel schedule for A/B runs.
+#ifndef AKS_TAIL_REDUCE
+#define AKS_TAIL_REDUCE 1
+#endif
+__device__ __forceinline__ void st_partial(c128 *p, double re, double im) {
+    double *d = reinterpret_cast<double *>(p);
+    __hip_atomic_store(d, re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // global_store_dwordx2 ... sc1
+    __hip_atomic_store(d + 1, im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ c128 ld_partial(const c128 *p) {
+    double *d = reinterpret_cast<double *>(const_cast<c128 *>(p));
+    const double re = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_load_dwordx2 ... sc1
+    const double im = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_double2(re, im);
+}
+// All threads of the workgroup call this after their partial-row stores.  True in every thread of the workgroup that
+// arrived last (all rows of `partial` written by this launch are then complete and readable with ld_partial).
+__device__ __forceinline__ bool last_block_arrives(unsigned *ticket) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // EVERY storing wave: its sc1 stores have left the CU
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old + 1u == gridDim.x;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // for the next launch
+        s_last = last;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
 // Block-wide sums of the 2 NC + 1 accumulators of the panel kernels:
 //   out[c] = (sum ar[c], sum ai[c]) for c < NC, and *nrm_out = sum nrm (if nrm_out != nullptr).
 // Fixed evaluation order => bitwise reproducible.  Must be called by all 256 threads.
-template <int NC>
+// FINAL = false: `out` is this workgroup's partial row (write-through stores, see above).  FINAL = true: the inputs are
+// sums over partial rows and `out` is the reduction slot the next stage reads (plain stores; `drop_im`: real-packed
+// panels keep Re only, as k_reduce does).
+template <int NC, bool FINAL = false>
 __device__ __forceinline__ void block_reduce_panel(const double (&ar)[NC], const double (&ai)[NC], double nrm,
-                                                   c128 *__restrict__ out, c128 *__restrict__ nrm_out) {
+                                                   c128 *__restrict__ out, c128 *__restrict__ nrm_out, bool drop_im = false) {
     constexpr int K = 2 * NC + 1;
     constexpr int ROUNDS = (K + 63) / 64;
     constexpr int KP = ROUNDS == 1 ? next_pow2(K) : 64;   // values per round
@@ -199,14 +247,39 @@ __device__ __forceinline__ void block_reduce_panel(const double (&ar)[NC], const
         double sr = 0.0, si = 0.0;
 #pragma unroll
         for (int k = 0; k < WAVES; ++k) { sr += red[k][2 * t]; si += red[k][2 * t + 1]; }
-        out[t] = make_double2(sr, si);
+        if (FINAL) out[t] = make_double2(sr, drop_im ? 0.0 : si);
+        else st_partial(&out[t], sr, si);
     }
     if (nrm_out != nullptr && t == 64) {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < WAVES; ++k) s += red[k][2 * NC];
-        *nrm_out = make_double2(s, 0.0);
+        if (FINAL) *nrm_out = make_double2(s, 0.0);
+        else st_partial(nrm_out, s, 0.0);
     }
+}
+
+// The last workgroup's part: red_out[0 .. NC] = sum over the launch's partial rows of columns 0 .. NC (NC projections
+// + the norm slot), k_reduce's order (see above).  `zero_slot` as in k_reduce.
+template <int NC>
+__device__ __forceinline__ void tail_reduce_panel(const c128 *partial, int ldp, c128 *__restrict__ red_out,
+                                                  c128 *__restrict__ zero_slot, bool real_mode) {
+    double ar[NC], ai[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ar[c] = ai[c] = 0.0;
+    double nrm = 0.0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += BLOCK) {
+        const c128 *row = partial + (int64_t)b * ldp;
+        c128 pv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) pv[c] = ld_partial(&row[c]);
+        const c128 pn = ld_partial(&row[NC]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { ar[c] += pv[c].x; ai[c] += pv[c].y; }
+        nrm += pn.x;
+    }
+    block_reduce_panel<NC, true>(ar, ai, nrm, red_out, red_out + NC, real_mode);
+    if (zero_slot != nullptr && threadIdx.x == 0) zero_slot[0] = make_double2(0.0, 0.0);
 }
 
 // Deferred normalisation (AKS_EXPAND_DEFER_SCALE).  The reference normalises a new basis vector at once
@@ -228,11 +301,14 @@ __device__ __forceinline__ bool second_pass_needed(const c128 *red1, const c128 
 // ------------------------------------------------------------------ projection
 // partial[bx*ldp + c0 + c] = sum over this block's rows of conj(V[i, c0+c]) * w[i]
 // partial[bx*ldp + nrm_slot] = sum |w[i]|^2                    (only if nrm_slot >= 0)
+// red_out != nullptr (only with c0 == 0 and nrm_slot == NC: the one launch that covers the whole panel): the last
+// workgroup to finish also sums the partial rows into red_out[0 .. NC] (see "second stage ... inside the producing kernel").
 template <int NC>
 __global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *__restrict__ V, int64_t ldv,
-                                               const c128 *__restrict__ w, c128 *__restrict__ partial,
+                                               const c128 *__restrict__ w, c128 *partial,
                                                int ldp, int nrm_slot, const aks_ctrl *__restrict__ ctrl,
-                                               const double *__restrict__ cs, int raw0) {
+                                               const double *__restrict__ cs, int raw0, c128 *__restrict__ red_out,
+                                               unsigned *ticket, c128 *__restrict__ zero_slot) {
     if (ctrl->broken) return;
     __shared__ double ssc[NC];                            // scales of this group's columns (raw columns: >= raw0)
     if (threadIdx.x < NC) ssc[threadIdx.x] = cs[c0 + threadIdx.x];
@@ -260,6 +336,8 @@ __global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *_
     }
     c128 *row = partial + (int64_t)blockIdx.x * ldp;
     block_reduce_panel<NC>(ar, ai, nrm, row + c0, nrm_slot >= 0 ? row + nrm_slot : nullptr);
+    if (red_out == nullptr) return;                        // (kernel argument: uniform over the grid)
+    if (last_block_arrives(ticket)) tail_reduce_panel<NC>(partial, ldp, red_out, zero_slot, ctrl->real_mode != 0);
 }
 
 // ------------------------------------------------------------------ fused update + re-projection
@@ -270,9 +348,10 @@ __global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *_
 template <int NC>
 __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__restrict__ V, int64_t ldv,
                                                       c128 *__restrict__ w, const c128 *__restrict__ h,
-                                                      c128 *__restrict__ partial, int ldp,
+                                                      c128 *partial, int ldp,
                                                       const aks_ctrl *__restrict__ ctrl,
-                                                      const double *__restrict__ cs, int raw0) {
+                                                      const double *__restrict__ cs, int raw0,
+                                                      c128 *__restrict__ red_out, unsigned *ticket) {
     if (ctrl->broken) return;
     __shared__ c128 hs[NC];
     __shared__ double ssc[NC];
@@ -314,6 +393,8 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__
     }
     c128 *row = partial + (int64_t)blockIdx.x * ldp;
     block_reduce_panel<NC>(ar, ai, nrm, row, row + NC);
+    if (red_out == nullptr) return;
+    if (last_block_arrives(ticket)) tail_reduce_panel<NC>(partial, ldp, red_out, nullptr, ctrl->real_mode != 0);
 }
 
 // ------------------------------------------------------------------ fused update + re-projection, wide panels
@@ -418,18 +499,88 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj_split(int64_t n, int J, c
     }
 }
 
+// ------------------------------------------------------------------ the step's book-keeping
+// h -> H[0:J, j], beta, breakdown test, counters (ortho.py:95,103,107; decomposition.py:61-65).  Called by ALL threads
+// of ONE workgroup; no barrier inside.  normalize as in k_finish (the n-sized division of mode 1 is k_finish's own).
+// `twice` / `nrm3`: whether the step ran the second pass, and ||w''||^2 if it did.
+__device__ __forceinline__ bool finish_step(int J, c128 *__restrict__ Hcol, int64_t ldh, double tol, int normalize,
+                                            const c128 *red1, const c128 *red2, bool twice, double nrm3,
+                                            aks_ctrl *ctrl, double *__restrict__ cs) {
+    const double beta = sqrt(twice ? nrm3 : red2[J].x);
+    const bool broke = beta < tol;  // ortho.py:107
+    for (int c = threadIdx.x; c < J; c += BLOCK) {
+        c128 hv = red1[c];  // ortho.py:95
+        if (twice) { hv.x += red2[c].x; hv.y += red2[c].y; }  // ortho.py:103
+        Hcol[(int64_t)c * ldh] = hv;
+    }
+    if (threadIdx.x == 0) {
+        if (!broke && normalize) Hcol[(int64_t)J * ldh] = make_double2(beta, 0.0);  // decomposition.py:65
+        if (!broke && normalize == 2) cs[J] = beta;
+        // a breakdown ends the expansion: no column from J on is a raw basis column, whatever an earlier, discarded
+        // attempt at this expansion (lazy third all-reduce) may have booked there
+        if (broke && normalize == 2)
+            for (int c = J; c < AKS_MAX_DIM + 2; ++c) cs[c] = 0.0;
+        ctrl->deferred = normalize == 2 ? 1 : 0;
+        ctrl->beta_in = sqrt(red1[J].x);
+        ctrl->beta = beta;
+        ctrl->steps_done += 1;
+        ctrl->second_passes += twice ? 1 : 0;
+        if (broke) { ctrl->n_iter = J; ctrl->broken = 1; }  // decomposition.py:61-63 (n_iter = j+1 = J)
+    }
+    return broke;
+}
+
+// What the second-pass kernels do about the step's book-keeping (it needs the LAST norm of the step, which only they
+// -- or nobody, when the DGKS test does not fire -- produce):
+//   FIN_NONE      nothing: k_finish follows (the public stage entry points; normalize == 1, whose n-sized division
+//                 is a kernel of its own anyway)
+//   FIN_ALWAYS    the step ends here: workgroup 0 books it when no second pass is needed, the last workgroup of the
+//                 second pass otherwise (one GPU, or several with the lazy third all-reduce)
+//   FIN_IF_ONCE   only when no second pass is needed; after a second pass the norm has to be summed over the ranks
+//                 first, so k_finish follows (and does nothing if the step was booked here: its `only_if_twice`)
+enum { FIN_NONE = 0, FIN_ALWAYS = 1, FIN_IF_ONCE = 2 };
+struct FinArgs {
+    c128 *Hcol;
+    int64_t ldh;
+    double tol;
+    double *cs;
+    c128 *red3;              // where the norm after the second pass goes (always written when the pass runs)
+    unsigned *ticket;        // nullptr: the block partials are summed by k_reduce<true> (no in-kernel second stage)
+    int normalize, mode;
+};
+
+// Common ending of the second-pass kernels: this workgroup's norm partial -> [last workgroup: sum, red3, book-keeping].
+__device__ __forceinline__ void second_pass_tail(double block_nrm, c128 *partial, int ldp, int nrm_slot, int J,
+                                                 const c128 *red1, const c128 *red2, aks_ctrl *ctrl, const FinArgs &fin,
+                                                 double *scratch) {
+    if (threadIdx.x == 0) st_partial(&partial[(int64_t)blockIdx.x * ldp + nrm_slot], block_nrm, 0.0);
+    if (fin.ticket == nullptr) return;
+    if (!last_block_arrives(fin.ticket)) return;
+    double sr = 0.0;                                     // k_reduce<true>'s sum: thread t takes rows t, t + 256, ...
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += BLOCK) sr += ld_partial(&partial[(int64_t)b * ldp + nrm_slot]).x;
+    sr = block_sum(sr, scratch);                         // (valid in thread 0)
+    __shared__ double s_nrm3;
+    if (threadIdx.x == 0) { s_nrm3 = sr; fin.red3[0] = make_double2(sr, 0.0); }
+    __syncthreads();
+    if (fin.mode == FIN_ALWAYS) finish_step(J, fin.Hcol, fin.ldh, fin.tol, fin.normalize, red1, red2, true, s_nrm3, ctrl, fin.cs);
+}
+
 // ------------------------------------------------------------------ update (any width)
 // w[i] -= sum_{c<J} V[i,c] h[c];  partial[bx*ldp + nrm_slot] = sum |w'[i]|^2.
 // PRED: run only if the DGKS test asks for the second pass (ortho.py:101).
 template <bool PRED>
 __global__ __launch_bounds__(BLOCK) void k_update(int64_t n, int J, const c128 *__restrict__ V, int64_t ldv,
                                                  c128 *__restrict__ w, const c128 *__restrict__ h,
-                                                 c128 *__restrict__ partial, int ldp, int nrm_slot,
-                                                 const c128 *__restrict__ red1, const c128 *__restrict__ red2,
-                                                 double eta, const aks_ctrl *__restrict__ ctrl,
-                                                 const double *__restrict__ cs, int raw0) {
+                                                 c128 *partial, int ldp, int nrm_slot,
+                                                 const c128 *red1, const c128 *red2,
+                                                 double eta, aks_ctrl *ctrl,
+                                                 const double *__restrict__ cs, int raw0, FinArgs fin) {
     if (ctrl->broken) return;
-    if (PRED && !second_pass_needed(red1, red2, J, eta)) return;
+    if (PRED && !second_pass_needed(red1, red2, J, eta)) {
+        if (fin.mode != FIN_NONE && blockIdx.x == 0)
+            finish_step(J, fin.Hcol, fin.ldh, fin.tol, fin.normalize, red1, red2, false, 0.0, ctrl, fin.cs);
+        return;
+    }
     __shared__ c128 hs[AKS_MAX_DIM + 8];
     __shared__ double ssc[AKS_MAX_DIM + 8];
     __shared__ double red_n[WAVES];
@@ -469,12 +620,68 @@ __global__ __launch_bounds__(BLOCK) void k_update(int64_t n, int J, const c128 *
         nrm = fma(wv.x, wv.x, fma(wv.y, wv.y, nrm));
     }
     const double s = block_sum(nrm, red_n);
-    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * ldp + nrm_slot] = make_double2(s, 0.0);
+    second_pass_tail(s, partial, ldp, nrm_slot, J, red1, red2, ctrl, fin, red_n);
+}
+
+// The same with the panel width as a template parameter (J <= 40): all NC column loads of a row are in flight at
+// once instead of four at a time -- the recipe of k_update_proj without its re-projection accumulators, so 4 NC
+// instead of 8 NC registers (the generic kernel ran at 5.7 - 6.1 TB/s where the projection reaches
+// 6.3 - 6.9; it is 27 - 30 % of the device time on the Laplacians, whose every step takes the second pass).  Same
+// arithmetic in the same order as k_update<true>: w comes out bit for bit the same.
+template <int NC>
+__global__ __launch_bounds__(BLOCK) void k_update_nc(int64_t n, const c128 *__restrict__ V, int64_t ldv,
+                                                    c128 *__restrict__ w, const c128 *__restrict__ h,
+                                                    c128 *partial, int ldp, int nrm_slot,
+                                                    const c128 *red1, const c128 *red2, double eta, aks_ctrl *ctrl,
+                                                    const double *__restrict__ cs, int raw0, FinArgs fin) {
+    if (ctrl->broken) return;
+    if (!second_pass_needed(red1, red2, NC, eta)) {
+        if (fin.mode != FIN_NONE && blockIdx.x == 0)
+            finish_step(NC, fin.Hcol, fin.ldh, fin.tol, fin.normalize, red1, red2, false, 0.0, ctrl, fin.cs);
+        return;
+    }
+    __shared__ c128 hs[NC];
+    __shared__ double ssc[NC];
+    __shared__ double red_n[WAVES];
+    if (threadIdx.x < NC) { hs[threadIdx.x] = h[threadIdx.x]; ssc[threadIdx.x] = cs[threadIdx.x]; }
+    __syncthreads();
+    double nrm = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        // coefficients re-read from LDS per tile above this width (as in k_update_proj; without its accumulators the
+        // kernel then needs ~4 NC + 30 registers: 4 waves per SIMD at NC = 20, 2 at NC = 40)
+#ifndef AKS_UPDNC_HS_LDS_FROM
+#define AKS_UPDNC_HS_LDS_FROM 8
+#endif
+        if constexpr (NC > AKS_UPDNC_HS_LDS_FROM) asm volatile("" ::: "memory");
+        c128 wv = w[i];
+        c128 v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = ld_panel(&V[i + (int64_t)c * ldv]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c >= raw0 && is_raw(ssc[c])) v[c] = unscale(v[c], ssc[c]);           // (wave-uniform)
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const c128 hc = hs[c];
+            sr = fma(v[c].x, hc.x, fma(-v[c].y, hc.y, sr));
+            si = fma(v[c].x, hc.y, fma(v[c].y, hc.x, si));
+        }
+        wv.x -= sr;
+        wv.y -= si;
+        w[i] = wv;
+        nrm = fma(wv.x, wv.x, fma(wv.y, wv.y, nrm));
+    }
+    const double s = block_sum(nrm, red_n);
+    second_pass_tail(s, partial, ldp, nrm_slot, NC, red1, red2, ctrl, fin, red_n);
 }
 
 // ------------------------------------------------------------------ second-stage reduction
 // out[c] = sum_b partial[b*ldp + first + c], c = blockIdx.x < count; fixed order => reproducible.
 // PRED as in k_update (skips when no second pass ran, leaving `out` untouched).
+// (Since round 4 only behind the kernels that have no in-kernel second stage: panels wider than 40 columns, and the
+// -DAKS_TAIL_REDUCE=0 build.)
 template <bool PRED>
 __global__ __launch_bounds__(BLOCK) void k_reduce(const c128 *__restrict__ partial, int n_blocks, int ldp,
                                                  int first, c128 *__restrict__ out, int J,
@@ -504,31 +711,17 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const c128 *__restrict__ parti
 __global__ __launch_bounds__(BLOCK) void k_finish(int64_t n, int J, c128 *__restrict__ w, c128 *__restrict__ Hcol,
                                                  int64_t ldh, double tol, double eta, int normalize,
                                                  const c128 *__restrict__ red1, const c128 *__restrict__ red2,
-                                                 const c128 *__restrict__ red3, aks_ctrl *__restrict__ ctrl,
-                                                 double *__restrict__ cs) {
+                                                 const c128 *__restrict__ red3, aks_ctrl *ctrl,
+                                                 double *__restrict__ cs, int only_if_twice) {
     // normalize: 0 = leave w as it is; 1 = H[J, j] = beta and w /= beta (decomposition.py:65-66); 2 = H[J, j] = beta
     // and column J stays raw with colscale[J] = beta (deferred normalisation: its readers divide)
+    // only_if_twice: a step that needed no second pass has been booked by the second-pass kernel (FIN_IF_ONCE)
     if (ctrl->broken) return;
     const bool twice = second_pass_needed(red1, red2, J, eta);
+    if (only_if_twice && !twice) return;
     const double beta = sqrt(twice ? red3[0].x : red2[J].x);
     const bool broke = beta < tol;  // ortho.py:107
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < J; c += BLOCK) {
-            c128 hv = red1[c];  // ortho.py:95
-            if (twice) { hv.x += red2[c].x; hv.y += red2[c].y; }  // ortho.py:103
-            Hcol[(int64_t)c * ldh] = hv;
-        }
-        if (threadIdx.x == 0) {
-            if (!broke && normalize) Hcol[(int64_t)J * ldh] = make_double2(beta, 0.0);  // decomposition.py:65
-            if (!broke && normalize == 2) cs[J] = beta;
-            ctrl->deferred = normalize == 2 ? 1 : 0;
-            ctrl->beta_in = sqrt(red1[J].x);
-            ctrl->beta = beta;
-            ctrl->steps_done += 1;
-            ctrl->second_passes += twice ? 1 : 0;
-            if (broke) { ctrl->n_iter = J; ctrl->broken = 1; }  // decomposition.py:61-63 (n_iter = j+1 = J)
-        }
-    }
+    if (blockIdx.x == 0) finish_step(J, Hcol, ldh, tol, normalize, red1, red2, twice, red3[0].x, ctrl, cs);
     if (broke || normalize != 1) return;
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
@@ -1122,7 +1315,9 @@ struct Ws {
     aks_ctrl *ctrl;
     c128 *red1, *red2, *red3, *partial;
     double *colscale;          // per basis column: 0 = normalised, else the column is raw and this is its divisor
+    unsigned *ticket(int i) const { return AKS_TAIL_REDUCE ? reinterpret_cast<unsigned *>(ctrl->ticket) + i : nullptr; }
 };
+enum { TICKET_PROJ = 0, TICKET_UPDATE_PROJ = 1, TICKET_UPDATE = 2 };
 
 int bind_ws(void *d_ws, int64_t ws_bytes, int64_t n_rows, int32_t max_dim, Ws *out) {
     if (d_ws == nullptr) return fail(AKS_ERR_ARG, "workspace pointer is null");
@@ -1153,13 +1348,23 @@ int check_panel(int64_t n_rows, int32_t J, const void *V, int64_t ldv, const voi
 
 template <int NC>
 void launch_proj_nc(dim3 grid, hipStream_t s, int64_t n, int c0, const c128 *V, int64_t ldv, const c128 *w,
-                    c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0, hipEvent_t ev0) {
-    launch_timed(k_proj<NC>, grid, dim3(BLOCK), 0, s, ev0, (hipEvent_t) nullptr, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0);
+                    c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0, hipEvent_t ev0,
+                    c128 *red_out, unsigned *ticket, c128 *zero_slot) {
+    launch_timed(k_proj<NC>, grid, dim3(BLOCK), 0, s, ev0, (hipEvent_t) nullptr, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0,
+                 red_out, ticket, zero_slot);
 }
 template <int NC>
 void launch_update_proj_nc(dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
-                           const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0) {
-    hipLaunchKernelGGL(k_update_proj<NC>, grid, dim3(BLOCK), 0, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0);
+                           const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0,
+                           c128 *red_out, unsigned *ticket) {
+    hipLaunchKernelGGL(k_update_proj<NC>, grid, dim3(BLOCK), 0, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0, red_out, ticket);
+}
+template <int NC>
+void launch_update_nc(dim3 grid, hipStream_t s, hipEvent_t ev1, int64_t n, const c128 *V, int64_t ldv, c128 *w, const c128 *h,
+                      c128 *partial, int ldp, const c128 *red1, const c128 *red2, double eta, aks_ctrl *ctrl,
+                      const double *cs, int raw0, FinArgs fin) {
+    launch_timed(k_update_nc<NC>, grid, dim3(BLOCK), 0, s, (hipEvent_t) nullptr, ev1, n, V, ldv, w, h, partial, ldp, 0, red1, red2, eta,
+                 ctrl, cs, raw0, fin);
 }
 
 #define AKS_NC_CASES(M) \
@@ -1168,9 +1373,9 @@ void launch_update_proj_nc(dim3 grid, hipStream_t s, int64_t n, const c128 *V, i
 
 void dispatch_proj(int nc, dim3 grid, hipStream_t s, int64_t n, int c0, const c128 *V, int64_t ldv,
                    const c128 *w, c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0,
-                   hipEvent_t ev0) {
+                   hipEvent_t ev0, c128 *red_out, unsigned *ticket, c128 *zero_slot) {
     switch (nc) {
-#define M(N) case N: launch_proj_nc<N>(grid, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0, ev0); break;
+#define M(N) case N: launch_proj_nc<N>(grid, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0, ev0, red_out, ticket, zero_slot); break;
         AKS_NC_CASES(M)
 #if AKS_NC_MAX > 32
         M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40)
@@ -1188,9 +1393,22 @@ constexpr int FUSED_EXACT_MAX = AKS_FUSED_EXACT_MAX;
 
 #define AKS_NC_CASES_WIDE(M) M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40)
 void dispatch_update_proj(int nc, dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
-                          const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0) {
+                          const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0,
+                          c128 *red_out, unsigned *ticket) {
     switch (nc) {
-#define M(N) case N: launch_update_proj_nc<N>(grid, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0); break;
+#define M(N) case N: launch_update_proj_nc<N>(grid, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0, red_out, ticket); break;
+        AKS_NC_CASES(M)
+        AKS_NC_CASES_WIDE(M)
+#undef M
+        default: break;
+    }
+}
+
+void dispatch_update_nc(int nc, dim3 grid, hipStream_t s, hipEvent_t ev1, int64_t n, const c128 *V, int64_t ldv, c128 *w,
+                        const c128 *h, c128 *partial, int ldp, const c128 *red1, const c128 *red2, double eta,
+                        aks_ctrl *ctrl, const double *cs, int raw0, const FinArgs &fin) {
+    switch (nc) {
+#define M(N) case N: launch_update_nc<N>(grid, s, ev1, n, V, ldv, w, h, partial, ldp, red1, red2, eta, ctrl, cs, raw0, fin); break;
         AKS_NC_CASES(M)
         AKS_NC_CASES_WIDE(M)
 #undef M
@@ -1241,15 +1459,18 @@ void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c12
     const int base = J / groups, extra = J % groups;
     const int n_blocks = panel_blocks(ws, base);          // (every group writes the same rows of `partial`)
     const dim3 grid(n_blocks);
+    // one launch covers the panel (J <= 40): its last workgroup sums the partial rows itself; several groups: k_reduce
+    unsigned *ticket = groups == 1 ? ws.ticket(TICKET_PROJ) : nullptr;
     int c0 = 0;
     for (int g = 0; g < groups; ++g) {
         const int nc = base + (g < extra ? 1 : 0);
         dispatch_proj(nc, grid, s, n, c0, V, ldv, w, ws.partial, ws.lay.ld_partial, g == 0 ? J : -1, ws.ctrl, ws.colscale, raw0,
-                      g == 0 ? ev0 : nullptr);
+                      g == 0 ? ev0 : nullptr, ticket ? red_out : nullptr, ticket, zero_slot);
         c0 += nc;
     }
-    hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
-                       ws.lay.ld_partial, 0, red_out, J, nullptr, nullptr, 0.0, zero_slot, ws.ctrl);
+    if (ticket == nullptr)
+        hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
+                           ws.lay.ld_partial, 0, red_out, J, nullptr, nullptr, 0.0, zero_slot, ws.ctrl);
 }
 
 // Dynamic LDS above the default limit has to be allowed per kernel AND per device: aks_device_init does that for
@@ -1629,20 +1850,26 @@ static int gs_update_project_(int64_t n_rows, int32_t J, const aks_c128 *d_V, in
 #endif
     const bool exact = J <= exact_max && J <= 40 && !(AKS_FUSED_SPLIT_LOW && J >= 5 && J <= 12);
     const int n_blocks = exact ? panel_blocks(ws, J) : ws.lay.n_blocks;
+    unsigned *ticket = exact ? ws.ticket(TICKET_UPDATE_PROJ) : nullptr;      // the exact-width kernel sums its own partial rows
     if (exact)
         dispatch_update_proj(J, dim3(n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
-                             ws.lay.ld_partial, ws.ctrl, ws.colscale, raw0);
+                             ws.lay.ld_partial, ws.ctrl, ws.colscale, raw0, ticket ? ws.red2 : nullptr, ticket);
     else
         dispatch_update_proj_split(J, dim3(n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
                                    ws.lay.ld_partial, ws.ctrl, ws.colscale, raw0);
-    hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
-                       ws.lay.ld_partial, 0, ws.red2, J, nullptr, nullptr, 0.0, nullptr, ws.ctrl);
+    if (ticket == nullptr)
+        hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
+                           ws.lay.ld_partial, 0, ws.red2, J, nullptr, nullptr, 0.0, nullptr, ws.ctrl);
     AKS_CHECK_LAUNCH("aks_gs_update_project");
     return AKS_OK;
 }
 
+// Second pass + the norm behind it.  `fin_mode` / Hcol ... normalize: what the kernel does about the step's
+// book-keeping (FIN_* above); ev1: the probe's stop event when this is the step's last launch.
 static int gs_update_norm_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv, aks_c128 *d_w, double eta,
-                           void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream, int raw0) {
+                           void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream, int raw0,
+                           int fin_mode = FIN_NONE, aks_c128 *d_Hcol = nullptr, int64_t ldh = 0, double tol = 0.0,
+                           int32_t normalize = 0, hipEvent_t ev1 = nullptr) {
     int rc = check_panel(n_rows, J, d_V, ldv, d_w, max_dim);
     if (rc != AKS_OK) return rc;
     Ws ws;
@@ -1656,11 +1883,29 @@ static int gs_update_norm_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64
 #else
     const int n_blocks = panel_blocks(ws, 4, 2);
 #endif
-    hipLaunchKernelGGL(k_update<true>, dim3(n_blocks), dim3(BLOCK), 0, s, n_rows, J,
-                       reinterpret_cast<const c128 *>(d_V), ldv, reinterpret_cast<c128 *>(d_w), ws.red2,
-                       ws.partial, ws.lay.ld_partial, 0, ws.red1, ws.red2, eta, ws.ctrl, ws.colscale, raw0);
-    hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
-                       ws.lay.ld_partial, 0, ws.red3, J, ws.red1, ws.red2, eta, nullptr, ws.ctrl);
+    FinArgs fin;
+    fin.Hcol = reinterpret_cast<c128 *>(d_Hcol);
+    fin.ldh = ldh;
+    fin.tol = tol;
+    fin.cs = ws.colscale;
+    fin.red3 = ws.red3;
+    fin.ticket = ws.ticket(TICKET_UPDATE);
+    fin.normalize = normalize;
+    fin.mode = fin.ticket != nullptr ? fin_mode : FIN_NONE;       // (book-keeping in the kernel needs its own norm sum)
+    const c128 *V = reinterpret_cast<const c128 *>(d_V);
+    c128 *w = reinterpret_cast<c128 *>(d_w);
+#ifndef AKS_UPDATE_EXACT_MAX
+#define AKS_UPDATE_EXACT_MAX 40       // widest exact-width second-pass kernel (0: the generic kernel at every width)
+#endif
+    if (J <= AKS_UPDATE_EXACT_MAX && J <= 40)
+        dispatch_update_nc(J, dim3(n_blocks), s, ev1, n_rows, V, ldv, w, ws.red2, ws.partial, ws.lay.ld_partial, ws.red1, ws.red2,
+                           eta, ws.ctrl, ws.colscale, raw0, fin);
+    else
+        launch_timed(k_update<true>, dim3(n_blocks), dim3(BLOCK), 0, s, (hipEvent_t) nullptr, ev1, n_rows, (int)J, V, ldv, w, ws.red2,
+                     ws.partial, ws.lay.ld_partial, 0, ws.red1, ws.red2, eta, ws.ctrl, ws.colscale, raw0, fin);
+    if (fin.ticket == nullptr)
+        hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
+                           ws.lay.ld_partial, 0, ws.red3, J, ws.red1, ws.red2, eta, nullptr, ws.ctrl);
     AKS_CHECK_LAUNCH("aks_gs_update_norm");
     return AKS_OK;
 }
@@ -1682,7 +1927,7 @@ int aks_gs_update_norm(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t l
 
 static int gs_finish_(int64_t n_rows, int32_t J, aks_c128 *d_w, aks_c128 *d_Hcol, int64_t ldh, double tol,
                       double eta, int32_t normalize, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream,
-                      hipEvent_t ev1) {
+                      hipEvent_t ev1, int only_if_twice = 0) {
     if (d_w == nullptr || d_Hcol == nullptr) return fail(AKS_ERR_ARG, "null pointer");
     if (J < 1 || J > max_dim) return fail(AKS_ERR_ARG, "J must satisfy 1 <= J <= max_dim");
     if (ldh < 1) return fail(AKS_ERR_ARG, "ldh must be positive");
@@ -1693,7 +1938,7 @@ static int gs_finish_(int64_t n_rows, int32_t J, aks_c128 *d_w, aks_c128 *d_Hcol
     // (deferred normalisation: nothing of length n to do -- one block books H, beta and the column's scale)
     launch_timed(k_finish, dim3(normalize == 1 ? ws.lay.n_blocks : 1), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
                  (hipEvent_t) nullptr, ev1, n_rows, J, reinterpret_cast<c128 *>(d_w), reinterpret_cast<c128 *>(d_Hcol), ldh, tol, eta,
-                 (int)normalize, ws.red1, ws.red2, ws.red3, ws.ctrl, ws.colscale);
+                 (int)normalize, ws.red1, ws.red2, ws.red3, ws.ctrl, ws.colscale, only_if_twice);
     AKS_CHECK_LAUNCH("k_finish");
     return AKS_OK;
 }
@@ -1710,8 +1955,12 @@ static int dgks_gs_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv,
     if (rc != AKS_OK) return rc;
     rc = gs_update_project_(n_rows, J, d_V, ldv, d_w, d_ws, ws_bytes, max_dim, stream, raw0);
     if (rc != AKS_OK) return rc;
-    rc = gs_update_norm_(n_rows, J, d_V, ldv, d_w, eta, d_ws, ws_bytes, max_dim, stream, raw0);
-    if (rc != AKS_OK) return rc;
+    // normalize != 1: nothing of length n is left to do after the second pass, so the kernel that produces (or skips)
+    // it books the step -- H column, beta, breakdown, counters -- and k_finish is not launched at all
+    const bool fold = AKS_TAIL_REDUCE && normalize != 1;
+    rc = gs_update_norm_(n_rows, J, d_V, ldv, d_w, eta, d_ws, ws_bytes, max_dim, stream, raw0,
+                         fold ? FIN_ALWAYS : FIN_NONE, d_Hcol, ldh, tol, normalize, fold ? ev.stop : nullptr);
+    if (rc != AKS_OK || fold) return rc;
     return gs_finish_(n_rows, J, d_w, d_Hcol, ldh, tol, eta, normalize, d_ws, ws_bytes, max_dim, stream, ev.stop);
 }
 
@@ -2177,9 +2426,19 @@ int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 
             if (rc == AKS_OK) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red1), 2 * (J + 1), stream);
             if (rc == AKS_OK) rc = gs_update_project_(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream, raw0);
             if (rc == AKS_OK) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red2), 2 * (J + 1), stream);
-            if (rc == AKS_OK) rc = gs_update_norm_(n_panel, J, d_V, ldv, w, eta, d_ws, ws_bytes, max_dim, stream, raw0);
+            // the step's book-keeping rides on the second-pass kernel when no n-sized normalisation follows: always with
+            // the lazy third all-reduce (a step that does take the second pass makes the caller repeat the expansion
+            // anyway), otherwise only for the steps that need no second pass -- after one, the norm is summed over the
+            // ranks first and k_finish books the step
+            const bool fold = AKS_TAIL_REDUCE && norm_mode != 1;
+            const int fin_mode = !fold ? FIN_NONE : (lazy_third ? FIN_ALWAYS : FIN_IF_ONCE);
+            const bool last = fin_mode == FIN_ALWAYS;
+            if (rc == AKS_OK) rc = gs_update_norm_(n_panel, J, d_V, ldv, w, eta, d_ws, ws_bytes, max_dim, stream, raw0, fin_mode,
+                                                   d_H + j, ldh, tol, norm_mode, last ? eo.stop : nullptr);
             if (rc == AKS_OK && !lazy_third) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red3), 2, stream);
-            if (rc == AKS_OK) rc = gs_finish_(n_panel, J, w, d_H + j, ldh, tol, eta, norm_mode, d_ws, ws_bytes, max_dim, stream, eo.stop);
+            if (rc == AKS_OK && !last)
+                rc = gs_finish_(n_panel, J, w, d_H + j, ldh, tol, eta, norm_mode, d_ws, ws_bytes, max_dim, stream, eo.stop,
+                                fin_mode == FIN_IF_ONCE ? 1 : 0);
         }
         if (rc != AKS_OK) return rc;
     }

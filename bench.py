@@ -32,6 +32,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -44,6 +45,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CONFIG_OF = {"random": 5, "laplace2d": 2, "laplace3d": 4, "markov": 1, "banded": 3, "file": 3}   # BASELINE.json configs[] (1-based)
 _FILE_MATRIX = {}   # --matrix: path -> CSR, loaded once per process
+_RNG_LOCK = threading.Lock()   # numpy's global RNG (the reference's start-vector stream) is one per process
 GPU = None     # torch.cuda.is_available(), set by run_rank: the device-timing objects need a GPU (the product
                # itself refuses to run without one; tests/bench_rehearsal.py drives the launcher / rank logic on CPU)
 
@@ -77,6 +79,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-real-leg", action="store_true",
                     help="skip the extra measurement of partial_schur(arithmetic='real') on the same matrix")
     ap.add_argument("--no-workloads", action="store_true", help="skip the Markov / Laplace legs")
+    ap.add_argument("--leg-rows", type=int, default=None,
+                    help="(N > 1) matrix dimension of the sharded Markov / 3-D Laplace / real-packed legs instead of their "
+                         "BASELINE sizes (rehearsals)")
     ap.add_argument("--chained", action="store_true",
                     help="force the Python-chained stage path on one GPU (the multi-GPU code path)")
     ap.add_argument("--arithmetic", choices=["complex", "real"], default="complex",
@@ -191,12 +196,14 @@ def build_rows(args, r0, r1, n, dims):
     return rows
 
 
-def ortho_algorithmic_bytes(n_local, J, second):
+def ortho_algorithmic_bytes(n_local, J, second, deferred=False):
     """Bytes the fused Gram-Schmidt schedule must move for one step at panel width J:
     panel reads (projection, update+re-projection, second update if run) and the w traffic
-    of each stage (fused figure)."""
+    of each stage (fused figure).  ``deferred``: the expansion left its new columns raw
+    (deferred normalisation), so the ``w /= beta`` pass (one read + one write of w) does not exist and
+    is not counted -- a fraction must not be quoted against bytes the kernels never have to move."""
     panel = 16 * n_local * J * (3 if second else 2)
-    w = 16 * n_local * (1 + 2 + (2 if second else 0) + 2)
+    w = 16 * n_local * (1 + 2 + (2 if second else 0) + (0 if deferred else 2))
     return panel + w
 
 
@@ -307,14 +314,16 @@ def _measure(args, comm, world, rank):
     """Build the operator for args.workload, run warmup + steps restarts, return (dict, context for extras)."""
     import torch
     from arnoldi_amd import _hip
-    from arnoldi_amd.dist import row_offsets
+    from arnoldi_amd.dist import row_offsets, slab_offsets
     from arnoldi_amd.engine import CsrOperator
     from arnoldi_amd.krylov_schur import KrylovSchurSolver
-    from arnoldi_amd.utils import arg_largest_magnitude, arg_largest_real
+    from arnoldi_amd.utils import arg_largest_magnitude, arg_largest_real, rand_normalized_vector
 
     real = args.arithmetic == "real"
     n, dims = problem_size(args)
-    offsets = row_offsets(n, world)
+    # grids are cut into slabs of whole planes / lines along their last dimension (SURVEY 8(e): "Laplace: z-slabs":
+    # one plane to exchange with each neighbour), everything else into equal row blocks
+    offsets = slab_offsets(dims, world) if args.workload in ("laplace2d", "laplace3d") else row_offsets(n, world)
     r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
     t_setup = time.perf_counter()
     rows = build_rows(args, r0, r1, n, dims)
@@ -324,14 +333,17 @@ def _measure(args, comm, world, rank):
 
     nev, m = args.nev, args.max_dim
     p = min(nev + 5, m - 1)
-    np.random.seed(0)
+    with _RNG_LOCK:                                    # the reference's start vector: np.random.seed(0), randn(n)
+        np.random.seed(0)
+        v0 = rand_normalized_vector(n, np.float64 if real else np.complex128)
     sort_key = arg_largest_real if args.workload == "markov" else arg_largest_magnitude
     if real:
         from arnoldi_amd.krylov_schur_real import RealKrylovSchurSolver
 
-        solver = RealKrylovSchurSolver(op, nev, m, p, 1e-8, sort_key, comm=comm)
+        solver = RealKrylovSchurSolver(op, nev, m, p, 1e-8, sort_key, comm=comm, v0=v0)
     else:
-        solver = KrylovSchurSolver(op, nev, m, p, 1e-8, sort_key, comm=comm)
+        solver = KrylovSchurSolver(op, nev, m, p, 1e-8, sort_key, comm=comm, v0=v0)
+    del v0
     ctx = solver.ctx
     if args.chained:
         ctx.force_chained = True
@@ -350,6 +362,7 @@ def _measure(args, comm, world, rank):
     if GPU:
         torch.cuda.synchronize()
     initial_ms = (time.perf_counter() - t0) * 1e3
+    deferred_initial = ctx.deferred_expansions > 0          # did the m-step expansion leave its columns raw?
 
     for i in range(args.warmup):
         solver.contract(i)
@@ -363,7 +376,13 @@ def _measure(args, comm, world, rank):
         ctx.spmv_events = []
     second0 = int(ctx.last_ctrl.second_passes) - ctx.discarded_second_passes      # (an expansion that had to be
     steps0 = int(ctx.last_ctrl.steps_done) - ctx.discarded_steps                  # repeated is counted once)
+    deferred0 = ctx.deferred_expansions
 
+    # one mode for the whole timed region: a probed restart launches kernel by kernel (an event pair per kernel group),
+    # so the un-probed restarts of --probe-every K > 1 must not replay a hipGraph in between
+    graph_was = ctx.use_graph
+    if probe is not None:
+        ctx.use_graph = False
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -373,13 +392,10 @@ def _measure(args, comm, world, rank):
         solver.expand()
     sync()
     elapsed = time.perf_counter() - t0
+    ctx.use_graph = graph_was
 
     if comm is not None:
-        import torch.distributed as dist
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if comm.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = comm.max_float(elapsed)              # the slowest rank's clock
 
     # ---- per-kernel device time measured inside the timed region --------------------------
     if probe is not None:
@@ -396,12 +412,14 @@ def _measure(args, comm, world, rank):
     steps_done = int(ctx.last_ctrl.steps_done) - ctx.discarded_steps - steps0
     seconds = int(ctx.last_ctrl.second_passes) - ctx.discarded_second_passes - second0
     frac_second = seconds / max(steps_done, 1)
+    # the timed re-expansions either all deferred their normalisations or none did (same shape every restart)
+    deferred = (ctx.deferred_expansions - deferred0) >= args.steps
     n_panel = ctx.basis.n_rows                      # rows of the panel the Gram-Schmidt kernels see
     per_cycle = 0.0   # Gram-Schmidt bytes of one restart's steps, at the measured second-pass rate
     widths = range(p + 1, m + 1)
     for J in widths:
-        per_cycle += (frac_second * ortho_algorithmic_bytes(n_panel, J, True)
-                      + (1 - frac_second) * ortho_algorithmic_bytes(n_panel, J, False))
+        per_cycle += (frac_second * ortho_algorithmic_bytes(n_panel, J, True, deferred)
+                      + (1 - frac_second) * ortho_algorithmic_bytes(n_panel, J, False, deferred))
     ortho = None
     if n_ortho:
         total = per_cycle * n_ortho / max(len(widths), 1)
@@ -409,7 +427,8 @@ def _measure(args, comm, world, rank):
         ortho = {"bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(a / HBM_PEAK_GBS, 4), "launch_groups": n_ortho,
                  "avg_ms_per_step": round(ortho_ms / n_ortho, 4),
-                 "second_pass_fraction": round(frac_second, 3), "traffic": None}
+                 "second_pass_fraction": round(frac_second, 3), "normalisation_deferred": bool(deferred),
+                 "traffic": None}
 
     # Small problems (kernels of 20-60 us) follow the host's launch latency: the same restarts again with the
     # re-expansion replayed as a hipGraph (AKS_GRAPH=1 of the product: one launch per restart), no probe.
@@ -457,6 +476,7 @@ def _measure(args, comm, world, rank):
         "spmv_tune_mode": getattr(op.diag, "tune_mode", None),
         "spmv_bytes": spmv_bytes, "spmv_avg_ms": spmv_avg_ms, "n_spmv": n_spmv, "achieved": achieved,
         "ortho": ortho, "frac_second": frac_second, "per_cycle": per_cycle, "n_panel": n_panel,
+        "deferred": bool(deferred), "deferred_initial": bool(deferred_initial),
         "n_local": op.n_local, "exchange": exchange,
         "levels_per_round": getattr(getattr(op.diag, "binned", None), "levels_per_round", None),
         "lanes_per_wave_load": getattr(getattr(op.diag, "binned", None), "lanes_per_load", None),
@@ -525,10 +545,13 @@ def pmc_ortho_traffic(res, args, world=1):
             return None, None, f"profiles/{name}: {steps} steps are not an initial expansion plus whole re-expansions"
         re_exp = (steps - m) // (m - p)
 
-        def alg(J):
-            return fs * ortho_algorithmic_bytes(n_panel, J, True) + (1 - fs) * ortho_algorithmic_bytes(n_panel, J, False)
+        def alg(J, deferred):
+            return (fs * ortho_algorithmic_bytes(n_panel, J, True, deferred)
+                    + (1 - fs) * ortho_algorithmic_bytes(n_panel, J, False, deferred))
 
-        expected = sum(alg(J) for J in range(1, m + 1)) + re_exp * sum(alg(J) for J in range(p + 1, m + 1))
+        # (the profiled command is this command: its initial expansion and its re-expansions defer as this run's did)
+        expected = (sum(alg(J, res["deferred_initial"]) for J in range(1, m + 1))
+                    + re_exp * sum(alg(J, res["deferred"]) for J in range(p + 1, m + 1)))
         counted = sum(pmc[f]["launches"] * pmc[f]["hbm_bytes_per_launch_fetch_x2"] for f in GS_FAMILIES if f in pmc)
         ratio = counted / expected
         per_step = res["per_cycle"] / max(m - p, 1)
@@ -540,9 +563,9 @@ def pmc_ortho_traffic(res, args, world=1):
         return None, None, f"pmc summary unreadable: {e}"
 
 
-def leg_summary(res, args):
-    """What an extra leg (child process) reports back."""
-    traffic, note = pmc_traffic(res, args)
+def leg_summary(res, args, world=1):
+    """What an extra leg reports back (a child process on one GPU; the ranks themselves for N > 1)."""
+    traffic, note = pmc_traffic(res, args, world)
     out = {"spmv_traffic_bytes": traffic, "spmv_traffic_source": note, "restarts_per_s": res["value"], "ms_per_step": res["ms_per_step"], "n": res["n"], "nnz": res["nnz_local"],
            "nev": res["nev"], "max_dim": res["m"], "spmv_form": res["spmv_form"],
            "spmv_avg_ms": round(res["spmv_avg_ms"], 4), "spmv_algorithmic_bytes": res["spmv_bytes"],
@@ -551,7 +574,7 @@ def leg_summary(res, args):
            "ortho_achieved_GBs": res["ortho"]["achieved"] if res["ortho"] else None,
            "ortho_frac": res["ortho"]["frac"] if res["ortho"] else None,
            "second_pass_fraction": round(res["frac_second"], 3), "setup_s": round(res["setup_s"], 2)}
-    o_traffic, o_ratio, _ = pmc_ortho_traffic(res, args)
+    o_traffic, o_ratio, _ = pmc_ortho_traffic(res, args, world)
     if o_traffic is not None:
         out["ortho_traffic_bytes_per_step"], out["ortho_traffic_over_algorithmic"] = o_traffic, o_ratio
     if res["graph_rate"] is not None:
@@ -694,6 +717,117 @@ def emit(line):
 _REAL_STDOUT = 1
 
 
+def headline(res, args, world, comm_forced=False, preflight=None):
+    """The JSON object of the headline measurement (what rank 0 prints), from ``measure``'s result."""
+    n, m, p, nev = res["n"], res["m"], res["p"], res["nev"]
+    traffic, traffic_note = pmc_traffic(res, args, world)
+    achieved, spmv_bytes = res["achieved"], res["spmv_bytes"]
+    out = {
+        "metric": "krylov_restarts_per_sec",
+        "value": res["value"],
+        "unit": "restarts/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "complex128" if args.arithmetic == "complex" else "float64",
+        "data": "synthetic" if args.matrix is None else f"file {os.path.basename(args.matrix)}",
+        "config": {
+            "workload": ((f"{os.path.basename(args.matrix)}" if args.matrix else f"{args.workload} CSR")
+                         + f" n={n} nnz={res['nnz_local'] if world == 1 else 'sharded'} "
+                         f"(BASELINE config {CONFIG_OF[args.workload]} shape), "
+                         f"partial_schur k={nev} max_dim={m} p={p}, "
+                         f"1 step = 1 Krylov-Schur restart ({m - p} Arnoldi steps + host Schur + truncation)"),
+            "n": n, "nnz_rank0": res["nnz_local"], "nev": nev, "max_dim": m, "p": p,
+            "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
+            "path": (("aks_arnoldi_expand: one C call per expansion"
+                      + (", RCCL all-reduces and ghost exchange issued from C" if res["exchange"] or comm_forced else ""))
+                     if res["native"] else "python-chained stages + torch.distributed collectives"),
+            "exchange": res["exchange"],
+            "native_preflight": preflight,
+        },
+        "initial_expand_ms": round(res["initial_ms"], 2),
+        "setup_s": round(res["setup_s"], 2),
+        "arnoldi_steps_timed": res["steps_done"],
+        "roofline": {
+            "kernel": spmv_kernel_name(res, world),
+            "spmv_form": res["spmv_form"],
+            "spmv_form_chosen_by": res["spmv_tune_mode"],
+            "spmv_autotune_ms": res["spmv_tune_ms"],
+            "bound": "hbm",
+            "achieved": round(achieved, 1) if achieved else None,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+            "traffic": traffic,
+            "traffic_source": traffic_note,
+            "algorithmic_bytes_per_launch": spmv_bytes,
+            "avg_launch_ms": round(res["spmv_avg_ms"], 4),
+            "launches": res["n_spmv"],
+        },
+        "roofline_ortho": res["ortho"],
+    }
+    if res["ortho"]:
+        o_traffic, o_ratio, o_note = pmc_ortho_traffic(res, args, world)
+        res["ortho"].update(traffic=o_traffic, traffic_over_algorithmic=o_ratio, traffic_source=o_note,
+                            algorithmic_bytes_per_step=int(res["per_cycle"] / max(m - p, 1)))
+    n_loc, per_cycle, elapsed = res["n_panel"], res["per_cycle"], res["elapsed"]
+    rr = {"algorithmic_GB_per_restart": round(((m - p) * spmv_bytes + per_cycle + 16 * n_loc * (m + p) + 32 * n_loc) / 1e9, 2),
+          "second_pass_fraction": round(res["frac_second"], 3)}
+    rr["achieved_GBs"] = round(rr["algorithmic_GB_per_restart"] * world / (elapsed / args.steps), 1)
+    rr["frac_of_peak"] = round(rr["achieved_GBs"] / (HBM_PEAK_GBS * world), 4)
+    # SURVEY 8(d)'s own per-restart figure (three panel reads per step whether or not the second pass
+    # runs): (m-p) B_spmv + 16 n 3 S(m,p) + B_tr, with S = sum of the panel widths J = p+1 .. m
+    S = sum(range(p + 1, m + 1))
+    survey_bytes = (m - p) * spmv_bytes + 16 * n_loc * 3 * S + 16 * n_loc * (m + p) + 32 * n_loc
+    rr["survey_fused_GB_per_restart"] = round(survey_bytes / 1e9, 2)
+    rr["survey_fused_frac_of_peak"] = round(survey_bytes * world / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)
+    out["restart_roofline"] = rr
+    return out
+
+
+def sharded_legs(args, comm, world, rank, log=None):
+    """N > 1: north_star asks for restarts/s "on synthetic Markov/Laplace CSR at 1/2/4/8 GPUs", and
+    the headline's uniformly random matrix is the one workload whose ghost exchange cannot shrink with N.  After the
+    headline, in the SAME rank processes: the Markov chain (n = 10M, a few grid lines of ghosts), the 3-D Laplacian of
+    BASELINE config 4 (n = 16M, z-slabs: one plane per neighbour) and the headline matrix in real-packed arithmetic
+    (half the exchange volume) -- each with its exchange block and per-SpMV split.  ``--leg-rows R`` shrinks all three
+    (rehearsals).  Collective: every rank runs every leg; a leg that fails on one rank fails on all (same inputs)."""
+    import copy
+    import gc
+
+    import torch
+
+    legs = []
+    small = args.leg_rows
+    specs = (("markov", dict(workload="markov", n=small or 10_000_000, nev=5, max_dim=20, arithmetic="complex")),
+             ("laplace3d", dict(workload="laplace3d", n=small or 16_000_000, nev=10, max_dim=40, arithmetic="complex")),
+             ("random_real_packed", dict(workload="random", n=small or args.n, nev=args.nev, max_dim=args.max_dim,
+                                         per_row=args.per_row, arithmetic="real")))
+    for name, over in specs:
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.steps, a.warmup = min(args.steps, 5), 2
+        gc.collect()
+        if GPU:
+            torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        res = measure(a, comm, world, rank)
+        leg = leg_summary(res, a, world)
+        leg.update(name=name, n_gpus=world, exchange=res["exchange"], wall_s=round(time.perf_counter() - t0, 1),
+                   dtype="float64 (real-packed)" if over["arithmetic"] == "real" else "complex128",
+                   path="C-driven (aks_arnoldi_expand)" if res["native"] else "python-chained")
+        if log is not None:
+            log(f"leg {name}: {leg['restarts_per_s']} restarts/s")
+        legs.append(leg)
+        del res
+    return legs
+
+
 def run_rank(args, argv):
     global _REAL_STDOUT
     sys.stdout.flush()
@@ -753,75 +887,13 @@ def run_rank(args, argv):
         emit(json.dumps(leg_summary(res, args)))
         return 0
 
-    out = None
-    if rank == 0:
-        n, m, p, nev = res["n"], res["m"], res["p"], res["nev"]
-        traffic, traffic_note = pmc_traffic(res, args, world)
-        achieved, spmv_bytes = res["achieved"], res["spmv_bytes"]
-        out = {
-            "metric": "krylov_restarts_per_sec",
-            "value": res["value"],
-            "unit": "restarts/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": res["ms_per_step"],
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "complex128" if args.arithmetic == "complex" else "float64",
-            "data": "synthetic" if args.matrix is None else f"file {os.path.basename(args.matrix)}",
-            "config": {
-                "workload": ((f"{os.path.basename(args.matrix)}" if args.matrix else f"{args.workload} CSR")
-                             + f" n={n} nnz={res['nnz_local'] if world == 1 else 'sharded'} "
-                             f"(BASELINE config {CONFIG_OF[args.workload]} shape), "
-                             f"partial_schur k={nev} max_dim={m} p={p}, "
-                             f"1 step = 1 Krylov-Schur restart ({m - p} Arnoldi steps + host Schur + truncation)"),
-                "n": n, "nnz_rank0": res["nnz_local"], "nev": nev, "max_dim": m, "p": p,
-                "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
-                "path": (("aks_arnoldi_expand: one C call per expansion"
-                          + (", RCCL all-reduces and ghost exchange issued from C" if res["exchange"] or comm_forced else ""))
-                         if res["native"] else "python-chained stages + torch.distributed collectives"),
-                "exchange": res["exchange"],
-                "native_preflight": preflight,
-            },
-            "initial_expand_ms": round(res["initial_ms"], 2),
-            "setup_s": round(res["setup_s"], 2),
-            "arnoldi_steps_timed": res["steps_done"],
-            "roofline": {
-                "kernel": spmv_kernel_name(res, world),
-                "spmv_form": res["spmv_form"],
-                "spmv_form_chosen_by": res["spmv_tune_mode"],
-                "spmv_autotune_ms": res["spmv_tune_ms"],
-                "bound": "hbm",
-                "achieved": round(achieved, 1) if achieved else None,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                "traffic": traffic,
-                "traffic_source": traffic_note,
-                "algorithmic_bytes_per_launch": spmv_bytes,
-                "avg_launch_ms": round(res["spmv_avg_ms"], 4),
-                "launches": res["n_spmv"],
-            },
-            "roofline_ortho": res["ortho"],
-        }
-        if res["ortho"]:
-            o_traffic, o_ratio, o_note = pmc_ortho_traffic(res, args, world)
-            res["ortho"].update(traffic=o_traffic, traffic_over_algorithmic=o_ratio, traffic_source=o_note,
-                                algorithmic_bytes_per_step=int(res["per_cycle"] / max(m - p, 1)))
-        n_loc, per_cycle, elapsed = res["n_panel"], res["per_cycle"], res["elapsed"]
-        rr = {"algorithmic_GB_per_restart": round(((m - p) * spmv_bytes + per_cycle + 16 * n_loc * (m + p) + 32 * n_loc) / 1e9, 2),
-              "second_pass_fraction": round(res["frac_second"], 3)}
-        rr["achieved_GBs"] = round(rr["algorithmic_GB_per_restart"] * world / (elapsed / args.steps), 1)
-        rr["frac_of_peak"] = round(rr["achieved_GBs"] / (HBM_PEAK_GBS * world), 4)
-        # SURVEY 8(d)'s own per-restart figure (three panel reads per step whether or not the second pass
-        # runs): (m-p) B_spmv + 16 n 3 S(m,p) + B_tr, with S = sum of the panel widths J = p+1 .. m
-        S = sum(range(p + 1, m + 1))
-        survey_bytes = (m - p) * spmv_bytes + 16 * n_loc * 3 * S + 16 * n_loc * (m + p) + 32 * n_loc
-        rr["survey_fused_GB_per_restart"] = round(survey_bytes / 1e9, 2)
-        rr["survey_fused_frac_of_peak"] = round(survey_bytes * world / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)
-        out["restart_roofline"] = rr
+    out = headline(res, args, world, comm_forced, preflight) if rank == 0 else None
+
+    # ---- N > 1: the workloads that can scale, through the same ranks (no child processes once the GPUs are in use)
+    if world > 1 and args.workload == "random" and args.arithmetic == "complex" and not args.no_workloads:
+        legs = sharded_legs(args, comm, world, rank)
+        if rank == 0:
+            out["workloads"] = legs
 
     if comm is not None:
         comm.barrier()

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define AKS_ABI_VERSION 3
+#define AKS_ABI_VERSION 4
 
 #define AKS_OK 0
 #define AKS_ERR_ARG (-1)         /* bad argument (null pointer, size, alignment) */
@@ -65,7 +65,9 @@ typedef struct aks_ctrl {
     double beta;           /* ||w|| after orthogonalisation, last step (ortho.py:98/105) */
     int32_t real_mode;     /* 1: real-packed panel (aks_workspace_set_real); read by the reductions */
     int32_t deferred;      /* 1: the last step left its new column raw (AKS_EXPAND_DEFER_SCALE was honoured)  */
-    double reserved[3];
+    uint32_t ticket[4];    /* arrival counters of the panel kernels whose last workgroup sums the per-workgroup partial
+                              rows itself (ABI 4); zero between launches: the last arriver resets its word           */
+    double reserved;
 } aks_ctrl;
 
 /* Byte offsets of the workspace regions (all 256-byte aligned). */

@@ -28,22 +28,35 @@ namespace {
 
 constexpr int MAX_RANKS = 8;
 constexpr size_t AR_CAP = 8192;                 // doubles per all-reduce
-constexpr size_t BOX_CAP = 16u << 20;           // bytes per (source, destination) mailbox (the segment is sparse)
-constexpr double TIMEOUT_S = 60.0;
+// bytes per (source, destination) mailbox: AKS_MOCK_BOX_MB, default 192 MiB -- the 2-rank exchange of BASELINE config 5
+// (n = 10M random CSR) is 73 MB per message (the old fixed 16 MiB could not rehearse it).  The segment
+// holds nranks^2 mailboxes and is SPARSE: /dev/shm pages exist only for bytes that were actually sent.
+constexpr size_t BOX_CAP_DEFAULT_MB = 192;
+constexpr double TIMEOUT_DEFAULT_S = 180.0;     // AKS_MOCK_TIMEOUT_S
+
+size_t env_size(const char *name, size_t dflt) {
+    const char *v = getenv(name);
+    if (v == nullptr || *v == 0) return dflt;
+    char *end = nullptr;
+    const unsigned long long x = strtoull(v, &end, 10);
+    return (end == v || x == 0) ? dflt : (size_t)x;
+}
+const double TIMEOUT_S = (double)env_size("AKS_MOCK_TIMEOUT_S", (size_t)TIMEOUT_DEFAULT_S);
 
 struct Shared {
     std::atomic<int> ready, count, sense;
     int nranks;
+    size_t box_cap;                              // bytes per mailbox (every rank must have computed the same)
     std::atomic<long long> calls[MAX_RANKS];     // collective calls made so far, per rank (diagnostics)
     size_t box_bytes[MAX_RANKS][MAX_RANKS];
     double ar[MAX_RANKS][AR_CAP];
-    // followed by MAX_RANKS * MAX_RANKS mailboxes of BOX_CAP bytes
+    // followed by nranks * nranks mailboxes of box_cap bytes
 };
 
 struct MockComm {
     Shared *sh = nullptr;
     char *boxes = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0, box_cap = 0;
     int rank = 0, nranks = 1, local_sense = 0;
     std::string name;
 };
@@ -75,7 +88,7 @@ void barrier(MockComm *c) {
     }
 }
 
-char *box(MockComm *c, int src, int dst) { return c->boxes + ((size_t)src * MAX_RANKS + dst) * BOX_CAP; }
+char *box(MockComm *c, int src, int dst) { return c->boxes + ((size_t)src * c->nranks + dst) * c->box_cap; }
 
 void run_group(std::vector<Op> &ops) {
     if (ops.empty()) return;
@@ -87,7 +100,7 @@ void run_group(std::vector<Op> &ops) {
     c->sh->calls[c->rank].fetch_add(1);
     for (auto &o : ops)
         if (o.send) {
-            if (o.bytes > BOX_CAP) die(c, "message larger than the mock's mailbox");
+            if (o.bytes > c->box_cap) die(c, "message larger than the mock's mailbox (raise AKS_MOCK_BOX_MB)");
             if (hipMemcpy(box(c, c->rank, o.peer), o.ptr, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) die(c, "D2H copy failed");
             c->sh->box_bytes[c->rank][o.peer] = o.bytes;
         }
@@ -126,7 +139,8 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
     if (nranks < 1 || nranks > MAX_RANKS || rank < 0 || rank >= nranks) return ncclInvalidArgument;
     MockComm *c = new MockComm();
     c->rank = rank; c->nranks = nranks; c->name = id.internal;
-    c->bytes = sizeof(Shared) + (size_t)MAX_RANKS * MAX_RANKS * BOX_CAP;
+    c->box_cap = env_size("AKS_MOCK_BOX_MB", BOX_CAP_DEFAULT_MB) << 20;
+    c->bytes = sizeof(Shared) + (size_t)nranks * nranks * c->box_cap;
     int fd = -1;
     const auto t0 = std::chrono::steady_clock::now();
     if (rank == 0) {
@@ -151,6 +165,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
     c->boxes = static_cast<char *>(p) + sizeof(Shared);
     if (rank == 0) {
         c->sh->nranks = nranks;
+        c->sh->box_cap = c->box_cap;
         c->sh->count.store(0); c->sh->sense.store(0);
         for (int a = 0; a < MAX_RANKS; ++a) { c->sh->calls[a].store(0); for (int b = 0; b < MAX_RANKS; ++b) c->sh->box_bytes[a][b] = (size_t)-1; }
         c->sh->ready.store(1);
@@ -160,6 +175,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > TIMEOUT_S) die(c, "rank 0 never initialised the segment");
         }
         if (c->sh->nranks != nranks) die(c, "ranks disagree on the communicator's size");
+        if (c->sh->box_cap != c->box_cap) die(c, "ranks disagree on AKS_MOCK_BOX_MB");
     }
     barrier(c);
     *out = reinterpret_cast<ncclComm_t>(c);

@@ -24,11 +24,16 @@ def test_bench_carries_no_test_double():
 
 
 def test_bench_starts_its_own_ranks():
-    res = _run(["--gpus", "2", "--rows", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    res = _run(["--gpus", "2", "--rows", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--leg-rows", "4000"])
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout                      # ONE JSON line, from rank 0
     out = json.loads(lines[0])
+    # N > 1: the workloads that can scale (Markov, 3-D Laplace in z-slabs, real-packed) are measured by the same ranks
+    legs = {leg["name"]: leg for leg in out["workloads"]}
+    assert set(legs) == {"markov", "laplace3d", "random_real_packed"}
+    assert all(leg["n_gpus"] == 2 and leg["restarts_per_s"] > 0 and leg["exchange"]["ghost_bytes_received_per_spmv_rank0"] > 0
+               for leg in legs.values()), legs
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["metric"] == "krylov_restarts_per_sec"
     assert out["scaling"] == "strong" and out["config"]["parallelism"] == "row-sharded x2"
     ex = out["config"]["exchange"]
@@ -51,7 +56,7 @@ def test_bench_under_torch_distributed_run():
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--gpus", "2", "--rows", "20000", "--steps", "2",
-                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+                          "--warmup", "1", "--no-cpu-baseline", "--no-workloads"], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout

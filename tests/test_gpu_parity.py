@@ -924,7 +924,8 @@ def test_bench_multi_rank_line_on_the_c_driven_path(amd):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "400000", "--steps", "2",
-                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+                          "--warmup", "1", "--no-cpu-baseline", "--leg-rows", "300000"], capture_output=True, text=True,
+                         timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -934,6 +935,18 @@ def test_bench_multi_rank_line_on_the_c_driven_path(amd):
     split = ex["spmv_device_ms_rank0"]
     assert ex["ghost_bytes_received_per_spmv_rank0"] > 0 and ex["collectives_per_arnoldi_step"] == 3
     assert all(split[k] is not None and split[k] > 0 for k in ("pack", "exchange", "diag_block", "ghost_wait_plus_offdiag_block"))
+    # N > 1: the workloads that can scale ride in the same line, measured by the same ranks:
+    # Markov, the 3-D Laplacian cut into z-slabs, and the headline matrix in real-packed arithmetic
+    legs = {leg["name"]: leg for leg in out["workloads"]}
+    assert set(legs) == {"markov", "laplace3d", "random_real_packed"}
+    for name, leg in legs.items():
+        assert "error" not in leg and leg["restarts_per_s"] > 0 and leg["n_gpus"] == 2 and leg["path"].startswith("C-driven"), leg
+        assert leg["exchange"]["ghost_bytes_received_per_spmv_rank0"] > 0 and leg["exchange"]["spmv_device_ms_rank0"]["exchange"] > 0
+    assert legs["laplace3d"]["exchange"]["collectives_per_arnoldi_step"] == 4 and legs["laplace3d"]["second_pass_fraction"] > 0.9
+    assert legs["random_real_packed"]["dtype"].startswith("float64")     # 8 bytes per exchanged entry instead of 16
+    # a z-slab's halo is one plane of the grid
+    nx = round(300_000 ** (1 / 3))
+    assert legs["laplace3d"]["exchange"]["ghost_bytes_received_per_spmv_rank0"] == 16 * nx * (nx + 1)
 
 
 def test_rccl_collectives_one_rank(amd, tmp_path):

@@ -1,0 +1,239 @@
+"""TEST INFRASTRUCTURE: BASELINE configs 4 and 5 through the SHARDED C-driven path at FULL size, 8 ranks on one GPU.
+
+    AKS_LIB_PATH=tests/mock_rccl/libarnoldi_hip.so python tests/thread_ranks_worker.py --case c4|c5|bench --out FILE
+
+The ranks are threads of this process (tests/thread_ranks.py: a GPU box admits six processes on its card, the
+configs need eight ranks); each drives ``aks_arnoldi_expand`` on its own ``aks_shard`` -- diagonal / off-diagonal
+blocks, pack list, per-peer counts, communicator -- exactly as a rank process of ``bench.py --gpus 8`` does, with
+the ghost exchange (grouped send / recv) and the stage all-reduces issued from C over tests/mock_rccl, whose
+barriers check call order, peers and message sizes.  What is checked ("next round" item 1):
+
+  c4     3-D Laplace 251 x 252 x 253 (n = 16 002 756), z-slabs, k = 10, m = 40: expansion + two restarts; H bit-equal on
+         all ranks; V^H V = I and A V = V H from per-rank device pieces; the first expansion redone once for the third
+         all-reduce (``lazy_redos == 1``); the leading Ritz values against the one-GPU run on the same start vector.
+  c5     random CSR n = 10M with the planted spectrum, 8 ranks and 2 ranks (a 73 MB message per SpMV): solved to
+         convergence; planted eigenvalues found; restart count and History of the one-GPU solve; device-side residuals
+         <= 1.05 x the one-GPU solve's.
+  bench  ``bench.py``'s measurement with 8 ranks at the full n = 10M: the line with config.exchange and rank 0's
+         per-SpMV split (numbers of a shared GPU and a host-copy "network": structure only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "arnoldi-py_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("AKS_LIB_PATH", os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"))
+os.environ["AKS_GRAPH"] = "0"                      # the stand-in synchronises streams: nothing to capture
+
+import numpy as np  # noqa: E402
+
+C128 = np.complex128
+T0 = time.perf_counter()
+
+
+def log(msg):
+    sys.stderr.write(f"[{time.perf_counter() - T0:7.1f} s] {msg}\n")
+    sys.stderr.flush()
+
+
+def case_c4(ranks, dims, restarts=2):
+    import torch
+    from arnoldi_amd import matrices
+    from arnoldi_amd.dist import slab_offsets
+    from arnoldi_amd.engine import CsrOperator
+    from arnoldi_amd.krylov_schur import KrylovSchurSolver
+    from arnoldi_amd.utils import arg_largest_magnitude, rand_normalized_vector
+    from thread_ranks import run_ranks
+
+    n = int(np.prod(dims))
+    nev, m, p = 10, 40, 15
+    np.random.seed(0)
+    v0 = rand_normalized_vector(n, C128)
+    offs = slab_offsets(dims, ranks)
+    cols = (0, 7, 14, 15, 30, 39)
+
+    # one GPU, same start vector: the reference for the Ritz values
+    A = matrices.laplace3d(*dims)
+    nnz = int(A.nnz)
+    s1 = KrylovSchurSolver(A, nev, m, p, 1e-8, arg_largest_magnitude, v0=v0)
+    del A
+    assert s1.start() == m
+    for r in range(restarts):
+        assert not s1.contract(r)
+        assert s1.expand() == m
+    torch.cuda.synchronize()
+    H1 = s1.H.copy()
+    form1 = s1.op.spmv_form
+    del s1
+    torch.cuda.empty_cache()
+    log("c4: one-GPU reference done")
+
+    def rank_fn(comm, rank):
+        r0, r1 = int(offs[rank]), int(offs[rank + 1])
+        rows = matrices.laplace_rows(dims, r0, r1)
+        op = CsrOperator(local_rows=rows, offsets=offs, comm=comm)
+        del rows
+        s = KrylovSchurSolver(op, nev, m, p, 1e-8, arg_largest_magnitude, v0=v0, comm=comm)
+        assert s.start() == m
+        for r in range(restarts):
+            assert not s.contract(r)
+            assert s.expand() == m
+        ctx, nl = s.ctx, op.n_local
+        V = ctx.basis.V[:, :nl]                                   # (m+1, n_local) device view
+        G = (V.conj() @ V.T).cpu().numpy()                        # this rank's share of V^H V
+        Hd = torch.from_numpy(s.H).cuda()
+        y = torch.empty(ctx.basis.ldv, dtype=torch.complex128, device="cuda")
+        res2 = []
+        for j in cols:                                            # A V[:, j] - V H[:, j], this rank's rows
+            ctx.op.apply(ctx.basis.col(j), y, ctx.ws)             # (collective: ghost exchange through the C path)
+            r = y[:nl] - (Hd[:, j].unsqueeze(0) @ V).squeeze(0)
+            res2.append(float(torch.linalg.norm(r)) ** 2)
+        return {"H": s.H.copy(), "G": G, "res2": res2, "lazy_redos": ctx.lazy_redos, "n_ghost": int(op.n_ghost),
+                "n_send": int(op.n_send), "n_local": nl, "form": op.spmv_form, "native": bool(op.native_comm),
+                "c_driven": bool(op.c_driven), "collectives": ctx.collectives_per_step(),
+                "second_passes": int(ctx.last_ctrl.second_passes) - ctx.discarded_second_passes}
+
+    out = run_ranks(ranks, rank_fn)
+    log("c4: sharded run done")
+    G = sum(o["G"] for o in out)
+    ritz = lambda H: np.sort_complex(np.linalg.eigvals(H[:m, :m]))        # noqa: E731
+    lead = lambda H: np.sort(np.abs(np.linalg.eigvals(H[:m, :m])))[::-1][:nev]   # noqa: E731
+    r8, r1 = ritz(out[0]["H"]), ritz(H1)
+    return {
+        "n": n, "nnz": nnz, "ranks": ranks, "offsets": [int(x) for x in offs],
+        "H_bit_equal_across_ranks": bool(all(np.array_equal(o["H"], out[0]["H"]) for o in out)),
+        "orth_err": float(np.abs(G - np.eye(m + 1)).max()),
+        "arnoldi_residuals": [float(np.sqrt(sum(o["res2"][i] for o in out))) for i in range(len(cols))],
+        "lazy_redos": [o["lazy_redos"] for o in out], "collectives_per_step": [o["collectives"] for o in out],
+        "n_ghost": [o["n_ghost"] for o in out], "n_send": [o["n_send"] for o in out],
+        "n_local": [o["n_local"] for o in out], "forms": [o["form"] for o in out], "form_one_gpu": form1,
+        "native": bool(all(o["native"] and o["c_driven"] for o in out)),
+        "second_passes": [o["second_passes"] for o in out],
+        "ritz_hull": [float(r8.real.min()), float(r8.real.max()), float(np.abs(r8.imag).max())],
+        "leading_ritz_rel_diff_vs_one_gpu": float(np.abs(lead(out[0]["H"]) - lead(H1)).max() / np.abs(lead(H1)).max()),
+        "H_rel_diff_vs_one_gpu": float(np.abs(out[0]["H"] - H1).max() / np.abs(H1).max()),
+    }
+
+
+def case_c5(rank_counts, n):
+    import torch
+    from arnoldi_amd import matrices, partial_schur
+    from arnoldi_amd.dist import row_offsets
+    from arnoldi_amd.engine import CsrOperator
+    from arnoldi_amd.utils import rand_normalized_vector
+    from thread_ranks import run_ranks
+
+    planted = (4.0, 3.7, 3.4, 3.1, 2.8, 2.5)
+    A = matrices.random_csr(n, 5, 1234, planted=planted)
+    log("c5: matrix built")
+    np.random.seed(0)
+    v0 = rand_normalized_vector(n, C128)
+    st = {}
+    partial_schur(A, 5, max_dim=20, v0=v0, stats=st, gather=False)
+    vals1, _, rel1 = st["solver"].true_residuals()
+    one = {"restarts": int(st["restarts"]), "hist_restarts": [int(x) for x in st["solver"].history.restarts],
+           "hist_matvecs": [int(x) for x in st["solver"].history.matvecs], "rel_max": float(rel1.max()),
+           "vals": sorted(float(v) for v in vals1.real)[::-1], "form": st["spmv_form"]}
+    del st
+    torch.cuda.empty_cache()
+    log(f"c5: one-GPU solve done ({one['restarts']} restarts)")
+    result = {"n": n, "nnz": int(A.nnz), "planted": list(planted), "one_gpu": one, "sharded": {}}
+    for ranks in rank_counts:
+        offs = row_offsets(n, ranks)
+
+        def rank_fn(comm, rank):
+            rows = A[int(offs[rank]): int(offs[rank + 1])]
+            op = CsrOperator(local_rows=rows, offsets=offs, comm=comm)
+            del rows
+            stats = {}
+            partial_schur(op, 5, max_dim=20, v0=v0, comm=comm, stats=stats, gather=False)
+            solver = stats["solver"]
+            vals, _, rel = solver.true_residuals()                 # device-side, shard-wise + all-reduce
+            ctx = solver.ctx
+            return {"restarts": int(stats["restarts"]), "hist_restarts": [int(x) for x in solver.history.restarts],
+                    "hist_matvecs": [int(x) for x in solver.history.matvecs], "rel_max": float(rel.max()),
+                    "vals": sorted(float(v) for v in vals.real)[::-1], "imag_max": float(np.abs(vals.imag).max()),
+                    "T": solver.H[:5, :5].copy(), "n_ghost": int(op.n_ghost), "n_send": int(op.n_send),
+                    "forms": [op.spmv_form, getattr(op.off, "form", None)], "native": bool(op.native_comm and op.c_driven),
+                    "lazy_redos": ctx.lazy_redos, "collectives": ctx.collectives_per_step(),
+                    "deferred": int(stats["deferred_normalisations"])}
+
+        out = run_ranks(ranks, rank_fn)
+        log(f"c5: {ranks} ranks done ({out[0]['restarts']} restarts)")
+        r0 = out[0]
+        result["sharded"][str(ranks)] = {
+            "T_bit_equal_across_ranks": bool(all(np.array_equal(o["T"], r0["T"]) for o in out)),
+            "restarts": r0["restarts"], "hist_restarts": r0["hist_restarts"], "hist_matvecs": r0["hist_matvecs"],
+            "rel_max": max(o["rel_max"] for o in out), "vals": r0["vals"], "imag_max": r0["imag_max"],
+            "ghost_bytes_per_spmv": [16 * o["n_ghost"] for o in out], "sent_bytes_per_spmv": [16 * o["n_send"] for o in out],
+            "forms": r0["forms"], "native": bool(all(o["native"] for o in out)), "lazy_redos": [o["lazy_redos"] for o in out],
+            "collectives_per_step": r0["collectives"], "deferred_expansions": r0["deferred"],
+        }
+    return result
+
+
+def case_bench(ranks, rows, steps, warmup, leg_rows):
+    """bench.py's rank logic on thread ranks: ``measure`` per rank, ``headline`` on rank 0 (+ the sharded legs)."""
+    import bench
+    from thread_ranks import run_ranks
+
+    bench.GPU = True
+    argv = ["--gpus", str(ranks), "--rows", str(rows), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline"]
+    if leg_rows is not None:
+        argv += ["--leg-rows", str(leg_rows)]
+    else:
+        argv += ["--no-workloads"]
+    args = bench.parse_args(argv)
+
+    def rank_fn(comm, rank):
+        res = bench.measure(args, comm, ranks, rank)
+        out = bench.headline(res, args, ranks) if rank == 0 else None
+        if not args.no_workloads:
+            legs = bench.sharded_legs(args, comm, ranks, rank, log=log if rank == 0 else None)
+            if rank == 0:
+                out["workloads"] = legs
+        return out
+
+    out = run_ranks(ranks, rank_fn)[0]
+    out["data"] = "rehearsal: thread ranks sharing one GPU, host-copy stand-in for RCCL (structure only, not a measurement)"
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", required=True, choices=["c4", "c5", "bench"])
+    ap.add_argument("--ranks", type=int, default=8)
+    ap.add_argument("--rows", type=int, default=None, help="shrink the problem (local rehearsals); default = BASELINE size")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--leg-rows", type=int, default=None)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    import torch
+
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    if a.case == "c4":
+        dims = (251, 252, 253)
+        if a.rows:
+            nx = max(int(round(a.rows ** (1.0 / 3.0))), 8)
+            dims = (nx, nx + 1, nx + 2)
+        res = case_c4(a.ranks, dims)
+    elif a.case == "c5":
+        res = case_c5([a.ranks, 2] if a.ranks != 2 else [2], a.rows or 10_000_000)
+    else:
+        res = case_bench(a.ranks, a.rows or 10_000_000, a.steps, a.warmup, a.leg_rows)
+    res["wall_s"] = round(time.perf_counter() - T0, 1)
+    with open(a.out, "w") as f:
+        json.dump(res, f)
+    log(f"{a.case}: written {a.out}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
