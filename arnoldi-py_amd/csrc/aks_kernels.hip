@@ -182,10 +182,23 @@ __device__ __forceinline__ void transpose_reduce_step(double (&v)[KP], int lane)
 // "Workgroup dispatch, XCD placement & inter-workgroup visibility", valid-forms table row 1: one lane's agent-scope
 // add per storing workgroup after every storing wave's drain and a workgroup barrier, the last arriver told by the
 // value its add returned, every handed-off byte stored and loaded sc1.)  The ticket words live in the control block;
-// the last arriver zeroes its word again, aks_workspace_init zeroes them all.  -DAKS_TAIL_REDUCE=0 rebuilds the
-// separate-kernel schedule for A/B runs.
-#ifndef AKS_TAIL_REDUCE
-#define AKS_TAIL_REDUCE 1
+// the last arriver zeroes its word again, aks_workspace_init zeroes them all.
+//
+// MEASURED (profiles/r04_tail_ab.txt, whole restarts, builds interleaved on one box): on the two wide panel kernels this
+// is a LOSS -- restarts/s -4 % at n = 1.25M (random CSR and Markov, m = 20), -4 % on a 2M-row 3-D Laplacian (m = 40),
+// -0.6 % at n = 10M: a streaming kernel's 256 workgroups finish within a microsecond of each other, their 256 arrivals
+// queue on the one counter (11 - 13 ns each, MI355X_MICROARCH.md "fanin": 3.6 - 4.5 us under streaming load), and the
+// last arriver then still has a dependent round of sc1 reads in front of it -- more than the kernel boundary (~2 us)
+// plus the 21-workgroup k_reduce it replaces.  (The 4.4 - 4.9 us per one-block launch that profiles/r03_small_trace.txt
+// shows, and VERDICT r03 counted, is rocprofv3's per-dispatch overhead; in an un-profiled stream a Gram-Schmidt
+// step's five small launches cost ~10 us together.)  So the panel kernels keep their k_reduce (AKS_TAIL_PANEL = 0;
+// build with 1 for the in-kernel form), and the mechanism serves the place where it removes launches without adding
+// arrivals to the common path: the second-pass kernel, see FIN_* below (AKS_FOLD_FINISH).
+#ifndef AKS_TAIL_PANEL
+#define AKS_TAIL_PANEL 0
+#endif
+#ifndef AKS_FOLD_FINISH
+#define AKS_FOLD_FINISH 1
 #endif
 __device__ __forceinline__ void st_partial(c128 *p, double re, double im) {
     double *d = reinterpret_cast<double *>(p);
@@ -628,6 +641,16 @@ __global__ __launch_bounds__(BLOCK) void k_update(int64_t n, int J, const c128 *
 // instead of 8 NC registers (the generic kernel ran at 5.7 - 6.1 TB/s where the projection reaches
 // 6.3 - 6.9; it is 27 - 30 % of the device time on the Laplacians, whose every step takes the second pass).  Same
 // arithmetic in the same order as k_update<true>: w comes out bit for bit the same.
+// MEASURED AND NOT SHIPPED (profiles/r04_update_nc_ab.txt, r04_tail_ab.txt "sep" against "sepgen"): at n = 16M the generic
+// kernel runs at 5.9 - 6.5 TB/s for J = 16 .. 40 and every geometry of this one (256 / 512 / 1024 / 2048 workgroups,
+// coefficients in registers or in LDS) at 5.7 - 6.3, 0 - 2 % behind width by width (2M rows: +-1 %, ahead only at
+// J = 40); whole restarts 9.12 against 9.31 (3-D Laplace 16M) and 66.7 against 67.4 restarts/s (2M).  The second pass
+// is a read stream with one rewritten column, like the fused update, and sits at that pattern's rate with
+// four loads in flight per lane as well as with forty.  Compiled only with -DAKS_UPDATE_EXACT_MAX=<widest J>.
+#ifndef AKS_UPDATE_EXACT_MAX
+#define AKS_UPDATE_EXACT_MAX 0        // widest exact-width second-pass kernel (0: the generic kernel at every width)
+#endif
+#if AKS_UPDATE_EXACT_MAX > 0
 template <int NC>
 __global__ __launch_bounds__(BLOCK) void k_update_nc(int64_t n, const c128 *__restrict__ V, int64_t ldv,
                                                     c128 *__restrict__ w, const c128 *__restrict__ h,
@@ -676,12 +699,13 @@ __global__ __launch_bounds__(BLOCK) void k_update_nc(int64_t n, const c128 *__re
     const double s = block_sum(nrm, red_n);
     second_pass_tail(s, partial, ldp, nrm_slot, NC, red1, red2, ctrl, fin, red_n);
 }
+#endif   // AKS_UPDATE_EXACT_MAX > 0
 
 // ------------------------------------------------------------------ second-stage reduction
 // out[c] = sum_b partial[b*ldp + first + c], c = blockIdx.x < count; fixed order => reproducible.
 // PRED as in k_update (skips when no second pass ran, leaving `out` untouched).
-// (Since round 4 only behind the kernels that have no in-kernel second stage: panels wider than 40 columns, and the
-// -DAKS_TAIL_REDUCE=0 build.)
+// (The panel kernels' in-kernel alternative, -DAKS_TAIL_PANEL=1, was measured slower: see "second stage of the
+// reductions inside the producing kernel" above.)
 template <bool PRED>
 __global__ __launch_bounds__(BLOCK) void k_reduce(const c128 *__restrict__ partial, int n_blocks, int ldp,
                                                  int first, c128 *__restrict__ out, int J,
@@ -1315,7 +1339,7 @@ struct Ws {
     aks_ctrl *ctrl;
     c128 *red1, *red2, *red3, *partial;
     double *colscale;          // per basis column: 0 = normalised, else the column is raw and this is its divisor
-    unsigned *ticket(int i) const { return AKS_TAIL_REDUCE ? reinterpret_cast<unsigned *>(ctrl->ticket) + i : nullptr; }
+    unsigned *ticket(int i) const { return reinterpret_cast<unsigned *>(ctrl->ticket) + i; }
 };
 enum { TICKET_PROJ = 0, TICKET_UPDATE_PROJ = 1, TICKET_UPDATE = 2 };
 
@@ -1359,6 +1383,7 @@ void launch_update_proj_nc(dim3 grid, hipStream_t s, int64_t n, const c128 *V, i
                            c128 *red_out, unsigned *ticket) {
     hipLaunchKernelGGL(k_update_proj<NC>, grid, dim3(BLOCK), 0, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0, red_out, ticket);
 }
+#if AKS_UPDATE_EXACT_MAX > 0
 template <int NC>
 void launch_update_nc(dim3 grid, hipStream_t s, hipEvent_t ev1, int64_t n, const c128 *V, int64_t ldv, c128 *w, const c128 *h,
                       c128 *partial, int ldp, const c128 *red1, const c128 *red2, double eta, aks_ctrl *ctrl,
@@ -1366,6 +1391,7 @@ void launch_update_nc(dim3 grid, hipStream_t s, hipEvent_t ev1, int64_t n, const
     launch_timed(k_update_nc<NC>, grid, dim3(BLOCK), 0, s, (hipEvent_t) nullptr, ev1, n, V, ldv, w, h, partial, ldp, 0, red1, red2, eta,
                  ctrl, cs, raw0, fin);
 }
+#endif
 
 #define AKS_NC_CASES(M) \
     M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) \
@@ -1404,6 +1430,7 @@ void dispatch_update_proj(int nc, dim3 grid, hipStream_t s, int64_t n, const c12
     }
 }
 
+#if AKS_UPDATE_EXACT_MAX > 0
 void dispatch_update_nc(int nc, dim3 grid, hipStream_t s, hipEvent_t ev1, int64_t n, const c128 *V, int64_t ldv, c128 *w,
                         const c128 *h, c128 *partial, int ldp, const c128 *red1, const c128 *red2, double eta,
                         aks_ctrl *ctrl, const double *cs, int raw0, const FinArgs &fin) {
@@ -1415,6 +1442,7 @@ void dispatch_update_nc(int nc, dim3 grid, hipStream_t s, hipEvent_t ev1, int64_
         default: break;
     }
 }
+#endif
 
 template <int NQ>
 void launch_update_proj_split(dim3 grid, hipStream_t s, int64_t n, int J, const c128 *V, int64_t ldv, c128 *w,
@@ -1460,7 +1488,7 @@ void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c12
     const int n_blocks = panel_blocks(ws, base);          // (every group writes the same rows of `partial`)
     const dim3 grid(n_blocks);
     // one launch covers the panel (J <= 40): its last workgroup sums the partial rows itself; several groups: k_reduce
-    unsigned *ticket = groups == 1 ? ws.ticket(TICKET_PROJ) : nullptr;
+    unsigned *ticket = (AKS_TAIL_PANEL && groups == 1) ? ws.ticket(TICKET_PROJ) : nullptr;
     int c0 = 0;
     for (int g = 0; g < groups; ++g) {
         const int nc = base + (g < extra ? 1 : 0);
@@ -1850,7 +1878,7 @@ static int gs_update_project_(int64_t n_rows, int32_t J, const aks_c128 *d_V, in
 #endif
     const bool exact = J <= exact_max && J <= 40 && !(AKS_FUSED_SPLIT_LOW && J >= 5 && J <= 12);
     const int n_blocks = exact ? panel_blocks(ws, J) : ws.lay.n_blocks;
-    unsigned *ticket = exact ? ws.ticket(TICKET_UPDATE_PROJ) : nullptr;      // the exact-width kernel sums its own partial rows
+    unsigned *ticket = (AKS_TAIL_PANEL && exact) ? ws.ticket(TICKET_UPDATE_PROJ) : nullptr;   // (the kernel sums its own partial rows)
     if (exact)
         dispatch_update_proj(J, dim3(n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
                              ws.lay.ld_partial, ws.ctrl, ws.colscale, raw0, ticket ? ws.red2 : nullptr, ticket);
@@ -1889,18 +1917,19 @@ static int gs_update_norm_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64
     fin.tol = tol;
     fin.cs = ws.colscale;
     fin.red3 = ws.red3;
-    fin.ticket = ws.ticket(TICKET_UPDATE);
+    // the kernel sums its own norm partials (last-arriver ticket) exactly when it also books the step: only then does
+    // that save launches (k_reduce<true> AND k_finish); a step that takes no second pass never reaches the ticket
+    fin.ticket = fin_mode != FIN_NONE ? ws.ticket(TICKET_UPDATE) : nullptr;
     fin.normalize = normalize;
-    fin.mode = fin.ticket != nullptr ? fin_mode : FIN_NONE;       // (book-keeping in the kernel needs its own norm sum)
+    fin.mode = fin_mode;
     const c128 *V = reinterpret_cast<const c128 *>(d_V);
     c128 *w = reinterpret_cast<c128 *>(d_w);
-#ifndef AKS_UPDATE_EXACT_MAX
-#define AKS_UPDATE_EXACT_MAX 40       // widest exact-width second-pass kernel (0: the generic kernel at every width)
-#endif
+#if AKS_UPDATE_EXACT_MAX > 0
     if (J <= AKS_UPDATE_EXACT_MAX && J <= 40)
         dispatch_update_nc(J, dim3(n_blocks), s, ev1, n_rows, V, ldv, w, ws.red2, ws.partial, ws.lay.ld_partial, ws.red1, ws.red2,
                            eta, ws.ctrl, ws.colscale, raw0, fin);
     else
+#endif
         launch_timed(k_update<true>, dim3(n_blocks), dim3(BLOCK), 0, s, (hipEvent_t) nullptr, ev1, n_rows, (int)J, V, ldv, w, ws.red2,
                      ws.partial, ws.lay.ld_partial, 0, ws.red1, ws.red2, eta, ws.ctrl, ws.colscale, raw0, fin);
     if (fin.ticket == nullptr)
@@ -1957,7 +1986,7 @@ static int dgks_gs_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv,
     if (rc != AKS_OK) return rc;
     // normalize != 1: nothing of length n is left to do after the second pass, so the kernel that produces (or skips)
     // it books the step -- H column, beta, breakdown, counters -- and k_finish is not launched at all
-    const bool fold = AKS_TAIL_REDUCE && normalize != 1;
+    const bool fold = AKS_FOLD_FINISH && normalize != 1;
     rc = gs_update_norm_(n_rows, J, d_V, ldv, d_w, eta, d_ws, ws_bytes, max_dim, stream, raw0,
                          fold ? FIN_ALWAYS : FIN_NONE, d_Hcol, ldh, tol, normalize, fold ? ev.stop : nullptr);
     if (rc != AKS_OK || fold) return rc;
@@ -2430,7 +2459,7 @@ int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 
             // the lazy third all-reduce (a step that does take the second pass makes the caller repeat the expansion
             // anyway), otherwise only for the steps that need no second pass -- after one, the norm is summed over the
             // ranks first and k_finish books the step
-            const bool fold = AKS_TAIL_REDUCE && norm_mode != 1;
+            const bool fold = AKS_FOLD_FINISH && norm_mode != 1;
             const int fin_mode = !fold ? FIN_NONE : (lazy_third ? FIN_ALWAYS : FIN_IF_ONCE);
             const bool last = fin_mode == FIN_ALWAYS;
             if (rc == AKS_OK) rc = gs_update_norm_(n_panel, J, d_V, ldv, w, eta, d_ws, ws_bytes, max_dim, stream, raw0, fin_mode,
