@@ -509,7 +509,7 @@ class ArnoldiContext:
         which orders the host behind the copy that used it."""
         b = self.basis
         Q = np.ascontiguousarray(Q, dtype=C128)
-        if not b.V.is_cuda:                                   # CPU tensors (tests/fake_hip.py)
+        if not b.V.is_cuda or os.environ.get("AKS_COEF_UPLOAD") == "sync":     # CPU tensors (tests/fake_hip.py); A/B
             return torch.from_numpy(Q).to(b.device)
         if self._coef_stage is None or self._coef_stage[0].numel() < Q.size:
             cap = max(Q.size, self.max_dim * self.max_dim)

@@ -220,7 +220,21 @@ __device__ __forceinline__ bool last_block_arrives(unsigned *ticket) {
     if (threadIdx.x == 0) {
         const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = old + 1u == gridDim.x;
-        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // for the next launch
+        if (last) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // for the next launch
+            // the consumer's agent-scope acquire (MI355X_MICROARCH.md, "Consumer, always"): sc1 loads alone are only
+            // measured valid with ONE workgroup per CU, and the second-pass kernel runs two -- without this fence a
+            // full-size solve once in a while summed one STALE partial (a 1/512 error in beta: the residual 2.2e-3
+            // instead of 8.7e-9 of tests/test_gpu_sharded_full.py's one-GPU leg, round 4).  One lane fences, its
+            // s_waitcnt holds the barrier below until the invalidate has completed; ~1.7 us, on the last workgroup only.
+#ifndef AKS_TICKET_ACQUIRE
+#define AKS_TICKET_ACQUIRE 1
+#endif
+#if AKS_TICKET_ACQUIRE
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        }
         s_last = last;
     }
     __syncthreads();
@@ -1059,12 +1073,20 @@ __global__ __launch_bounds__(BLOCK) void k_truncate_mfma(int64_t n, int m, int p
 
 // after a restart compression of columns [0, m] into [0, p]: the p new columns are normalised; column p is a bit
 // copy of column m and inherits its scale; columns behind it are dead
-__global__ void k_colscale_after_truncate(double *__restrict__ cs, int m, int p) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const double sm = cs[m];
-        for (int c = 0; c <= m; ++c) cs[c] = 0.0;
-        cs[p] = sm;
-    }
+// (Round 4: a real bug of round 3's deferred normalisation lived here.  The one-thread form  sm = cs[m]; clear cs[0..m];
+// cs[p] = sm  compiled to an s_load (scalar cache path) of cs[m] followed by vector stores that clear cs[m] WITHOUT waiting
+// for the scalar load -- the two paths are not ordered by the hardware, so when the load missed the scalar cache the
+// stores overtook it, the carried scale read as 0 and column p -- a raw column -- was taken for a normalised one by the
+// next expansion: errors of 1e-3 .. 1e-1 in H, a few times in a hundred restarts, timing-dependent (found at full size:
+// tests/thread_ranks_worker.py --case repro; the 2.2e-3 residual of a one-GPU config-5 solve was the same bug).  Now:
+// every lane LOADS with a vector load, the workgroup's barrier waits for all of them, then lane c stores column c's
+// scale.)
+__global__ __launch_bounds__(BLOCK) void k_colscale_after_truncate(double *cs, int m, int p) {
+    const double sm = __hip_atomic_load(&cs[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // global_load (not s_load)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (blockIdx.x == 0 && c <= m) cs[c] = c == p ? sm : 0.0;
 }
 
 // w *= alpha (the normalisation at the end of the explicit-restart solvers' mgs, explicit_restarts.py:77)
@@ -1089,7 +1111,12 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int64_t count, const int32_t *
 // ------------------------------------------------------------------ tile-binned two-phase SpMV
 // (include/arnoldi_hip.h, "tile-binned two-phase SpMV"; measurements behind the shape of both kernels:
 // profiles/microbench/tile_binned_spmv.hip, vmem_issue_cost.hip)
-constexpr int PB_CW_BITS = AKS_PB_SLAB_BITS, PB_CW = 1 << PB_CW_BITS;       // columns per sub-slab
+// columns per sub-slab: 2^AKS_PB_SLAB_BITS, or -DAKS_PB_SLAB_COLS=<any count <= 10240> for experiments (10240 complex
+// entries fill the 160 KiB of LDS: 1.25 x longer pieces for phase 2, profiles/r04_pb_bytes_ab.txt)
+#ifndef AKS_PB_SLAB_COLS
+#define AKS_PB_SLAB_COLS (1 << AKS_PB_SLAB_BITS)
+#endif
+constexpr int PB_CW_BITS = AKS_PB_SLAB_BITS, PB_CW = AKS_PB_SLAB_COLS;
 constexpr int PB_RB_BITS = AKS_PB_ROWBLOCK_BITS, PB_RB = 1 << PB_RB_BITS;   // rows per row block
 constexpr int PB_W = AKS_PB_WAVES, PB_K = AKS_PB_RUNS_PER_WAVE, PB_RPR = PB_W * PB_K;
 #ifndef AKS_PB_DEPTH
@@ -1103,18 +1130,31 @@ constexpr int PB_MAX_LEVELS = 8;             // 3-bit level field next to the 13
 #ifndef AKS_PB_TICKS
 #define AKS_PB_TICKS 0           // diagnostic build: wave 0 of every phase-2 workgroup leaves s_memtime sums per pipeline
 #endif                           // section in the first doubles of the product scratch (pb_abi_bench prints them)
-static_assert(PB_CW_BITS <= 13 && PB_RB_BITS <= 13, "lcol / lrow are 13-bit fields");
+static_assert(PB_CW <= 65536 && PB_RB_BITS <= 13, "lcol is a 16-bit, lrow a 13-bit field");
 static_assert(PB_B % PB_D == 0 && PB_B * PB_K <= 64, "descriptor block: a multiple of the depth, one lane per slot");
 static_assert((PB_K == 4 || PB_K == 8) && AKS_PB_RUN_MAX == 64, "a lane's words of a round are one 8- or 16-byte load");
 struct alignas(PB_K * 2) PbWords { unsigned v[PB_K / 2]; };     // a lane's PB_K (level, row) words of one round
 static_assert(PB_W <= PB_MAX_LEVELS, "a level counts waves");
 
 typedef double v2d __attribute__((ext_vector_type(2)));
+#ifndef AKS_PB_NT_STORE
+#define AKS_PB_NT_STORE 1        // 0: plain product stores (experiment: products that should stay in the Infinity Cache)
+#endif
 __device__ __forceinline__ void store_stream(c128 v, c128 *p) {      // written once, read by another kernel
+#if AKS_PB_NT_STORE
     v2d t; t.x = v.x; t.y = v.y;
     __builtin_nontemporal_store(t, reinterpret_cast<v2d *>(p));
+#else
+    *p = v;
+#endif
 }
-__device__ __forceinline__ void store_stream(double v, double *p) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void store_stream(double v, double *p) {
+#if AKS_PB_NT_STORE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 #ifndef AKS_NT_PB
 #define AKS_NT_PB 0              // A/B knob: non-temporal loads of the streams the binned kernels read once
 #endif
@@ -1142,7 +1182,8 @@ __global__ __launch_bounds__(PB_P1_THREADS) void k_pb_phase1(int64_t n_cols, con
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
     XT *xs = reinterpret_cast<XT *>(pb_smem);
     const int s = blockIdx.x;
-    const int64_t c0 = (int64_t)s << PB_CW_BITS;
+    if (slab_begin[s] >= slab_end[s]) return;            // a sub-slab without entries (off-diagonal blocks; column groups)
+    const int64_t c0 = (int64_t)s * PB_CW;
     const int cw = (int)min((int64_t)PB_CW, n_cols - c0);
     // x may be a RAW basis column (deferred normalisation): its entries are divided by the column's scale as they are
     // staged -- once per entry, where k_finish would have divided them in a pass of its own
@@ -1612,7 +1653,7 @@ int check_pb(const aks_pb_matrix *A, const void *x, const void *y) {
     if (A->n_rows <= 0 || A->n_cols <= 0 || A->nnz < 0 || A->nnz_pad < 8 || A->n_runs < PB_RPR ||
         A->n_runs % PB_RPR != 0 || A->n_lrow != A->n_runs * AKS_PB_RUN_MAX)
         return fail(AKS_ERR_ARG, "bad sizes (n_runs: whole rounds, the last one empty; n_lrow = 64 n_runs)");
-    if (A->n_slabs != (int32_t)((A->n_cols + PB_CW - 1) >> PB_CW_BITS) ||
+    if (A->n_slabs != (int32_t)((A->n_cols + PB_CW - 1) / PB_CW) ||
         A->n_rowblocks != (int32_t)((A->n_rows + PB_RB - 1) >> PB_RB_BITS))
         return fail(AKS_ERR_ARG, "n_slabs / n_rowblocks do not match the shape");
     if (!A->d_val || !A->d_lcol || !A->d_slab_begin || !A->d_slab_end || !A->d_runs || !A->d_rb_run_ptr ||
@@ -2016,7 +2057,7 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
         fail(AKS_ERR_ARG, "matrix shape out of range");
         return nullptr;
     }
-    const int64_t n_ss = (n_cols + PB_CW - 1) >> PB_CW_BITS, n_rb = (n_rows + PB_RB - 1) >> PB_RB_BITS;
+    const int64_t n_ss = (n_cols + PB_CW - 1) / PB_CW, n_rb = (n_rows + PB_RB - 1) >> PB_RB_BITS;
     if (n_ss * n_rb > ((int64_t)1 << 26)) {        // (checked before any array is read)
         fail(AKS_ERR_UNSUPPORTED, "too many (sub-slab, row block) tiles for the binned form");
         return nullptr;
@@ -2037,7 +2078,7 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
         for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
             const int32_t c = indices[k];
             if (c < 0 || c >= n_cols) { fail(AKS_ERR_ARG, "column index out of range"); return nullptr; }
-            ++cnt[(int64_t)(c >> PB_CW_BITS) * n_rb + rb];
+            ++cnt[(int64_t)(c / PB_CW) * n_rb + rb];
         }
     }
     // phase-1 order: (sub-slab, row block, row, column); a sub-slab's slots start on a multiple of 8
@@ -2062,8 +2103,8 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
             const int64_t rb = r >> PB_RB_BITS;
             for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
                 const int32_t c = indices[k];
-                const int32_t q = cur[(int64_t)(c >> PB_CW_BITS) * n_rb + rb]++;
-                P->lcol[q] = (uint16_t)(c & (PB_CW - 1));
+                const int32_t q = cur[(int64_t)(c / PB_CW) * n_rb + rb]++;
+                P->lcol[q] = (uint16_t)(c % PB_CW);
                 row13[q] = (uint16_t)(r & (PB_RB - 1));
                 if (values_complex) {
                     P->val[2 * (size_t)q] = vr[2 * (size_t)k];
@@ -2511,7 +2552,8 @@ int aks_truncate_ws(int64_t n_rows, int32_t m, int32_t p, aks_c128 *d_V, int64_t
         default: return fail(AKS_ERR_UNSUPPORTED, "p exceeds AKS_MAX_TRUNC");
     }
     if (rc != AKS_OK) return rc;
-    hipLaunchKernelGGL(k_colscale_after_truncate, dim3(1), dim3(64), 0, s, ws.colscale + col0, (int)m, (int)p);
+    static_assert(AKS_MAX_DIM + 1 <= BLOCK, "one lane per basis column");
+    hipLaunchKernelGGL(k_colscale_after_truncate, dim3(1), dim3(BLOCK), 0, s, ws.colscale + col0, (int)m, (int)p);
     AKS_CHECK_LAUNCH("k_colscale_after_truncate");
     return AKS_OK;
 }

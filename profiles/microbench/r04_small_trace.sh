@@ -11,7 +11,11 @@ out = sys.argv[1]
 f = glob.glob(out + "/t/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-name = lambda r: r["Kernel_Name"].split("(")[0].split("<")[0].replace("(anonymous namespace)::", "")[:40]
+def name(r):
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+    if k.startswith("void "):
+        k = k[5:]
+    return k.split("(")[0][:40]
 # steady state: take the last 60 % of the trace
 rows = rows[int(len(rows) * 0.4):]
 dur = collections.defaultdict(list); gap = collections.defaultdict(list)

@@ -6,8 +6,11 @@
 //   hipcc --offload-arch=gfx950 -O3 -Iinclude -o profiles/microbench/rocsparse_crosscheck \
 //       profiles/microbench/rocsparse_crosscheck.cpp -Larnoldi-py_amd/arnoldi_amd/lib -larnoldi_hip -lrocsparse \
 //       -Wl,-rpath,'$ORIGIN/../../arnoldi-py_amd/arnoldi_amd/lib'
-//   ./profiles/microbench/rocsparse_crosscheck [n] [per_row] [alg]     alg: -1 all (default), 0..4 one of the list below,
-//                                                                     9 none (the library's forms only)
+//   ./profiles/microbench/rocsparse_crosscheck n per_row alg     alg: 0..4 ONE of the algorithms listed below, 9 none (the
+//                                                                library's forms only)
+// ONE rocSPARSE algorithm per process, by construction: analysing one matrix descriptor for a second algorithm faulted
+// inside rocSPARSE 4.2 ("Memory access fault by GPU ... address (nil)", round 3), so the program no longer has a mode
+// that does that -- loop over the algorithms from the shell (profiles/r03_rocsparse_crosscheck.txt was made that way).
 #include <hip/hip_runtime.h>
 #include <rocsparse/rocsparse.h>
 
@@ -38,6 +41,10 @@ int main(int argc, char **argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 10000000;
     const int per_row = argc > 2 ? atoi(argv[2]) : 5;
     const int which = argc > 3 ? atoi(argv[3]) : -1;
+    if (which < 0 || (which > 4 && which != 9)) {
+        fprintf(stderr, "usage: rocsparse_crosscheck n per_row alg   (alg: 0..4 one rocSPARSE algorithm, 9 none; one per process)\n");
+        return 2;
+    }
     const int64_t nnz = n * per_row;
     setvbuf(stdout, nullptr, _IOLBF, 0);
     printf("random CSR n=%lld nnz=%lld, values float64, vectors complex128 (rocSPARSE %d)\n", (long long)n, (long long)nnz,
@@ -110,7 +117,7 @@ int main(int argc, char **argv) {
     double ymax = 0;
     for (double v : h_ref) ymax = std::max(ymax, std::fabs(v));
 
-    // ---- rocSPARSE, generic API, every CSR algorithm
+    // ---- rocSPARSE, generic API: the one CSR algorithm asked for
     rocsparse_handle handle;
     RS(rocsparse_create_handle(&handle));
     rocsparse_spmat_descr matA;
@@ -130,7 +137,7 @@ int main(int argc, char **argv) {
     int index = -1;
     for (auto &a : algs) {
         ++index;
-        if (which >= 0 && which != index) continue;
+        if (which != index) continue;              // exactly one algorithm ever touches the descriptor
         printf("%-44s ...\n", a.name);
         size_t bytes = 0;
         rocsparse_status s = rocsparse_spmv(handle, rocsparse_operation_none, &alpha, matA, vecX, &beta, vecY, rocsparse_datatype_f64_c,

@@ -97,6 +97,12 @@ void run_group(std::vector<Op> &ops) {
         if (o.comm != c) die(c, "one group spans two communicators");
         if (hipStreamSynchronize(o.stream) != hipSuccess) die(c, "hipStreamSynchronize failed");
     }
+    // The library issues the group on its side stream BEHIND an event recorded on the compute stream (the pack kernel).
+    // RCCL's kernels would be ordered behind that event by the GPU; these host copies are only as ordered as
+    // hipStreamSynchronize(side stream) makes them, and at full size that was observed not to cover the pack kernel
+    // every time (run-to-run different bits with 73 MB messages, tests/thread_ranks_worker.py --case repro).  A
+    // stand-in has no business being subtle: wait for the whole device.
+    if (hipDeviceSynchronize() != hipSuccess) die(c, "hipDeviceSynchronize failed");
     c->sh->calls[c->rank].fetch_add(1);
     for (auto &o : ops)
         if (o.send) {
@@ -115,6 +121,11 @@ void run_group(std::vector<Op> &ops) {
             }
             if (hipMemcpy(o.ptr, box(c, o.peer, c->rank), o.bytes, hipMemcpyHostToDevice) != hipSuccess) die(c, "H2D copy failed");
         }
+    // hipMemcpy from PAGEABLE host memory may return once the data sits in the runtime's staging buffer, before the DMA
+    // to the device has finished -- and the kernels that read the ghost buffer run on non-blocking streams, which the
+    // null stream does not order.  Without this wait a 73 MB message (2-rank config 5) could land after its reader had
+    // started: run-to-run different bits (round 4, tests/thread_ranks_worker.py --case repro).
+    if (hipStreamSynchronize(nullptr) != hipSuccess) die(c, "hipStreamSynchronize(null stream) failed");
     barrier(c);
     for (auto &o : ops)
         if (o.send) c->sh->box_bytes[c->rank][o.peer] = (size_t)-1;     // consumed: a recv without a send now mismatches
@@ -231,6 +242,7 @@ ncclResult_t ncclAllReduce(const void *sendbuf, void *recvbuf, size_t count, ncc
         for (size_t i = 0; i < count; ++i) sum[i] += c->sh->ar[r][i];
     }
     if (hipMemcpy(recvbuf, sum.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) die(c, "H2D copy failed");
+    if (hipStreamSynchronize(nullptr) != hipSuccess) die(c, "hipStreamSynchronize(null stream) failed");   // (see run_group)
     barrier(c);
     c->sh->box_bytes[c->rank][c->rank] = (size_t)-1;
     barrier(c);

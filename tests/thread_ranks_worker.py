@@ -134,10 +134,16 @@ def case_c5(rank_counts, n):
     np.random.seed(0)
     v0 = rand_normalized_vector(n, C128)
     st = {}
-    partial_schur(A, 5, max_dim=20, v0=v0, stats=st, gather=False)
+    Q1, T1, _ = partial_schur(A, 5, max_dim=20, v0=v0, stats=st, gather=False)
     vals1, _, rel1 = st["solver"].true_residuals()
+    ev, S = np.linalg.eig(T1)                       # the same residuals on the host (README.md:47-48)
+    vecs = Q1 @ S
+    rel_host = np.linalg.norm(A @ vecs - vecs * ev, axis=0) / np.abs(ev)
+    del Q1, vecs
     one = {"restarts": int(st["restarts"]), "hist_restarts": [int(x) for x in st["solver"].history.restarts],
            "hist_matvecs": [int(x) for x in st["solver"].history.matvecs], "rel_max": float(rel1.max()),
+           "rel_device": [float(x) for x in rel1], "rel_host": [float(x) for x in rel_host],
+           "second_passes": int(st["second_passes"]), "deferred": int(st["deferred_normalisations"]),
            "vals": sorted(float(v) for v in vals1.real)[::-1], "form": st["spmv_form"]}
     del st
     torch.cuda.empty_cache()
@@ -177,6 +183,115 @@ def case_c5(rank_counts, n):
     return result
 
 
+def case_graphguard(ranks):
+    """a re-expansion whose launch sequence contains a ghost exchange must NOT be captured into a
+    hipGraph, whatever AKS_GRAPH / AKS_GRAPH_COMM ask for (round 3: capturing the grouped send / recv forked onto the
+    communicator's side stream ended in a SIGSEGV with RCCL 2.26).  The guard sits in ArnoldiContext._expand_native; here
+    it is pinned: with both switches on, operators WITH an exchange run eager (no graph is ever built) and solve
+    correctly, an operator WITHOUT one (block-diagonal) still is allowed to replay.  Over the stand-in a capture that
+    did include an exchange would fail loudly (it synchronises streams), so a removed guard cannot pass this."""
+    import scipy.sparse as sp
+
+    import oracle
+    from arnoldi_amd import matrices, partial_schur
+    from thread_ranks import run_ranks
+
+    os.environ["AKS_GRAPH"] = "1"
+    os.environ["AKS_GRAPH_COMM"] = "1"
+    LR, LM = oracle.arg_largest_real, oracle.arg_largest_magnitude
+    Ar = matrices.random_csr(6000, 5, 1234, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5))
+    cases = {"mark50": (matrices.mark(50), 5, dict(max_dim=20, stopping_criterion=1e-8, sort_function=LR)),
+             "random_planted": (Ar, 5, dict(max_dim=20, sort_function=LM))}
+    want = {}
+    for name, (M, nev, kw) in cases.items():
+        np.random.seed(0)
+        v0 = np.random.randn(M.shape[0]).astype(C128)
+        v0 /= np.linalg.norm(v0)
+        Qo, To, ho = oracle.krylov_schur(M, nev, v0=v0, **kw)
+        want[name] = (v0, To, ho)
+
+    def rank_fn(comm, rank):
+        out = {}
+        for name, (M, nev, kw) in cases.items():
+            v0, To, ho = want[name]
+            st = {}
+            Q, T, hist = partial_schur(M, nev, comm=comm, v0=v0, stats=st, **kw)
+            ctx, op = st["solver"].ctx, st["solver"].op
+            _, _, rel = oracle.eig_residuals(M, Q, T)
+            out[name] = {"use_graph": bool(ctx.use_graph), "graphs_built": len(ctx._graphs), "any_exchange": bool(op.any_exchange),
+                         "native": bool(op.native_comm and op.c_driven), "restarts": int(st["restarts"]), "rel": float(rel.max()),
+                         "tol": float(st["tol"]), "hist_equal": bool(np.array_equal(hist.restarts, ho.restarts)),
+                         "eig_err": float(np.abs(np.diag(T) - np.diag(To)).max())}
+        return out
+
+    out = run_ranks(ranks, rank_fn)
+    del os.environ["AKS_GRAPH_COMM"]
+    os.environ["AKS_GRAPH"] = "0"
+    return {"ranks": out}
+
+
+def case_repro(ranks, n, repeats=3):
+    """The same sharded solve ``repeats`` times in one process: H after the initial expansion and after every restart
+    must be the SAME BITS every time (fixed-order reductions, rank-ordered all-reduces): where a run first departs from
+    the first one (which snapshot, which columns of H = which Arnoldi steps), and by how much.  This is the test that
+    found round 3's lost carried scale (k_colscale_after_truncate: a scalar load overtaken by the kernel's own vector
+    stores, a few restarts in a hundred at 2 ranks x 5M rows) -- a defect no small case had shown."""
+    import hashlib
+
+    from arnoldi_amd import matrices
+    from arnoldi_amd.dist import row_offsets
+    from arnoldi_amd.engine import CsrOperator
+    from arnoldi_amd.krylov_schur import KrylovSchurSolver
+    from arnoldi_amd.utils import arg_largest_magnitude, rand_normalized_vector
+    from thread_ranks import run_ranks
+
+    A = matrices.random_csr(n, 5, 1234, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5))
+    np.random.seed(0)
+    v0 = rand_normalized_vector(n, C128)
+    offs = row_offsets(n, ranks)
+    runs = []
+    for rep in range(repeats):
+        def rank_fn(comm, rank):
+            op = CsrOperator(local_rows=A[int(offs[rank]): int(offs[rank + 1])], offsets=offs, comm=comm)
+            s = KrylovSchurSolver(op, 5, 20, 10, 1.5e-8, arg_largest_magnitude, v0=v0, comm=comm)
+            Hs, info = [], []
+            s.start()
+            Hs.append(s.H.copy())
+            for r in range(6):
+                done = s.contract(r)
+                Hs.append(s.H.copy())
+                if done:
+                    break
+                s.expand()
+                Hs.append(s.H.copy())
+                c = s.ctx.last_ctrl
+                info.append((int(c.second_passes), int(c.steps_done), s.ctx.lazy_redos, s.ctx.deferred_expansions))
+            return Hs, info, [op.spmv_form, getattr(op.off, "form", None)]
+
+        out = run_ranks(ranks, rank_fn)
+        runs.append(out[0])
+        log(f"repro: run {rep} done, {len(out[0][0])} snapshots, info {out[0][1]}")
+    base = runs[0][0]
+    report = []
+    for rep in range(1, repeats):
+        first, worst = None, 0.0
+        for i, (a, b) in enumerate(zip(base, runs[rep][0])):
+            d = float(np.abs(a - b).max() / max(np.abs(a).max(), 1e-300))
+            worst = max(worst, d)
+            if d > 0 and first is None:
+                first = i
+        ev = lambda H: np.sort(np.abs(np.linalg.eigvals(H[:20, :20])))[::-1]        # noqa: E731
+        spec = [float(np.abs(ev(a) - ev(b)).max() / np.abs(ev(a)).max()) for a, b in zip(base, runs[rep][0])]
+        cols = None
+        if first is not None:                    # which COLUMNS of H (= which Arnoldi steps) differ in the first bad snapshot
+            a, b = base[first], runs[rep][0][first]
+            cols = [float(np.abs(a[:, j] - b[:, j]).max() / max(np.abs(a[:, j]).max(), 1e-300)) for j in range(a.shape[1])]
+        report.append({"run": rep, "first_differing_snapshot": first, "max_rel_diff": worst, "snapshots": len(base),
+                       "spectrum_rel_diff_per_snapshot": spec, "column_rel_diff_in_first_bad_snapshot": cols})
+    return {"ranks": ranks, "n": n, "forms": runs[0][2], "info": runs[0][1], "report": report,
+            "sha": [hashlib.sha256(np.ascontiguousarray(r[0][-1]).tobytes()).hexdigest()[:12] for r in runs]}
+
+
 def case_bench(ranks, rows, steps, warmup, leg_rows):
     """bench.py's rank logic on thread ranks: ``measure`` per rank, ``headline`` on rank 0 (+ the sharded legs)."""
     import bench
@@ -206,7 +321,7 @@ def case_bench(ranks, rows, steps, warmup, leg_rows):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--case", required=True, choices=["c4", "c5", "bench"])
+    ap.add_argument("--case", required=True, choices=["c4", "c5", "bench", "graphguard", "repro"])
     ap.add_argument("--ranks", type=int, default=8)
     ap.add_argument("--rows", type=int, default=None, help="shrink the problem (local rehearsals); default = BASELINE size")
     ap.add_argument("--steps", type=int, default=3)
@@ -226,6 +341,10 @@ def main():
         res = case_c4(a.ranks, dims)
     elif a.case == "c5":
         res = case_c5([a.ranks, 2] if a.ranks != 2 else [2], a.rows or 10_000_000)
+    elif a.case == "repro":
+        res = case_repro(a.ranks, a.rows or 10_000_000)
+    elif a.case == "graphguard":
+        res = case_graphguard(a.ranks)
     else:
         res = case_bench(a.ranks, a.rows or 10_000_000, a.steps, a.warmup, a.leg_rows)
     res["wall_s"] = round(time.perf_counter() - T0, 1)
