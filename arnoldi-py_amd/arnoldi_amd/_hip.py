@@ -217,13 +217,13 @@ def device_init(index):
     layer remembers which devices have had the dynamic-LDS limit of the large-LDS kernels raised."""
     if index in _devices_ready:
         return
-    import torch
+    from . import mem
 
     lib = load()                     # (takes _lock itself: not inside the device lock below)
     with _device_lock:
         if index in _devices_ready:
             return
-        with torch.cuda.device(index):
+        with mem.device_ctx(index):
             check(lib.aks_device_init(), "aks_device_init")
         _devices_ready.add(index)
 

@@ -1,7 +1,7 @@
 """Device-resident state of one row shard: CSR blocks, Krylov basis, workspace.
 
-torch is used for exactly three things: HBM allocations, the current HIP stream,
-and (in ``dist.py``) ``torch.distributed``.  All arithmetic goes through the C ABI
+Memory, streams and events come from ``mem.py`` -- torch tensors by default, or raw HIP allocations through ctypes
+(``AKS_HOST_ALLOC=hip``: no torch in the process at all).  All arithmetic goes through the C ABI
 of ``libarnoldi_hip.so`` (``_hip.py``); nothing here computes on the CPU.
 """
 from __future__ import annotations
@@ -12,22 +12,21 @@ import threading
 
 import numpy as np
 import scipy.sparse as sp
-import torch
 
-from . import _hip
+from . import _hip, mem
 
 C128 = np.complex128
 ETA_DGKS = float(np.sqrt(0.5))  # reference: src/arnoldi/ortho.py:6
 
 
 def _require_gpu(device):
-    if not torch.cuda.is_available():
+    if not mem.gpu_available():
         raise _hip.HipLibraryError(
             "no HIP device visible: arnoldi_amd runs its hot path on an MI355X only "
             "(there is no CPU fallback)"
         )
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    _hip.device_init(device.index if device.index is not None else torch.cuda.current_device())
+    device = mem.as_device(device)
+    _hip.device_init(device.index if device.index is not None else mem.current_device())
     return device
 
 
@@ -46,7 +45,7 @@ def _stream():
     cached = getattr(_tls, "stream", None)
     if cached is not None:
         return cached
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(mem.stream_ptr())
 
 
 class cached_stream:
@@ -118,10 +117,10 @@ class DeviceCSR:
         _hip.check(nt, "aks_csr_plan_tiles")
         self.n_tiles = int(nt)
         self.lanes_per_row = lanes_per_row or choose_lanes_per_row(self.n_rows, self.nnz)
-        self.indptr = torch.from_numpy(indptr).to(device)
-        self.indices = torch.from_numpy(np.ascontiguousarray(M.indices, dtype=np.int32)).to(device)
-        self.values = torch.from_numpy(np.ascontiguousarray(M.data)).to(device)
-        self.tiles = torch.from_numpy(tiles[: self.n_tiles + 1].copy()).to(device)
+        self.indptr = mem.upload(indptr, device)
+        self.indices = mem.upload(np.ascontiguousarray(M.indices, dtype=np.int32), device)
+        self.values = mem.upload(np.ascontiguousarray(M.data), device)
+        self.tiles = mem.upload(tiles[: self.n_tiles + 1].copy(), device)
 
         self._host = M            # kept until the SpMV form has been chosen (autotune)
         self.binned = None        # BinnedCSR once built
@@ -230,19 +229,19 @@ class DeviceCSR:
             elif not measure:
                 choice = forms[1]
         if choice is None:
-            x = torch.zeros(self.n_cols, dtype=torch.complex128, device=self.device)
-            y = torch.empty(self.n_rows, dtype=torch.complex128, device=self.device)
+            x = mem.zeros(self.n_cols, mem.c128, self.device)
+            y = mem.empty(self.n_rows, mem.c128, self.device)
             times = {}
             for form in forms:                 # two warm-up launches, then the fastest of 2 * reps timed ones
                 self.form = form
                 self.spmv(x, y, real=real)
                 self.spmv(x, y, real=real)
-                marks = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps + 1)]
+                marks = [mem.Event(enable_timing=True) for _ in range(2 * reps + 1)]
                 marks[0].record()
                 for e in marks[1:]:
                     self.spmv(x, y, real=real)
                     e.record()
-                torch.cuda.synchronize()
+                mem.synchronize()
                 times[form] = min(a.elapsed_time(b) for a, b in zip(marks, marks[1:]))
             self.tune_ms = times
             choice = "csr"
@@ -266,8 +265,8 @@ class DeviceCSR:
         real vectors (float64 tensors, or real-packed complex128 columns: two rows per slot)."""
         for t, need in ((x, self.n_cols), (y, self.n_rows)):   # raw addresses (hot loop) skip the checks
             if not isinstance(t, int):
-                have = t.numel() * (2 if (real and t.dtype == torch.complex128) else 1)
-                assert t.dtype == torch.complex128 or (real and t.dtype == torch.float64)
+                have = t.numel() * (2 if (real and t.dtype == mem.c128) else 1)
+                assert t.dtype == mem.c128 or (real and t.dtype == mem.f64)
                 assert have >= need and t.is_contiguous()
         wsp = _ptr(ws.buf) if ws is not None else C.c_void_p(0)
         lib = _hip.load()
@@ -307,7 +306,7 @@ class SlicedCSR:
         val = np.empty(max(nnz_pad, 1), values.dtype)
         _hip.check(lib.aks_sell_plan_fill(indptr.ctypes.data, indices.ctypes.data, values.ctypes.data, cplx, n_rows,
                                           slice_ptr.ctypes.data, col.ctypes.data, val.ctypes.data), "aks_sell_plan_fill")
-        self.slice_ptr, self.col, self.val = (torch.from_numpy(a).to(device) for a in (slice_ptr, col, val))
+        self.slice_ptr, self.col, self.val = (mem.upload(a, device) for a in (slice_ptr, col, val))
         self.padding = nnz_pad / max(int(M.nnz), 1)
         d = _hip.SellMatrix()
         d.n_rows, d.n_cols, d.nnz, d.nnz_pad, d.n_slices = n_rows, n_cols, int(M.nnz), nnz_pad, n_slices
@@ -349,10 +348,10 @@ class BinnedCSR:
         finally:
             lib.aks_pb_plan_destroy(plan)
         narrow = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32}     # torch has no unsigned 16/32
-        up = lambda a: torch.from_numpy(a.view(narrow.get(a.dtype, a.dtype))).to(device)  # noqa: E731
+        up = lambda a: mem.upload(a.view(narrow.get(a.dtype, a.dtype)), device)  # noqa: E731
         self.val, self.lcol, self.lrow, self.runs = up(val), up(lcol), up(lrow), up(runs)
         self.slab_begin, self.slab_end, self.rb_run_ptr = up(slab_begin), up(slab_end), up(rb_run_ptr)
-        self.prod = torch.zeros(int(sz.nnz_pad), dtype=torch.complex128, device=device)
+        self.prod = mem.zeros(int(sz.nnz_pad), mem.c128, device)
         self.n_slabs, self.n_rowblocks = int(sz.n_slabs), int(sz.n_rowblocks)
         rpr = _hip.PB_RUNS_PER_ROUND
         info = runs[:-rpr, 3]                                   # (the last round is the planner's empty one)
@@ -386,7 +385,7 @@ class Workspace:
         self.real = bool(real)      # real-packed panels: reductions drop the imaginary parts
         self.layout = _hip.workspace_layout(self.n_rows, self.max_dim)
         self.nbytes = int(self.layout.total_bytes)
-        self._raw = torch.empty(self.nbytes + 256, dtype=torch.uint8, device=device)
+        self._raw = mem.empty(self.nbytes + 256, mem.u8, device)
         skew = (-self._raw.data_ptr()) % 256
         self.buf = self._raw[skew: skew + self.nbytes]   # 256-byte aligned view
         assert self.buf.data_ptr() % 256 == 0
@@ -400,7 +399,7 @@ class Workspace:
             _hip.check(_hip.load().aks_workspace_set_real(_ptr(self.buf), 1, _stream()), "aks_workspace_set_real")
 
     def _slot(self, off, n_c128):
-        return self.buf[off: off + 16 * n_c128].view(torch.float64)
+        return self.buf[off: off + 16 * n_c128].view(mem.f64)
 
     def red(self, which, n_c128):
         """float64 view (2 doubles per complex) of reduction slot 1, 2 or 3 -- what a
@@ -433,8 +432,8 @@ class KrylovBasis:
         self.n_real = int(n_rows)
         self.n_rows, self.max_dim = ((int(n_rows) + 1) // 2 if real else int(n_rows)), int(max_dim)
         self.ldv = (self.n_rows + 63) // 64 * 64
-        self.V = torch.zeros((self.max_dim + 1, self.ldv), dtype=torch.complex128, device=device)
-        self.H = torch.zeros((self.max_dim + 1, self.max_dim), dtype=torch.complex128, device=device)
+        self.V = mem.zeros((self.max_dim + 1, self.ldv), mem.c128, device)
+        self.H = mem.zeros((self.max_dim + 1, self.max_dim), mem.c128, device)
         self.device = device
 
     def col(self, j):
@@ -451,7 +450,7 @@ class KrylovBasis:
         return buf.view(C128)
 
     def set_col(self, j, host_vec):
-        v = torch.from_numpy(self._pack(np.asarray(host_vec).reshape(1, -1))[0])
+        v = mem.host(self._pack(np.asarray(host_vec).reshape(1, -1))[0])
         self.V[j, : self.n_rows].copy_(v)
 
     def get_cols(self, j0, j1):
@@ -464,7 +463,7 @@ class KrylovBasis:
 
     def set_cols(self, j0, host_cols):
         a = self._pack(np.asarray(host_cols).T)
-        self.V[j0: j0 + a.shape[0], : self.n_rows].copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        self.V[j0: j0 + a.shape[0], : self.n_rows].copy_(mem.host(np.ascontiguousarray(a)))
 
     def download_H(self):
         return self.H.cpu().numpy()
@@ -548,7 +547,7 @@ class DeviceColumns:
         device = _require_gpu(device)
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
         self.ldv = (self.n_rows + 63) // 64 * 64
-        self.V = torch.zeros((self.n_cols, self.ldv), dtype=torch.complex128, device=device)
+        self.V = mem.zeros((self.n_cols, self.ldv), mem.c128, device)
         self.device = device
 
     def col(self, j):
@@ -556,7 +555,7 @@ class DeviceColumns:
 
     def set_cols(self, j0, host_cols):
         a = np.ascontiguousarray(np.asarray(host_cols, dtype=C128).T)
-        self.V[j0: j0 + a.shape[0], : self.n_rows].copy_(torch.from_numpy(a))
+        self.V[j0: j0 + a.shape[0], : self.n_rows].copy_(mem.host(a))
 
     def get_cols(self, j0=0, j1=None):
         j1 = self.n_cols if j1 is None else j1
@@ -571,7 +570,7 @@ def combine_columns(cols, j0, m, S, out=None):
     if out is None:
         out = DeviceColumns(cols.n_rows, q, cols.device)
     for c0 in range(0, q, 64):                        # column chunks keep S within the kernel's LDS budget
-        Sd = torch.from_numpy(np.ascontiguousarray(S[:, c0: c0 + 64])).to(cols.device)
+        Sd = mem.upload(np.ascontiguousarray(S[:, c0: c0 + 64]), cols.device)
         combine(cols.n_rows, m, cols.V.data_ptr() + 16 * cols.ldv * j0, cols.ldv, Sd,
                 out.V.data_ptr() + 16 * out.ldv * c0, out.ldv)
     return out
@@ -584,11 +583,11 @@ def fetch_H_and_ctrl(basis, ws):
     if not basis.V.is_cuda:                                   # CPU tensors (tests/fake_hip.py)
         return lambda: (basis.download_H(), ws.read_ctrl())
     if getattr(basis, "_H_pinned", None) is None:
-        basis._H_pinned = torch.empty(basis.H.shape, dtype=basis.H.dtype, pin_memory=True)
-        basis._ctrl_pinned = torch.empty(64, dtype=torch.uint8, pin_memory=True)
+        basis._H_pinned = mem.pinned_empty(tuple(basis.H.shape), basis.H.dtype)
+        basis._ctrl_pinned = mem.pinned_empty(64, mem.u8)
     basis._H_pinned.copy_(basis.H, non_blocking=True)
     basis._ctrl_pinned.copy_(ws.buf[:64], non_blocking=True)
-    ev = torch.cuda.Event()
+    ev = mem.Event()
     ev.record()
 
     def wait():

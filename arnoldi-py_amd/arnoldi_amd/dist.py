@@ -20,10 +20,27 @@ from __future__ import annotations
 
 import atexit
 
+import importlib
+
 import numpy as np
 import scipy.sparse as sp
-import torch
-import torch.distributed as dist
+
+
+class _Lazy:
+    """torch / torch.distributed, imported on first use: the partition helpers below are numpy only, and a process
+    that never makes a ``Comm`` (AKS_HOST_ALLOC=hip: one GPU, raw HIP allocations) never loads torch."""
+
+    def __init__(self, name):
+        self._name, self._mod = name, None
+
+    def __getattr__(self, attr):
+        if self._mod is None:
+            self._mod = importlib.import_module(self._name)
+        return getattr(self._mod, attr)
+
+
+torch = _Lazy("torch")
+dist = _Lazy("torch.distributed")
 
 
 # --------------------------------------------------------------------------- partition

@@ -22,9 +22,8 @@ import gc
 import os
 
 import numpy as np
-import torch
 
-from . import _hip, device as dev
+from . import _hip, device as dev, mem
 from .dist import Comm, row_offsets, split_local_rows
 
 C128 = np.complex128
@@ -101,11 +100,11 @@ class CsrOperator:
         send_idx = (np.concatenate(asked) - self.r0).astype(np.int32) if sum(self.send_counts) else np.zeros(0, np.int32)
         assert send_idx.size == 0 or (send_idx.min() >= 0 and send_idx.max() < self.n_local)
         d = self.diag.device
-        self.send_idx = torch.from_numpy(send_idx).to(d)
+        self.send_idx = mem.upload(send_idx, d)
         self.n_send = int(send_idx.size)
-        vec_dtype = torch.float64 if self.real else torch.complex128
-        self.sendbuf = torch.zeros(max(self.n_send, 1), dtype=vec_dtype, device=d)
-        self.ghostbuf = torch.zeros(max(self.n_ghost, 1), dtype=vec_dtype, device=d)
+        vec_dtype = mem.f64 if self.real else mem.c128
+        self.sendbuf = mem.zeros(max(self.n_send, 1), vec_dtype, d)
+        self.ghostbuf = mem.zeros(max(self.n_ghost, 1), vec_dtype, d)
         self.any_exchange = bool(sum(comm.allgather_int64([self.n_send + self.n_ghost])[r][0]
                                      for r in range(world)))
         self._build_shard()
@@ -178,8 +177,8 @@ class CsrOperator:
         if self.n_send:
             (dev.gather_f64 if real else dev.gather_c128)(self.n_send, self.send_idx, x, self.sendbuf)
         handle = self.comm.alltoallv_start(
-            self.sendbuf.view(torch.float64)[: w * self.n_send], self.send_counts,
-            self.ghostbuf.view(torch.float64)[: w * self.n_ghost], self.recv_counts, words=w)
+            self.sendbuf.view(mem.f64)[: w * self.n_send], self.send_counts,
+            self.ghostbuf.view(mem.f64)[: w * self.n_ghost], self.recv_counts, words=w)
         self.diag.spmv(x, y, False, ws, real)    # overlaps the exchange
         self.comm.alltoallv_finish(handle)
         if self.off is not None:
@@ -202,7 +201,7 @@ class HostOperator:
     def apply(self, x, y, ws=None):
         hx = x[: self.n].cpu().numpy()
         hy = np.asarray(self.A @ hx, dtype=C128).reshape(-1)
-        y[: self.n].copy_(torch.from_numpy(np.ascontiguousarray(hy)))
+        y[: self.n].copy_(mem.host(np.ascontiguousarray(hy)))
 
 
 class NullOperator:
@@ -257,6 +256,8 @@ class ArnoldiContext:
         # 2-D Laplace n = 1M: 50 / 119 restarts/s eager in a cold / warm process, 125 replayed in both)
         mode = os.environ.get("AKS_GRAPH", "auto")
         self.use_graph = mode == "1" or (mode == "auto" and getattr(op, "n_local", 1 << 62) <= 4_000_000)
+        if mem.BACKEND != "torch":
+            self.use_graph = False      # (capture and replay go through torch's hipGraph API)
         self._graphs = {}
         # look-ahead operator application (see expand): off with AKS_LOOKAHEAD=0
         self.allow_lookahead = os.environ.get("AKS_LOOKAHEAD", "1") != "0"
@@ -426,6 +427,8 @@ class ArnoldiContext:
         key = (start, end, float(tol), float(eta), w_ready, lazy, defer)
         graph_ok = not op.native_comm or (os.environ.get("AKS_GRAPH_COMM", "0") == "1" and not op.any_exchange)
         if self.use_graph and self.probe is None and start > 0 and graph_ok and b.V.is_cuda:
+            import torch
+
             g = self._graphs.get(key)
             if g is None:
                 g = torch.cuda.CUDAGraph()
@@ -457,7 +460,7 @@ class ArnoldiContext:
                 if w_ready and j == start:
                     pass                           # w = A V[:, start] was applied ahead of time
                 elif self.spmv_events is not None:   # bench.py: device time of the sharded SpMV
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0, e1 = mem.Event(enable_timing=True), mem.Event(enable_timing=True)
                     e0.record()
                     op.apply(x, w, ws)
                     e1.record()
@@ -510,11 +513,11 @@ class ArnoldiContext:
         b = self.basis
         Q = np.ascontiguousarray(Q, dtype=C128)
         if not b.V.is_cuda or os.environ.get("AKS_COEF_UPLOAD") == "sync":     # CPU tensors (tests/fake_hip.py); A/B
-            return torch.from_numpy(Q).to(b.device)
+            return mem.upload(Q, b.device)
         if self._coef_stage is None or self._coef_stage[0].numel() < Q.size:
             cap = max(Q.size, self.max_dim * self.max_dim)
-            self._coef_stage = [torch.empty(cap, dtype=torch.complex128, pin_memory=True) for _ in range(2)]
-            self._coef_dev = [torch.empty(cap, dtype=torch.complex128, device=b.device) for _ in range(2)]
+            self._coef_stage = [mem.pinned_empty(cap, mem.c128) for _ in range(2)]
+            self._coef_dev = [mem.empty(cap, mem.c128, b.device) for _ in range(2)]
         self._coef_turn ^= 1
         stage, out = self._coef_stage[self._coef_turn], self._coef_dev[self._coef_turn]
         stage[: Q.size].numpy()[:] = Q.reshape(-1)
@@ -598,7 +601,7 @@ class ArnoldiContext:
             total = 0.0
             for col, coef in ((0, (lam.real, -lam.imag)), (1, (lam.imag, lam.real))):
                 self.op.apply(pair.col(col), y, ws)
-                red1.copy_(torch.tensor([coef[0], 0.0, coef[1], 0.0], dtype=torch.float64, device=b.device))
+                red1.copy_(mem.host(np.array([coef[0], 0.0, coef[1], 0.0], dtype=np.float64)))
                 _hip.check(lib.aks_gs_update_project(b.n_rows, 2, dev._ptr(pair.V), pair.ldv, dev._ptr(y), *args),
                            "aks_gs_update_project")
                 if self._multi():
@@ -648,7 +651,7 @@ class ArnoldiContext:
         column k.  (Its second effect, ``V[:, k+1] = V[:, m]``, lands in a column the next expansion
         recomputes.)"""
         b = self.basis
-        Sd = torch.from_numpy(np.ascontiguousarray(np.asarray(s, dtype=C128).reshape(m - k, 1))).to(b.device)
+        Sd = mem.upload(np.ascontiguousarray(np.asarray(s, dtype=C128).reshape(m - k, 1)), b.device)
         self._need_normalised(m, "ritz_vector_into_first")
         rc = _hip.load().aks_truncate(b.n_rows, m - k, 1, b.V.data_ptr() + 16 * b.ldv * k, b.ldv,
                                       dev._ptr(Sd), dev._stream())
@@ -662,7 +665,7 @@ class ArnoldiContext:
         q = S.shape[1]
         assert 1 <= q <= m - k
         self._need_normalised(m, "ritz_vectors_into_first")
-        Sd = torch.from_numpy(S).to(b.device)
+        Sd = mem.upload(S, b.device)
         rc = _hip.load().aks_truncate(b.n_rows, m - k, q, b.V.data_ptr() + 16 * b.ldv * k, b.ldv,
                                       dev._ptr(Sd), dev._stream())
         _hip.check(rc, "aks_truncate")
@@ -703,10 +706,10 @@ class ArnoldiContext:
         if block is self.basis:
             self._need_normalised(j0 + len(values), "residual_norms")
         self._clear_ctrl()
-        lam = torch.from_numpy(values).to(b.device).view(torch.float64)
+        lam = mem.upload(values, b.device).view(mem.f64)
         y = self._scratch_col()
         red1, red2 = ws.red(1, 1), ws.red(2, 2)
-        out = torch.zeros(len(values), dtype=torch.float64, device=b.device)
+        out = mem.zeros(len(values), mem.f64, b.device)
         for i in range(len(values)):
             u = block.col(j0 + i)
             self.op.apply(u, y, ws)
@@ -715,7 +718,7 @@ class ArnoldiContext:
                                                  ws.nbytes, ws.max_dim, dev._stream()), "aks_gs_update_project")
             if self._multi():
                 self.comm.allreduce_sum_(red2)
-            out[i] = red2[2]
+            out[i: i + 1].copy_(red2[2: 3])
         return np.sqrt(out.cpu().numpy())
 
     def combine(self, j0, m, S, out=None):
@@ -733,6 +736,10 @@ class ArnoldiContext:
 
 def default_comm():
     """Comm over the default process group when torch.distributed is up with > 1 rank."""
+    import sys
+
+    if "torch.distributed" not in sys.modules:          # nobody can have initialised what was never imported
+        return None
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

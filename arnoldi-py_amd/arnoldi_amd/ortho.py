@@ -7,9 +7,8 @@ update + re-projection, conditional second update, finish).
 from __future__ import annotations
 
 import numpy as np
-import torch
 
-from . import device as dev
+from . import device as dev, mem
 
 C128 = np.complex128
 M_SQRT1_2 = dev.ETA_DGKS
@@ -27,7 +26,7 @@ def dgks_gs(w, V, h, tol=1e-8, eta=M_SQRT1_2, *, info=None):
     ws = dev.Workspace(n, J)
     basis.set_cols(0, V)
     basis.set_col(J, w)
-    hdev = torch.zeros(J + 1, dtype=torch.complex128, device=basis.device)
+    hdev = mem.zeros(J + 1, mem.c128, basis.device)
     dev.dgks_gs_device(basis, J, basis.col(J), hdev.data_ptr(), 1, float(tol), ws, float(eta),
                        normalize=False)
     ctrl = ws.read_ctrl()

@@ -22,11 +22,13 @@
 //                   so the panel is read once instead of twice.   (ortho.py:96-98,102)
 //   k_update_proj_split<NQ>  the same for wide panels: the J columns are dealt to the 4
 //                   waves of a block, partial updates meet in LDS.
-//   k_update<true>  second DGKS pass  w -= V h + ||w||^2, predicated on the device.
-//                                                       (ortho.py:101, 104-105)
+//   k_update<true>  second DGKS pass  w -= V h + ||w||^2, predicated on the device.  When no n-sized normalisation
+//                   follows (deferred normalisation) it also BOOKS the step -- H column, beta, breakdown, counters:
+//                   workgroup 0 when the pass is not needed, the last workgroup to finish (ticket) when it is -- so
+//                   neither k_reduce<true> nor k_finish is launched (round 4).   (ortho.py:101, 104-105)
 //   k_reduce        deterministic second stage of the block partial sums.
-//   k_finish        H column, beta, breakdown test, w /= beta.
-//                                                       (ortho.py:95,103,107; decomposition.py:61-66)
+//   k_finish        H column, beta, breakdown test, w /= beta  (the n-sized normalisation pass, and the book-keeping
+//                   when the second-pass kernel did not do it).    (ortho.py:95,103,107; decomposition.py:61-66)
 //   k_truncate_mfma<MT,NS>  V[:, :p] = V[:, :m] Qp in place on v_mfma_f64_16x16x4_f64 (one wave owns
 //                   16 NS rows), V[:, p] = V[:, m].     (krylov_schur.py:78,81)
 //   host side       aks_shard_apply / aks_arnoldi_expand chain these per Arnoldi step; with an RCCL

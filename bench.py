@@ -540,7 +540,9 @@ def pmc_ortho_traffic(res, args, world=1):
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
         m, p, n_panel, fs = res["m"], res["p"], res["n_panel"], res["frac_second"]
-        steps = pmc["k_finish"]["launches"]
+        # one second-pass launch (k_update<true>, usually an immediate exit) per Gram-Schmidt step in every schedule;
+        # k_finish is no longer launched when normalisation is deferred (the second-pass kernel books the step)
+        steps = pmc["k_update"]["launches"]
         if steps < m or (steps - m) % (m - p):
             return None, None, f"profiles/{name}: {steps} steps are not an initial expansion plus whole re-expansions"
         re_exp = (steps - m) // (m - p)

@@ -252,6 +252,8 @@ int aks_sell_spmv(const aks_sell_matrix *A, const aks_c128 *d_x, aks_c128 *d_y, 
  *                         beta -> ctrl; breakdown = beta < tol;
  *                         if normalize != 0 and no breakdown, the caller's next two
  *                         lines too: H[J, j] = beta and w /= beta              (decomposition.py:61-66)
+ * Chained inside the library (aks_dgks_gs, aks_arnoldi_expand) the last two stages are ONE launch whenever no n-sized
+ * normalisation follows (normalize 0, or 2 = deferred): the second-pass kernel books the step itself (ABI 4).
  */
 int aks_gs_project(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64_t ldv,
                    const aks_c128 *d_w, void *d_ws, int64_t ws_bytes, int32_t max_dim, void *stream);

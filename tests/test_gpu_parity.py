@@ -992,6 +992,31 @@ def test_rccl_collectives_one_rank(amd, tmp_path):
         assert o[k]["native_comm"] and o[k]["eig_err"] < 1e-7 and o[k]["rel"] < 1e-7, (k, o[k])
 
 
+def test_solves_without_torch_in_the_process(tmp_path):
+    """AKS_HOST_ALLOC=hip (arnoldi_amd/mem.py): device memory, stream, events and pinned staging straight from the HIP
+    runtime through ctypes -- the drop-in then needs numpy + scipy like the reference (VERDICT r03
+    item 8).  In a fresh process: BASELINE config 1 and the smoke solve's binned / deferred case with the reference's
+    History, real-packed mode, explicit restarts with deflation, device-side residuals -- and torch never imported."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    out = os.path.join(tmp_path, "hip_alloc.json")
+    env = dict(os.environ, AKS_HOST_ALLOC="hip")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hip_alloc_worker.py"), out], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    r = json.load(open(out))
+    assert r["backend"] == "hip" and r["torch_imported"] is False
+    m = r["mark50"]
+    assert m["hist_equal"] and m["eig_err"] < 1e-9 and m["rel"] <= max(1.05 * m["rel_oracle"], 1e-13) and m["device_residual_err"] < 1e-12, m
+    b = r["binned"]
+    assert b["hist_equal"] and b["form"] == "binned" and b["deferred"] > 0 and b["rel"] <= max(1.05 * b["rel_oracle"], 1e-13), b
+    assert r["real"]["rel"] < 1e-7 and r["real"]["eig_err"] < 1e-7 and r["deflation"]["hist_equal"] and r["deflation"]["eig_err"] < 1e-9, r
+
+
 def test_graph_replay_gives_identical_results(amd, monkeypatch):
     """Opt-in hipGraph replay of the re-expansion (AKS_GRAPH=1): bit-identical Q, T and History."""
     from arnoldi_amd.matrices import mark
