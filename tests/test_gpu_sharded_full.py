@@ -99,7 +99,7 @@ def test_config5_random_10m_planted_eight_and_two_ranks(tmp_path):
 def test_bench_eight_ranks_full_size_line(tmp_path):
     """``bench.py``'s rank logic (measure -> headline) with 8 ranks at n = 10M: the line the driver's --gpus 8 run prints,
     with the exchange block and rank 0's per-SpMV device-time split."""
-    out = _worker(tmp_path, "bench", ["--steps", "3", "--warmup", "1"])
+    out = _worker(tmp_path, "bench", ["--steps", "3", "--warmup", "1", "--leg-rows", "0"])
     assert out["n_gpus"] == 8 and out["config"]["n"] == 10_000_000 and out["value"] > 0
     assert "issued from C" in out["config"]["path"] and out["config"]["parallelism"] == "row-sharded x8"
     ex = out["config"]["exchange"]
@@ -108,7 +108,16 @@ def test_bench_eight_ranks_full_size_line(tmp_path):
     assert all(split[k] is not None and split[k] > 0 for k in ("pack", "exchange", "diag_block", "ghost_wait_plus_offdiag_block"))
     assert out["data"].startswith("rehearsal")
     assert out["roofline"]["launches"] == 3 * 9 and out["roofline_ortho"]["launch_groups"] == 3 * 10     # (a restart's first product is the look-ahead one)
-    print("bench x8 rehearsal:", out["value"], "restarts/s;", split)
+    # ... and the sharded legs of N > 1 at THEIR full sizes: Markov n = 10M (ghosts: a few grid lines), the 3-D Laplacian of
+    # config 4 in z-slabs (one 252 x 253 plane per neighbour), the headline matrix real-packed (8 instead of 16 bytes per entry)
+    legs = {leg["name"]: leg for leg in out["workloads"]}
+    assert set(legs) == {"markov", "laplace3d", "random_real_packed"}
+    assert all(leg["restarts_per_s"] > 0 and leg["path"].startswith("C-driven") and leg["n_gpus"] == 8 for leg in legs.values())
+    assert legs["markov"]["n"] > 10_000_000 and legs["markov"]["exchange"]["ghost_bytes_received_per_spmv_rank0"] < 200_000
+    assert legs["laplace3d"]["n"] == 252 * 253 * 254 and legs["laplace3d"]["exchange"]["ghost_bytes_received_per_spmv_rank0"] == 16 * 252 * 253
+    assert legs["laplace3d"]["exchange"]["collectives_per_arnoldi_step"] == 4 and legs["laplace3d"]["second_pass_fraction"] > 0.9
+    assert legs["random_real_packed"]["exchange"]["ghost_bytes_received_per_spmv_rank0"] * 2 == ex["ghost_bytes_received_per_spmv_rank0"]
+    print("bench x8 rehearsal:", out["value"], "restarts/s;", split, {k: v["restarts_per_s"] for k, v in legs.items()})
 
 
 @pytest.mark.gpu

@@ -230,7 +230,7 @@ def case_graphguard(ranks):
     return {"ranks": out}
 
 
-def case_repro(ranks, n, repeats=3):
+def case_repro(ranks, n, repeats=3, workload="random", real=False):
     """The same sharded solve ``repeats`` times in one process: H after the initial expansion and after every restart
     must be the SAME BITS every time (fixed-order reductions, rank-ordered all-reduces): where a run first departs from
     the first one (which snapshot, which columns of H = which Arnoldi steps), and by how much.  This is the test that
@@ -245,15 +245,36 @@ def case_repro(ranks, n, repeats=3):
     from arnoldi_amd.utils import arg_largest_magnitude, rand_normalized_vector
     from thread_ranks import run_ranks
 
-    A = matrices.random_csr(n, 5, 1234, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5))
+    from arnoldi_amd.dist import slab_offsets
+    from arnoldi_amd.utils import arg_largest_real
+
+    nev, m, p, sort = 5, 20, 10, arg_largest_magnitude
+    if workload == "markov":
+        mm = int(round((2 * n) ** 0.5))
+        A, sort = matrices.mark(mm), arg_largest_real
+        n = A.shape[0]
+        offs = row_offsets(n, ranks)
+    elif workload == "laplace3d":
+        nx = int(round(n ** (1.0 / 3.0)))
+        dims = (nx, nx + 1, nx + 2)
+        A = matrices.laplace3d(*dims)
+        n = A.shape[0]
+        offs, nev, m, p = slab_offsets(dims, ranks), 10, 40, 15
+    else:
+        A = matrices.random_csr(n, 5, 1234, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5))
+        offs = row_offsets(n, ranks)
     np.random.seed(0)
-    v0 = rand_normalized_vector(n, C128)
-    offs = row_offsets(n, ranks)
+    v0 = rand_normalized_vector(n, np.float64 if real else C128)
     runs = []
     for rep in range(repeats):
         def rank_fn(comm, rank):
-            op = CsrOperator(local_rows=A[int(offs[rank]): int(offs[rank + 1])], offsets=offs, comm=comm)
-            s = KrylovSchurSolver(op, 5, 20, 10, 1.5e-8, arg_largest_magnitude, v0=v0, comm=comm)
+            op = CsrOperator(local_rows=A[int(offs[rank]): int(offs[rank + 1])], offsets=offs, comm=comm, real=real)
+            if real:
+                from arnoldi_amd.krylov_schur_real import RealKrylovSchurSolver
+
+                s = RealKrylovSchurSolver(op, nev, m, p, 1.5e-8, sort, v0=v0, comm=comm)
+            else:
+                s = KrylovSchurSolver(op, nev, m, p, 1.5e-8, sort, v0=v0, comm=comm)
             Hs, info = [], []
             s.start()
             Hs.append(s.H.copy())
@@ -280,7 +301,7 @@ def case_repro(ranks, n, repeats=3):
             worst = max(worst, d)
             if d > 0 and first is None:
                 first = i
-        ev = lambda H: np.sort(np.abs(np.linalg.eigvals(H[:20, :20])))[::-1]        # noqa: E731
+        ev = lambda H: np.sort(np.abs(np.linalg.eigvals(H[:m, :m])))[::-1]        # noqa: E731
         spec = [float(np.abs(ev(a) - ev(b)).max() / np.abs(ev(a)).max()) for a, b in zip(base, runs[rep][0])]
         cols = None
         if first is not None:                    # which COLUMNS of H (= which Arnoldi steps) differ in the first bad snapshot
@@ -299,10 +320,10 @@ def case_bench(ranks, rows, steps, warmup, leg_rows):
 
     bench.GPU = True
     argv = ["--gpus", str(ranks), "--rows", str(rows), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline"]
-    if leg_rows is not None:
-        argv += ["--leg-rows", str(leg_rows)]
-    else:
+    if leg_rows is None:
         argv += ["--no-workloads"]
+    elif leg_rows > 0:
+        argv += ["--leg-rows", str(leg_rows)]           # (0: the legs at their BASELINE sizes)
     args = bench.parse_args(argv)
 
     def rank_fn(comm, rank):
@@ -327,6 +348,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--leg-rows", type=int, default=None)
+    ap.add_argument("--workload", default="random", choices=["random", "markov", "laplace3d"])
+    ap.add_argument("--real", action="store_true")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch
@@ -342,7 +365,7 @@ def main():
     elif a.case == "c5":
         res = case_c5([a.ranks, 2] if a.ranks != 2 else [2], a.rows or 10_000_000)
     elif a.case == "repro":
-        res = case_repro(a.ranks, a.rows or 10_000_000)
+        res = case_repro(a.ranks, a.rows or 10_000_000, workload=a.workload, real=a.real)
     elif a.case == "graphguard":
         res = case_graphguard(a.ranks)
     else:
