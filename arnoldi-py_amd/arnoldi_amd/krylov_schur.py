@@ -13,7 +13,7 @@ import scipy.linalg
 
 from .engine import ArnoldiContext, as_operator, default_comm
 from .history import History
-from .utils import arg_largest_magnitude, host_blas_threads, rand_normalized_vector, reorder_schur
+from .utils import arg_largest_magnitude, complex_schur, host_blas_threads, rand_normalized_vector, reorder_schur
 
 WORK_DTYPE = np.complex128  # krylov_schur.py:38: complex128 whatever A.dtype is
 
@@ -53,8 +53,9 @@ class KrylovSchurSolver:
         # Ordered Schur form of the projected matrix (host, LAPACK).  The reference calls
         # zgees twice (krylov_schur.py:69 and utils.py:45); the second call sees an upper-
         # triangular matrix and returns (T, I) unchanged, so one call followed by the same
-        # ?trexc sequence gives the same (T, Q).
-        T, Q = scipy.linalg.schur(H[:m, :m], output="complex")
+        # ?trexc sequence gives the same (T, Q).  (complex_schur: zgees, or dgees while H is exactly real
+        # and its spectrum is -- a third of the time, utils.py.)
+        T, Q = complex_schur(H[:m, :m])
         T, Q = reorder_schur(T, Q, self.sort_function(np.diag(T)))
 
         # truncation on the device: V[:, :p] <- V[:, :m] Q[:, :p];  V[:, p] <- V[:, m]
@@ -83,7 +84,7 @@ class KrylovSchurSolver:
         H, m, nev = self.H, self.m, self.nev
         if m < nev:
             raise ValueError(f"Happy breakdown: invariant subspace of dimension {m} < nev = {nev}")
-        T, Q = scipy.linalg.schur(H[:m, :m], output="complex")
+        T, Q = complex_schur(H[:m, :m])
         T, Q = reorder_schur(T, Q, self.sort_function(np.diag(T)))
         self.ctx.truncate(Q[:, :nev], m, nev)
         H[:nev, :nev] = T[:nev, :nev]

@@ -30,7 +30,7 @@ import numpy as np
 import scipy.linalg
 
 from .krylov_schur import KrylovSchurSolver
-from .utils import reorder_schur
+from .utils import complex_schur, reorder_schur
 
 
 class LockingKrylovSchurSolver(KrylovSchurSolver):
@@ -47,7 +47,7 @@ class LockingKrylovSchurSolver(KrylovSchurSolver):
         booked = restart * (self.max_dim - nev) + (m - nev)          # as krylov_schur.py:63
 
         S = H[l:m, l:m]
-        T, Z = scipy.linalg.schur(S, output="complex")
+        T, Z = complex_schur(S)
         T, Z = reorder_schur(T, Z, self.sort_function(np.diag(T)))
         beta = H[m, m - 1]                                           # the residual row of H is beta e_m^T
         coupling = beta * Z[-1, :]

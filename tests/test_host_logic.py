@@ -897,3 +897,29 @@ def test_scalar_load_hazard_lint():
         pytest.skip("no hipcc here: the current tree cannot be compiled to ISA")
     now = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
     assert now.returncode == 0 and " 0 candidate hazard(s)" in now.stdout, now.stdout[-3000:] + now.stderr[-2000:]
+
+
+def test_complex_schur_takes_the_real_route_only_when_it_is_a_complex_schur_form(monkeypatch):
+    """utils.complex_schur: for an exactly real matrix with a real spectrum the real Schur form (dgees, a third of the
+    time of zgees) is triangular and is returned as the complex Schur form; 2 x 2 blocks or any imaginary part mean zgees."""
+    import scipy.linalg
+    from arnoldi_amd.utils import complex_schur
+
+    rng = np.random.default_rng(0)
+    S = rng.standard_normal((12, 12))
+    sym = (S + S.T).astype(np.complex128)                       # real spectrum
+    T, Z = complex_schur(sym)
+    assert T.dtype == Z.dtype == np.complex128 and not T.imag.any() and not Z.imag.any()
+    assert np.abs(np.tril(T, -1)).max() == 0.0
+    np.testing.assert_allclose(Z @ T @ Z.conj().T, sym, atol=1e-12)
+    np.testing.assert_allclose(Z.conj().T @ Z, np.eye(12), atol=1e-13)
+    np.testing.assert_allclose(np.sort(np.diag(T).real), np.linalg.eigvalsh(sym.real), rtol=1e-12)
+    rot = S.astype(np.complex128)                               # real, complex pairs: the real form has 2 x 2 blocks
+    Tz, Zz = scipy.linalg.schur(rot, output="complex")
+    T2, Z2 = complex_schur(rot)
+    np.testing.assert_array_equal(T2, Tz)
+    np.testing.assert_array_equal(Z2, Zz)
+    cplx = sym + 1e-3j * S                                      # not real: zgees
+    np.testing.assert_array_equal(complex_schur(cplx)[0], scipy.linalg.schur(cplx, output="complex")[0])
+    monkeypatch.setenv("AKS_REAL_SCHUR", "0")
+    np.testing.assert_array_equal(complex_schur(sym)[0], scipy.linalg.schur(sym, output="complex")[0])
