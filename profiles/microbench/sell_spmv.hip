@@ -59,6 +59,69 @@ __global__ __launch_bounds__(256) void k_sell(int64_t n_rows, const int64_t *__r
     if (row < n_rows) y[row] = make_double2(sr, si);
 }
 
+// Round 4: fewer, wider vector-memory instructions.  A vector-memory instruction costs a CU >= 21 cycles whatever it
+// loads (vmem_issue_cost.txt), and the entry-major layout spends one 4-byte and one 8-byte load per entry: 3 instructions
+// per entry with the gather.  Here the entries of a lane are stored in GROUPS of G consecutive k ([group][lane][G]): one
+// 16-byte load brings G = 4 columns, two bring 4 values (G = 2: one 8-byte + one 16-byte load) -- 7 instead of 12
+// instructions per 4 entries.  The W % G last entries of a slice stay entry-major.  Same summation order (k ascending).
+template <int G, int UG, bool NT>
+__global__ __launch_bounds__(256) void k_sell_grp(int64_t n_rows, const int64_t *__restrict__ slice_ptr,
+                                                 const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                 const c128 *__restrict__ x, c128 *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t per = (gridDim.x + 7) / 8;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int64_t slice = wg * 4 + (threadIdx.x >> 6);
+    const int64_t row = slice * 64 + lane;
+    if (slice * 64 >= n_rows) return;
+    const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
+    const int W = (int)((p1 - p0) >> 6);
+    const int ng = W / G;
+    double sr = 0.0, si = 0.0;
+    typedef int32_t ivec __attribute__((ext_vector_type(G)));
+    typedef double dvec __attribute__((ext_vector_type(G)));
+    const ivec *cg = reinterpret_cast<const ivec *>(col + p0) + lane;
+    const dvec *vg = reinterpret_cast<const dvec *>(val + p0) + lane;
+    int g = 0;
+    for (; g + UG <= ng; g += UG) {
+        ivec cc[UG];
+        dvec vv[UG];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            cc[u] = NT ? __builtin_nontemporal_load(&cg[(int64_t)(g + u) * 64]) : cg[(int64_t)(g + u) * 64];
+            vv[u] = NT ? __builtin_nontemporal_load(&vg[(int64_t)(g + u) * 64]) : vg[(int64_t)(g + u) * 64];
+        }
+        c128 xx[UG][G];
+#pragma unroll
+        for (int u = 0; u < UG; ++u)
+#pragma unroll
+            for (int e = 0; e < G; ++e) xx[u][e] = x[cc[u][e] >= 0 ? cc[u][e] : 0];
+#pragma unroll
+        for (int u = 0; u < UG; ++u)
+#pragma unroll
+            for (int e = 0; e < G; ++e)
+                if (cc[u][e] >= 0) { sr = fma(vv[u][e], xx[u][e].x, sr); si = fma(vv[u][e], xx[u][e].y, si); }
+    }
+    for (; g < ng; ++g) {
+        const ivec cc = cg[(int64_t)g * 64];
+        const dvec vv = vg[(int64_t)g * 64];
+#pragma unroll
+        for (int e = 0; e < G; ++e) {
+            const c128 xx = x[cc[e] >= 0 ? cc[e] : 0];
+            if (cc[e] >= 0) { sr = fma(vv[e], xx.x, sr); si = fma(vv[e], xx.y, si); }
+        }
+    }
+    const int32_t *c = col + p0 + (int64_t)ng * G * 64 + lane;           // entry-major tail
+    const double *v = val + p0 + (int64_t)ng * G * 64 + lane;
+    for (int k = 0; k < W - ng * G; ++k) {
+        const int32_t cc = c[(int64_t)k * 64];
+        const double vv = v[(int64_t)k * 64];
+        const c128 xx = x[cc >= 0 ? cc : 0];
+        if (cc >= 0) { sr = fma(vv, xx.x, sr); si = fma(vv, xx.y, si); }
+    }
+    if (row < n_rows) y[row] = make_double2(sr, si);
+}
+
 // Round 3: the same walk as a two-stage software pipeline.  Two register sets (A, B) of U entries alternate: the
 // gathers of one set are issued, THEN the (column, value) loads of the set after next go out, then the gathered
 // set is summed -- vmcnt counts in issue order, so waiting for the gathers leaves the 2 U younger stream loads in
@@ -213,6 +276,29 @@ static void run(const char *name, const Csr &A) {
     time_it([&] { hipLaunchKernelGGL((k_sell_ab<4, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "ab4 XCD nt");
     time_it([&] { hipLaunchKernelGGL((k_sell_ab<6, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "ab6 XCD nt");
     time_it([&] { hipLaunchKernelGGL((k_sell_ab<8, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "ab8 XCD nt");
+    // grouped layouts (G = 4, 2): [group][lane][G] for the W / G full groups of a slice, entry-major tail
+    for (int G : {4, 2}) {
+        std::vector<int32_t> colg(sp[ns], -1);
+        std::vector<double> valg(sp[ns], 0.0);
+        for (int64_t r = 0; r < n; ++r) {
+            const int64_t s0 = sp[r / 64], W = (sp[r / 64 + 1] - s0) / 64, ng = W / G, lane = r % 64;
+            for (int64_t k = A.ptr[r]; k < A.ptr[r + 1]; ++k) {
+                const int64_t kk = k - A.ptr[r];
+                const int64_t q = kk < ng * G ? s0 + ((kk / G) * 64 + lane) * G + kk % G : s0 + ng * G * 64 + (kk - ng * G) * 64 + lane;
+                colg[q] = A.idx[k]; valg[q] = A.val[k];
+            }
+        }
+        int32_t *d_cg = upload(colg); double *d_vg = upload(valg);
+        if (G == 4) {
+            time_it([&] { hipLaunchKernelGGL((k_sell_grp<4, 1, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_cg, d_vg, x, y); }, "g4 u1 nt");
+            time_it([&] { hipLaunchKernelGGL((k_sell_grp<4, 2, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_cg, d_vg, x, y); }, "g4 u2 nt");
+            time_it([&] { hipLaunchKernelGGL((k_sell_grp<4, 1, false>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_cg, d_vg, x, y); }, "g4 u1");
+        } else {
+            time_it([&] { hipLaunchKernelGGL((k_sell_grp<2, 2, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_cg, d_vg, x, y); }, "g2 u2 nt");
+            time_it([&] { hipLaunchKernelGGL((k_sell_grp<2, 4, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_cg, d_vg, x, y); }, "g2 u4 nt");
+        }
+        CK(hipFree(d_cg)); CK(hipFree(d_vg));
+    }
     // check against the host CSR product on a sample of rows
     std::vector<double> hy(2 * n);
     CK(hipMemcpy(hy.data(), y, n * 16, hipMemcpyDeviceToHost));
