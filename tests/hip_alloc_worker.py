@@ -25,6 +25,51 @@ def main(out_path):
     from arnoldi_amd.matrices import mark, random_csr
 
     res = {"backend": mem.BACKEND}
+    # the array layer itself against numpy: pitched 2-D views, row / block slices, strided copies in both directions,
+    # views, zeroing, pinned staging
+    dev = mem.as_device(None)
+    rng = np.random.default_rng(0)
+    host = (rng.standard_normal((7, 640)) + 1j * rng.standard_normal((7, 640))).astype(np.complex128)
+    a = mem.zeros((7, 640), mem.c128, dev)
+    want = np.zeros_like(host)
+    steps = {}
+    a[1:6, :600].copy_(mem.host(host[1:6, :600]))                              # host -> pitched block
+    want[1:6, :600] = host[1:6, :600]
+    steps["block_upload"] = np.array_equal(a.cpu().numpy(), want)
+    a[3].zero_()
+    want[3] = 0
+    a[0, :5].copy_(mem.host(host[0, :5]))
+    want[0, :5] = host[0, :5]
+    steps["row_zero_and_row_slice"] = np.array_equal(a.cpu().numpy(), want)
+    b = mem.empty((4, 100), mem.c128, dev)
+    b.copy_(a[2:6, 50:150])                                                    # strided device -> contiguous device
+    want_b = want[2:6, 50:150].copy()
+    steps["strided_to_contiguous"] = np.array_equal(b.cpu().numpy(), want_b) and np.array_equal(a.cpu().numpy(), want)
+    a[0:4, 10:110].copy_(b)                                                    # contiguous -> strided
+    want[0:4, 10:110] = want_b
+    steps["contiguous_to_strided"] = np.array_equal(a[0:4, 10:110].cpu().numpy(), want_b) and np.array_equal(a.cpu().numpy(), want)
+    a[4:6, 600:640].zero_()                                                    # 2-D memset
+    a[1:3, 0:8].zero_()
+    want[4:6, 600:640] = 0
+    want[1:3, 0:8] = 0
+    steps["block_zero"] = np.array_equal(a.cpu().numpy(), want)
+    flat = mem.upload(np.arange(32, dtype=np.float64), dev)
+    steps["flat_views"] = (flat.view(mem.c128).numel() == 16 and flat[5].item() == 5.0
+                           and flat[3:9].cpu().numpy().tolist() == [3, 4, 5, 6, 7, 8]
+                           and flat.view(mem.c128)[2:4].cpu().numpy().tolist() == [4 + 5j, 6 + 7j])
+    pin = mem.pinned_empty((4, 100), mem.c128)
+    pin.copy_(b, non_blocking=True)
+    ev = mem.Event()
+    ev.record()
+    ev.synchronize()
+    steps["pinned_download"] = np.array_equal(pin.numpy(), want_b)
+    pin.numpy()[:] = 1.5
+    b.copy_(pin, non_blocking=True)
+    mem.synchronize()
+    steps["pinned_upload"] = bool((b.cpu().numpy() == 1.5).all())
+    res["array_layer"] = {k: bool(v) for k, v in steps.items()}
+    ok = all(steps.values())
+    res["array_layer_ok"] = bool(ok)
     A = mark(50)
     kw = dict(max_dim=20, stopping_criterion=1e-8, sort_function=oracle.arg_largest_real)
     np.random.seed(0)

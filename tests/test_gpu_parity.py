@@ -1009,7 +1009,7 @@ def test_solves_without_torch_in_the_process(tmp_path):
                          timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     r = json.load(open(out))
-    assert r["backend"] == "hip" and r["torch_imported"] is False
+    assert r["backend"] == "hip" and r["torch_imported"] is False and r["array_layer_ok"], r.get("array_layer")
     m = r["mark50"]
     assert m["hist_equal"] and m["eig_err"] < 1e-9 and m["rel"] <= max(1.05 * m["rel_oracle"], 1e-13) and m["device_residual_err"] < 1e-12, m
     b = r["binned"]
