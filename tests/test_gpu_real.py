@@ -263,6 +263,7 @@ def test_real_arithmetic_deflate_and_residual_norms(amd, monkeypatch):
     # the same with every operator in the binned form: the expansions defer their normalisations, so the breakdown
     # happens among raw columns and the deflating compression folds their scales (complex and real drivers)
     monkeypatch.setenv("AKS_SPMV_FORM", "binned")
+    monkeypatch.setenv("AKS_DEFER_MAX_STEPS", "40")         # (the cases expand by 20 steps; the default defers up to 12)
     rc.check_deflate_real()
     rc.check_residual_norms_real()
 

@@ -177,6 +177,28 @@ def test_sequences_with_a_ghost_exchange_are_never_captured(tmp_path):
             assert c["hist_equal"] and c["eig_err"] < 1e-9 and c["rel"] <= max(50 * c["tol"], 1e-7), (name, c)
 
 
+@pytest.mark.gpu
+def test_breakdown_in_the_step_that_triggers_the_lazy_redo_with_raw_columns(tmp_path):
+    """Three ranks, deferred normalisation, ``on_breakdown="deflate"``, an invariant block whose six rows are spread
+    over the ranks: the breakdown step is the first to need a second DGKS pass, so the expansion runs twice (the third
+    all-reduce is only issued from then on) and both attempts stop among raw columns.  Complex and real-packed drivers:
+    the block's wanted eigenvalues, A Q = Q T, one restart, every rank the same bits (this combination
+    had no test)."""
+    r = _worker(tmp_path, "breakdown", ["--ranks", "3"], timeout=400)
+    rows = r["block_rows"]
+    assert rows[0] < r["n"] // 3 and rows[-1] >= 2 * (r["n"] // 3 + 1), rows           # more than one rank holds the block
+    for mode in ("complex", "real"):
+        c = r[mode]
+        assert c["T_bit_equal_across_ranks"] and c["Q_bit_equal_across_ranks"], mode
+        assert c["T_diff_vs_one_gpu"] < 1e-12, (mode, c["T_diff_vs_one_gpu"])
+        assert c["one_gpu"]["lazy_redos"] == 0 and c["one_gpu"]["deferred"] == 1 and c["one_gpu"]["broken"]
+        for o in c["sharded"] + [c["one_gpu"]]:
+            assert o["native"] and o["broken"] and o["n_iter"] == 6 and o["deferred"] == 1, (mode, o)
+            assert o["restarts"] == 1 and o["hist"] == [1, 1, 1], (mode, o)
+            assert o["eig_err"] < 1e-10 and o["res"] < 1e-10 and o["orth"] < 1e-12, (mode, o)
+        assert all(o["lazy_redos"] == 1 for o in c["sharded"]), (mode, c["sharded"])
+
+
 # ------------------------------------------------------------------------------------------------- CPU
 def test_thread_comm_hand_offs():
     """The in-process stand-ins for the set-up exchanges (what torch.distributed carries between rank processes):

@@ -313,6 +313,62 @@ def case_repro(ranks, n, repeats=3, workload="random", real=False):
             "sha": [hashlib.sha256(np.ascontiguousarray(r[0][-1]).tobytes()).hexdigest()[:12] for r in runs]}
 
 
+def case_breakdown(ranks):
+    """A happy breakdown in the FIRST step that needs a second DGKS pass, on the sharded C-driven path with deferred
+    normalisation: the lazily omitted third all-reduce makes the expansion run twice (``lazy_redos == 1``) and both
+    attempts break down among raw columns; the redo must start from an untouched column 0 and the deflating compression
+    must fold the scales of the columns that exist.  Complex and real-packed drivers, against the one-GPU solve and the
+    eigenvalues of the invariant block."""
+    import scipy.sparse as sp
+
+    from arnoldi_amd import partial_schur
+    from arnoldi_amd.utils import arg_largest_real
+    from thread_ranks import run_ranks
+
+    os.environ["AKS_SPMV_FORM"] = "binned"           # a form whose expansions defer (engine.CsrOperator.form_defers)
+    os.environ["AKS_DEFER_MAX_STEPS"] = "40"
+    rng = np.random.default_rng(9)
+    B = rng.standard_normal((6, 6))
+    Cc = sp.random(3000, 3000, density=0.002, random_state=np.random.RandomState(1)) + sp.eye(3000) * 3
+    A = sp.block_diag([sp.csr_matrix(B), Cc], format="csr")
+    n = A.shape[0]
+    perm = np.random.default_rng(3).permutation(n)   # spread the invariant block's six rows over the ranks
+    A = A[perm][:, perm].tocsr()
+    A.sort_indices()
+    where = np.argsort(perm)[:6]                     # new positions of the block's coordinates
+    want = np.linalg.eigvals(B)
+    want = want[np.argsort(-want.real)][:3]
+    res = {"n": n, "ranks": ranks, "block_rows": sorted(int(x) for x in where)}
+    for mode in ("complex", "real"):
+        v0 = np.zeros(n, np.float64 if mode == "real" else C128)
+        v0[where] = np.random.default_rng(10).standard_normal(6)
+        v0 /= np.linalg.norm(v0)
+
+        def solve(comm):
+            st = {}
+            Q, T, hist = partial_schur(A, 3, max_dim=12, v0=v0.copy(), on_breakdown="deflate", sort_function=arg_largest_real,
+                                       arithmetic=mode, stats=st, comm=comm)
+            ctx = st["solver"].ctx
+            got = np.linalg.eigvals(T)
+            return {"T": np.asarray(T).copy(), "Q": np.asarray(Q).copy(), "restarts": int(st["restarts"]), "hist": [int(x) for x in hist.restarts],
+                    "eig_err": float(max(np.abs(got[:, None] - want[None, :]).min(axis=1).max(),
+                                         np.abs(got[:, None] - want[None, :]).min(axis=0).max())),
+                    "res": float(np.linalg.norm(A @ Q - Q @ T)), "orth": float(np.abs(Q.conj().T @ Q - np.eye(3)).max()),
+                    "lazy_redos": int(ctx.lazy_redos), "deferred": int(ctx.deferred_expansions), "broken": bool(ctx.last_ctrl.broken),
+                    "n_iter": int(ctx.last_ctrl.n_iter), "native": bool(getattr(st["solver"].op, "c_driven", False))}
+
+        one = solve(None)
+        out = run_ranks(ranks, lambda comm, rank: solve(comm))
+        pick = lambda o: {k: v for k, v in o.items() if k not in ("T", "Q")}        # noqa: E731
+        res[mode] = {"one_gpu": pick(one), "sharded": [pick(o) for o in out],
+                     "T_bit_equal_across_ranks": bool(all(np.array_equal(o["T"], out[0]["T"]) for o in out)),
+                     "Q_bit_equal_across_ranks": bool(all(np.array_equal(o["Q"], out[0]["Q"]) for o in out)),
+                     "T_diff_vs_one_gpu": float(np.abs(np.sort_complex(np.linalg.eigvals(out[0]["T"]))
+                                                       - np.sort_complex(np.linalg.eigvals(one["T"]))).max())}
+    del os.environ["AKS_SPMV_FORM"], os.environ["AKS_DEFER_MAX_STEPS"]
+    return res
+
+
 def case_bench(ranks, rows, steps, warmup, leg_rows):
     """bench.py's rank logic on thread ranks: ``measure`` per rank, ``headline`` on rank 0 (+ the sharded legs)."""
     import bench
@@ -342,7 +398,7 @@ def case_bench(ranks, rows, steps, warmup, leg_rows):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--case", required=True, choices=["c4", "c5", "bench", "graphguard", "repro"])
+    ap.add_argument("--case", required=True, choices=["c4", "c5", "bench", "graphguard", "repro", "breakdown"])
     ap.add_argument("--ranks", type=int, default=8)
     ap.add_argument("--rows", type=int, default=None, help="shrink the problem (local rehearsals); default = BASELINE size")
     ap.add_argument("--steps", type=int, default=3)
@@ -368,6 +424,8 @@ def main():
         res = case_repro(a.ranks, a.rows or 10_000_000, workload=a.workload, real=a.real)
     elif a.case == "graphguard":
         res = case_graphguard(a.ranks)
+    elif a.case == "breakdown":
+        res = case_breakdown(a.ranks)
     else:
         res = case_bench(a.ranks, a.rows or 10_000_000, a.steps, a.warmup, a.leg_rows)
     res["wall_s"] = round(time.perf_counter() - T0, 1)
