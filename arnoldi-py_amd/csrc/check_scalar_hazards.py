@@ -14,8 +14,15 @@ later store of the same wave from reaching memory first.  ``k_colscale_after_tru
 How: per kernel, a linear walk over the instructions (branches ignored) that tracks which SGPRs / VGPRs hold addresses
 derived from which kernel-argument pointer (kernarg loads, s_mov, s_add_u32 / s_addc_u32, v_mov, v_add_co / v_addc,
 v_lshl_add_u64); a scalar data load from argument P while a vector store through P is possible later -- before the
-load's wait -- or earlier, is reported.  Heuristic by design: it names candidates for a human to read, and exits 1 if
-there are any.  Exit 0 = none.
+load's wait -- or earlier, is reported.
+
+Not every address can be followed to an argument (pointers read from memory, addresses built across branches), so the
+"store overtakes a pending load" half is also checked without roots: EVERY vector store issued while a scalar data load
+has not been waited for must be explained -- different arguments; or the very same, unmodified SGPR base pair with
+disjoint byte ranges (fields of one struct); anything else is reported as unresolved.  The summary line says how many
+such stores there are at all (a handful: the compiler normally waits for its scalar loads long before it stores).
+
+Heuristic by design: it names candidates for a human to read, and exits 1 if there are any.  Exit 0 = none.
 """
 import os
 import re
@@ -43,16 +50,36 @@ def regs(op):
     return None, []
 
 
+LOAD_BYTES = {"dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16, "dwordx8": 32, "dwordx16": 64}
+STORE_BYTES = {"byte": 1, "short": 2, "dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16}
+
+
+def store_bytes(op):
+    """Bytes a vector store / atomic touches, from its mnemonic (None if unknown)."""
+    tail = op.split("_")
+    if "atomic" in tail:
+        return 8 if tail[-1] in ("x2", "f64", "u64", "i64", "b64") else 4
+    return STORE_BYTES.get(tail[-1])
+
+
 def check_kernel(name, lines):
     findings = []
     sroot, vroot = {}, {}           # register index -> kernarg byte offset of the pointer it derives from
+    sver = {}                       # SGPR index -> how often it has been written (is a base pair still the same value?)
+    vzero = {}                      # VGPR index -> True while it holds the literal 0 (v_mov_b32 vN, 0)
     karg = None                     # first SGPR of the kernarg segment pointer
-    pending = []                    # scalar data loads not yet waited for: (root, line no, text)
+    pending = []                    # scalar data loads not yet waited for: dicts (root, line no, text, base, byte range)
     stored = {}                     # root -> line no of the first vector store through it
     stats = check_kernel.stats
 
     def root_of(kind, idx):
         return (sroot if kind == "s" else vroot).get(idx)
+
+    def base_key(idx):
+        return tuple((i, sver.get(i, 0)) for i in idx)
+
+    def imm(a):
+        return int(a, 0) if re.match(r"^(0x[0-9a-fA-F]+|\d+)$", a) else None
 
     for no, raw in lines:
         text = raw.split(";")[0].strip()
@@ -64,7 +91,8 @@ def check_kernel(name, lines):
         if op.startswith("s_load_") or op.startswith("s_buffer_load"):
             dk, dst = regs(args[0])
             bk, base = regs(args[1])
-            off = int(args[2], 0) if len(args) > 2 and re.match(r"^(0x[0-9a-fA-F]+|\d+)$", args[2]) else 0
+            off_imm = imm(args[2]) if len(args) > 2 else 0
+            off = off_imm or 0
             if karg is None and bk == "s":
                 karg = base[0]
             if bk == "s" and base and base[0] == karg:
@@ -72,6 +100,7 @@ def check_kernel(name, lines):
                     sroot[d] = (off + 4 * i) & ~7
             else:
                 r = root_of("s", base[0]) if base else None
+                key = base_key(base)                          # (before the destination is written: it may be the base)
                 for d in dst:
                     sroot.pop(d, None)
                 stats["scalar_data_loads"] += 1
@@ -80,7 +109,11 @@ def check_kernel(name, lines):
                     if r in stored:
                         findings.append((name, no, f"scalar load of argument +{r:#x} AFTER a vector store through it (line {stored[r]}): "
                                                    f"the scalar cache is not coherent with vector stores | {text}"))
-                    pending.append((r, no, text))
+                size = LOAD_BYTES.get(op.split("_")[-1])
+                rng = (off_imm, off_imm + size) if off_imm is not None and size else None
+                pending.append({"root": r, "no": no, "text": text, "base": key, "range": rng})
+            for d in dst:
+                sver[d] = sver.get(d, 0) + 1
             continue
         if op == "s_waitcnt":
             if "lgkmcnt(0)" in text or re.search(r"s_waitcnt\s+(0x0+|0)\b", text):
@@ -91,6 +124,7 @@ def check_kernel(name, lines):
             sk, src = regs(args[1])
             for i, d in enumerate(dst):
                 r = root_of("s", src[i]) if sk == "s" and i < len(src) else None
+                sver[d] = sver.get(d, 0) + 1
                 if r is None:
                     sroot.pop(d, None)
                 else:
@@ -105,16 +139,18 @@ def check_kernel(name, lines):
                     r = root_of("s", idx[0])
                     break
             for d in dst:
+                sver[d] = sver.get(d, 0) + 1
                 if r is None:
                     sroot.pop(d, None)
                 else:
                     sroot[d] = r
             continue
         if op.startswith("s_") and args:                       # any other scalar ALU result is not an address we follow
-            dk, dst = regs(args[0])
-            if dk == "s":
+            dk, dst = regs(args[0])                            # (s_cmp_* only read their first operand: counted as a write,
+            if dk == "s":                                      #  which errs towards "cannot be told apart")
                 for d in dst:
                     sroot.pop(d, None)
+                    sver[d] = sver.get(d, 0) + 1
             continue
         if op.startswith(("v_mov_b32", "v_mov_b64", "v_add_co_u32", "v_addc_co_u32", "v_add_u32", "v_lshl_add_u64", "v_add_co_ci_u32")):
             dk, dst = regs(args[0])
@@ -124,8 +160,10 @@ def check_kernel(name, lines):
                 if idx and root_of(k, idx[0]) is not None:
                     r = root_of(k, idx[0])
                     break
+            zero = op.startswith("v_mov_b32") and len(args) == 2 and args[1] in ("0", "0x0")
             for d in dst:
                 if dk == "v":
+                    vzero[d] = zero
                     if r is None:
                         vroot.pop(d, None)
                     else:
@@ -142,20 +180,49 @@ def check_kernel(name, lines):
             if r is not None:
                 stats["vector_stores_followed"] += 1
                 stored.setdefault(r, no)
-                for pr, pno, ptext in pending:
-                    if pr == r:
-                        findings.append((name, no, f"vector store through argument +{r:#x} while the scalar load of line {pno} "
-                                                   f"({ptext}) has not been waited for: the store can overtake it | {text}"))
+            if pending:
+                stats["stores_with_a_load_pending"] += 1
+                saddr, soff = None, 0                          # the store's SGPR base pair and immediate offset, if it has one
+                for a in args[1:]:
+                    k, idx = regs(a.split()[0]) if a else (None, [])
+                    if k == "s" and len(idx) == 2:
+                        saddr = base_key(idx)
+                m = re.search(r"offset:(-?\d+)", text)
+                soff = int(m.group(1)) if m else 0
+                size = store_bytes(op)
+                for pl in pending:
+                    if r is not None and pl["root"] is not None and r != pl["root"]:
+                        continue                               # two different kernel arguments
+                    if saddr is not None and saddr == pl["base"] and pl["range"] and size:
+                        lo, hi = pl["range"]                   # saddr form: address = SGPR pair + VGPR offset + immediate; a
+                        vk, vidx = regs(args[0])               # uniform struct field has the VGPR offset set to literal 0
+                        if (soff + size <= lo or soff >= hi) and vk == "v" and vzero.get(vidx[0]) is True:
+                            continue                           # same base, disjoint bytes of one struct
+                    why = (f"through argument +{r:#x}" if r is not None and r == pl["root"] else "that cannot be told apart from it")
+                    findings.append((name, no, f"vector store {why} while the scalar load of line {pl['no']} ({pl['text']}) "
+                                               f"has not been waited for: the store can overtake it | {text}"))
             continue
-        if op.startswith("v_") and args:
+        if op.startswith(("global_load", "flat_load", "buffer_load", "ds_read", "ds_load", "scratch_load")) and args:
             dk, dst = regs(args[0])
             if dk == "v":
                 for d in dst:
                     vroot.pop(d, None)
+                    vzero.pop(d, None)
+            continue
+        if op.startswith("v_") and args:
+            dk, dst = regs(args[0])
+            for d in dst:
+                if dk == "v":
+                    vroot.pop(d, None)
+                    vzero.pop(d, None)
+                elif dk == "s":                                # v_readfirstlane / v_cmp into an SGPR pair
+                    sroot.pop(d, None)
+                    sver[d] = sver.get(d, 0) + 1
     return findings
 
 
-check_kernel.stats = {"scalar_data_loads": 0, "scalar_data_loads_followed": 0, "vector_stores": 0, "vector_stores_followed": 0}
+check_kernel.stats = {"scalar_data_loads": 0, "scalar_data_loads_followed": 0, "vector_stores": 0, "vector_stores_followed": 0,
+                      "stores_with_a_load_pending": 0}
 
 
 def check_listing(text):
@@ -203,7 +270,9 @@ def main(argv):
     st = check_kernel.stats
     print(f"{kernels} kernels checked, {len(findings)} candidate hazard(s); followed to a kernel argument: "
           f"{st['scalar_data_loads_followed']} of {st['scalar_data_loads']} scalar data loads, "
-          f"{st['vector_stores_followed']} of {st['vector_stores']} vector stores / atomics")
+          f"{st['vector_stores_followed']} of {st['vector_stores']} vector stores / atomics; "
+          f"{st['stores_with_a_load_pending']} store(s) issued with a scalar data load outstanding"
+          + (" (the unexplained ones are listed above)" if findings else ", each one explained (other argument, or disjoint bytes of one struct)"))
     return 1 if findings else 0
 
 
