@@ -256,8 +256,6 @@ class ArnoldiContext:
         # 2-D Laplace n = 1M: 50 / 119 restarts/s eager in a cold / warm process, 125 replayed in both)
         mode = os.environ.get("AKS_GRAPH", "auto")
         self.use_graph = mode == "1" or (mode == "auto" and getattr(op, "n_local", 1 << 62) <= 4_000_000)
-        if mem.BACKEND != "torch":
-            self.use_graph = False      # (capture and replay go through torch's hipGraph API)
         self._graphs = {}
         # look-ahead operator application (see expand): off with AKS_LOOKAHEAD=0
         self.allow_lookahead = os.environ.get("AKS_LOOKAHEAD", "1") != "0"
@@ -427,16 +425,12 @@ class ArnoldiContext:
         key = (start, end, float(tol), float(eta), w_ready, lazy, defer)
         graph_ok = not op.native_comm or (os.environ.get("AKS_GRAPH_COMM", "0") == "1" and not op.any_exchange)
         if self.use_graph and self.probe is None and start > 0 and graph_ok and b.V.is_cuda:
-            import torch
-
             g = self._graphs.get(key)
             if g is None:
-                g = torch.cuda.CUDAGraph()
                 gc_was_on = gc.isenabled()
                 gc.disable()     # a collection during capture could free device objects (illegal in capture)
                 try:
-                    with torch.cuda.graph(g, capture_error_mode="relaxed"):
-                        enqueue()
+                    g = mem.Graph(enqueue)       # torch's capture API, or hipStreamBeginCapture / EndCapture (mem.py)
                 finally:
                     if gc_was_on:
                         gc.enable()

@@ -9,9 +9,9 @@ small: allocate / zero / copy buffers, views of rows and sub-blocks, one stream,
 ``AKS_HOST_ALLOC=hip``              ``HipArray`` below: hipMalloc / hipMemcpyAsync / hipMemsetAsync / hipHostMalloc /
                                     events through ctypes on libamdhip64.so.  torch is never imported: the drop-in then
                                     needs what the reference needs -- numpy and scipy (the reference's
-                                    dependencies, pyproject.toml:9-13) -- plus the HIP runtime.  Single GPU, no hipGraph
-                                    replay, no torch.distributed (row-sharded solves need the torch backend for their
-                                    set-up exchanges).
+                                    dependencies, pyproject.toml:9-13) -- plus the HIP runtime.  Single GPU; hipGraph
+                                    replay through the runtime's capture API; no torch.distributed (row-sharded
+                                    solves need the torch backend for their set-up exchanges).
 
 Both backends expose the same handful of functions, and their arrays the same handful of methods (``data_ptr``, basic
 slicing, ``view``, ``copy_``, ``zero_``, ``cpu().numpy()``, ``item``), which is all device.py / engine.py use.
@@ -70,6 +70,17 @@ if BACKEND == "torch":
     def pinned_empty(shape, dtype):
         return torch.empty(shape, dtype=dtype, pin_memory=True)
 
+    class Graph:
+        """A launch sequence captured once into a hipGraph and replayed on the current stream."""
+
+        def __init__(self, enqueue):
+            self.g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g, capture_error_mode="relaxed"):     # (captures on a side stream of torch's)
+                enqueue()
+
+        def replay(self):
+            self.g.replay()
+
 # =============================================================================================== HIP backend
 else:
     c128, f64, u8, i32, i64 = (np.dtype(t) for t in (np.complex128, np.float64, np.uint8, np.int32, np.int64))
@@ -90,7 +101,9 @@ else:
             for fn in ("hipMalloc", "hipFree", "hipHostMalloc", "hipHostFree", "hipMemsetAsync", "hipMemset2DAsync",
                        "hipMemcpyAsync", "hipMemcpy2DAsync", "hipStreamCreateWithFlags", "hipStreamSynchronize",
                        "hipEventCreateWithFlags", "hipEventRecord", "hipEventSynchronize", "hipEventDestroy",
-                       "hipEventElapsedTime", "hipGetDeviceCount", "hipGetDevice", "hipSetDevice", "hipDeviceSynchronize"):
+                       "hipEventElapsedTime", "hipGetDeviceCount", "hipGetDevice", "hipSetDevice", "hipDeviceSynchronize",
+                       "hipStreamBeginCapture", "hipStreamEndCapture", "hipGraphInstantiate", "hipGraphLaunch",
+                       "hipGraphDestroy", "hipGraphExecDestroy"):
                 getattr(lib, fn).restype = C.c_int
             lib.hipGetErrorString.restype = C.c_char_p
             _rt.lib = lib
@@ -175,6 +188,36 @@ else:
             try:
                 if self.h:
                     _rt().hipEventDestroy(self.h)
+            except Exception:
+                pass
+
+    class Graph:
+        """A launch sequence captured once into a hipGraph (relaxed mode, on this thread's stream) and replayed there."""
+
+        def __init__(self, enqueue):
+            rt, s = _rt(), C.c_void_p(stream_ptr())
+            graph, self.exe = C.c_void_p(), C.c_void_p()
+            _ck(rt.hipStreamBeginCapture(s, 2), "hipStreamBeginCapture")          # hipStreamCaptureModeRelaxed
+            try:
+                enqueue()
+            except BaseException:
+                rt.hipStreamEndCapture(s, C.byref(graph))                         # leave capture mode, drop what was recorded
+                if graph:
+                    rt.hipGraphDestroy(graph)
+                raise
+            _ck(rt.hipStreamEndCapture(s, C.byref(graph)), "hipStreamEndCapture")
+            try:
+                _ck(rt.hipGraphInstantiate(C.byref(self.exe), graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
+            finally:
+                rt.hipGraphDestroy(graph)
+
+        def replay(self):
+            _ck(_rt().hipGraphLaunch(self.exe, C.c_void_p(stream_ptr())), "hipGraphLaunch")
+
+        def __del__(self):
+            try:
+                if self.exe:
+                    _rt().hipGraphExecDestroy(self.exe)
             except Exception:
                 pass
 

@@ -105,6 +105,19 @@ def main(out_path):
     np.random.seed(1)
     vo, xo, ho = oracle.explicit_restarts_with_deflation(M, 4, **kw30)
     res["deflation"] = {"hist_equal": bool(np.array_equal(h5.restarts, ho.restarts)), "eig_err": float(np.abs(vals - vo).max())}
+    # hipGraph replay through the runtime's own capture API (mem.Graph): the re-expansions of the same solve captured
+    # once and replayed -- same bits as the eager sequence, and a graph was really built
+    graph = {}
+    for flag in ("0", "1"):
+        os.environ["AKS_GRAPH"] = flag
+        np.random.seed(1)
+        stg = {}
+        Qg, Tg, hg = arnoldi_amd.partial_schur(B, 5, max_dim=20, stats=stg)
+        graph[flag] = (Qg, Tg, hg.restarts.copy(), len(stg["solver"].ctx._graphs), int(stg["restarts"]))
+    del os.environ["AKS_GRAPH"]
+    res["graph"] = {"bit_identical": bool(np.array_equal(graph["0"][0], graph["1"][0]) and np.array_equal(graph["0"][1], graph["1"][1])
+                                          and np.array_equal(graph["0"][2], graph["1"][2])),
+                    "graphs_eager": graph["0"][3], "graphs_replayed": graph["1"][3], "restarts": graph["1"][4]}
     res["torch_imported"] = "torch" in sys.modules
     json.dump(res, open(out_path, "w"))
     print(res)

@@ -1015,6 +1015,8 @@ def test_solves_without_torch_in_the_process(tmp_path):
     b = r["binned"]
     assert b["hist_equal"] and b["form"] == "binned" and b["deferred"] > 0 and b["rel"] <= max(1.05 * b["rel_oracle"], 1e-13), b
     assert r["real"]["rel"] < 1e-7 and r["real"]["eig_err"] < 1e-7 and r["deflation"]["hist_equal"] and r["deflation"]["eig_err"] < 1e-9, r
+    g = r["graph"]            # hipGraph replay without torch: hipStreamBeginCapture / EndCapture / GraphLaunch through ctypes
+    assert g["bit_identical"] and g["graphs_eager"] == 0 and g["graphs_replayed"] >= 1 and g["restarts"] > 1, g
 
 
 def test_graph_replay_gives_identical_results(amd, monkeypatch):
