@@ -136,9 +136,9 @@ def main(out_path):
                                                                        / max(np.abs(ref).max(), 1e-300))
     # a whole solve with the re-expansions replayed as hipGraphs that contain the RCCL all-reduces: the same bits
     # as the eager launch sequence (AKS_GRAPH is read when the context is made)
-    # (opt-in, AKS_GRAPH_COMM=1, and only for sequences without a ghost exchange: ending the capture of a grouped
-    # ncclSend / ncclRecv forked onto the communicator's side stream crashed inside hipStreamEndCapture on
-    # ROCm 7.2 / RCCL 2.26 -- round 3, this worker)
+    # (opt-in, AKS_GRAPH_COMM=1, and only for sequences without a ghost exchange: a capture that contained the grouped
+    # ncclSend / ncclRecv forked onto the communicator's side stream ended in a SIGSEGV in round 3, in this worker --
+    # ROCm 7.2 / RCCL 2.26, cause undecided, DESIGN section 4 -- and such sequences are kept eager ever since)
     graph = {}
     os.environ["AKS_GRAPH_COMM"] = "1"
     for mode in ("0", "1"):
