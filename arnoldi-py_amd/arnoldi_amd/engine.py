@@ -24,7 +24,7 @@ import os
 import numpy as np
 
 from . import _hip, device as dev, mem
-from .dist import Comm, row_offsets, split_local_rows
+from .dist import row_offsets, split_local_rows
 
 C128 = np.complex128
 

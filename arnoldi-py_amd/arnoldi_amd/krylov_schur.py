@@ -9,7 +9,6 @@ the MI355X through ``engine.ArnoldiContext``.
 from __future__ import annotations
 
 import numpy as np
-import scipy.linalg
 
 from .engine import ArnoldiContext, as_operator, default_comm
 from .history import History

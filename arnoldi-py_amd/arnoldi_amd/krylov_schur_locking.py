@@ -27,7 +27,6 @@ Dynamic p (ARPACK's rule, dnaup2): with ``l`` values locked the restart keeps
 from __future__ import annotations
 
 import numpy as np
-import scipy.linalg
 
 from .krylov_schur import KrylovSchurSolver
 from .utils import complex_schur, reorder_schur
