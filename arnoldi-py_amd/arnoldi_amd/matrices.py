@@ -163,3 +163,44 @@ def banded_csr(n, per_row=35, seed=1234, planted=None, dtype=np.float64):
         vals[where, h] = planted
     indptr = np.concatenate([[0], np.cumsum(ok.sum(axis=1))])
     return sp.csr_matrix((vals[ok], cols[ok].astype(np.int32), indptr.astype(np.int32)), shape=(n, n))
+
+
+def shell_csr(nx, ny, dof=5, seed=1234, planted=None, dtype=np.float64):
+    """A second stand-in for BASELINE config 3 with the STRUCTURE of a shell finite-element matrix such as af_shell10
+    (n = 1 508 065, 34.65 entries per row; not available offline): ``dof`` unknowns per node of an ``nx x ny``
+    triangulated sheet, every node coupled to itself and its six mesh neighbours (i +- 1, j), (i, j +- 1), (i + 1, j - 1),
+    (i - 1, j + 1) by dense ``dof x dof`` blocks -- 7 * dof = 35 entries per interior row in seven runs of ``dof``
+    consecutive columns, a node row apart, instead of ``banded_csr``'s one contiguous run.  Symmetric pattern,
+    non-symmetric values: off-diagonal U(-1, 1), diagonal U(0, 1) * 7 * dof / 4.  ``planted``: diagonal values written on
+    evenly spaced rows (dominant eigenvalues).  ``nx = ny = 549`` gives n = 1 507 005, nnz = 52.6M."""
+    rng = np.random.default_rng(seed)
+    nodes = nx * ny
+    i, j = np.arange(nodes, dtype=np.int64) % nx, np.arange(nodes, dtype=np.int64) // nx
+    steps = ((0, -1), (1, -1), (-1, 0), (0, 0), (1, 0), (-1, 1), (0, 1))              # ascending node number
+    nbr = np.empty((nodes, 7), dtype=np.int64)
+    ok = np.empty((nodes, 7), dtype=bool)
+    for k, (di, dj) in enumerate(steps):
+        ii, jj = i + di, j + dj
+        ok[:, k] = (ii >= 0) & (ii < nx) & (jj >= 0) & (jj < ny)
+        nbr[:, k] = jj * nx + ii
+    n = nodes * dof
+    # row (node, d) holds, per valid neighbour, the columns dof * nbr + (0 .. dof-1)
+    cols = np.empty((nodes, dof, 7, dof), dtype=np.int32)
+    cols[:] = ((dof * nbr).astype(np.int32)[:, :, None] + np.arange(dof, dtype=np.int32))[:, None, :, :]
+    cols = cols.reshape(n, 7 * dof)
+    keep = np.empty((nodes, dof, 7, dof), dtype=bool)
+    keep[:] = ok[:, None, :, None]
+    keep = keep.reshape(n, 7 * dof)
+    vals = rng.random((n, 7 * dof))                                                    # U(-1, 1), in place
+    vals *= 2.0
+    vals -= 1.0
+    vals = vals.astype(dtype, copy=False)
+    diag_slot = 3 * dof + (np.arange(n, dtype=np.int64) % dof)                          # the row's own column
+    rows = np.arange(n, dtype=np.int64)
+    vals[rows, diag_slot] = rng.uniform(0.0, 1.0, n) * 7 * dof / 4
+    if planted is not None:
+        where = np.linspace(n // 7, n - n // 7, len(planted)).astype(np.int64)
+        vals[where, diag_slot[where]] = planted
+    indptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))])
+    return sp.csr_matrix((vals[keep], cols[keep], indptr.astype(np.int32)), shape=(n, n))
+

@@ -17,7 +17,7 @@ The line printed by rank 0 also carries
                   algorithmic bytes (12 nnz + 36 n + 4) / average launch time vs 8 TB/s;
   roofline_ortho  the same for the Gram-Schmidt launches of the timed region;
   workloads       (N = 1) the other matrices of BASELINE.json -- Markov n = 10M (config 1 scaled), the 2-D Laplacian
-                  of config 2, the banded stand-in for config 3 and the 3-D Laplacian of config 4 (on one GPU) --
+                  of config 2, the banded and the shell-structured stand-ins for config 3 and the 3-D Laplacian of config 4 (on one GPU) --
                   through the same measurement, a few restarts each;
   real_arithmetic (N = 1) the same default workload with partial_schur(arithmetic="real");
   cpu_baseline    (N = 1) the CPU oracle (NumPy/SciPy restatement of the reference, validated against
@@ -43,7 +43,7 @@ for _p in (ROOT, os.path.join(ROOT, "arnoldi-py_amd")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CONFIG_OF = {"random": 5, "laplace2d": 2, "laplace3d": 4, "markov": 1, "banded": 3, "file": 3}   # BASELINE.json configs[] (1-based)
+CONFIG_OF = {"random": 5, "laplace2d": 2, "laplace3d": 4, "markov": 1, "banded": 3, "shell": 3, "file": 3}   # BASELINE.json configs[] (1-based)
 _FILE_MATRIX = {}   # --matrix: path -> CSR, loaded once per process
 _RNG_LOCK = threading.Lock()   # numpy's global RNG (the reference's start-vector stream) is one per process
 GPU = None     # torch.cuda.is_available(), set by run_rank: the device-timing objects need a GPU (the product
@@ -65,7 +65,9 @@ def parse_args(argv=None):
                     help="random = BASELINE config 5 (default); laplace2d / laplace3d = configs 2 / 4; "
                          "markov = mark(M) of the reference's README scaled to ~n rows (sorted LR); "
                          "banded = stand-in for config 3 (af_shell10 is not available offline): use "
-                         "--n 1500000 --per-row 35 --nev 20 --max-dim 41")
+                         "--n 1500000 --per-row 35 --nev 20 --max-dim 41; shell = the same config with the structure of "
+                         "a shell finite-element matrix (5 unknowns per node of a triangulated sheet, seven 5 x 5 "
+                         "blocks per row): --n 1500000 --nev 20 --max-dim 41")
     ap.add_argument("--matrix", default=None, metavar="FILE",
                     help="a matrix file (SuiteSparse .mat with Problem.A, MatrixMarket .mtx, scipy .npz) through "
                          "arnoldi_amd.harness.load_matrix, e.g. af_shell10.mat for BASELINE config 3 (the reference's "
@@ -153,6 +155,9 @@ def grid_dims(workload, n):
     if workload == "laplace2d":
         nx = int(round(n ** 0.5))
         return (nx, nx + 1)
+    if workload == "shell":                       # 5 unknowns per node of an nx x nx sheet
+        nx = max(int(round((n / 5.0) ** 0.5)), 2)
+        return (nx, nx)
     nx = int(round(n ** (1.0 / 3.0)))
     return (nx, nx + 1, nx + 2)
 
@@ -175,6 +180,8 @@ def problem_size(args):
     if args.workload in ("random", "banded"):
         return args.n, None
     dims = grid_dims(args.workload, args.n)
+    if args.workload == "shell":
+        return 5 * dims[0] * dims[1], dims
     n = dims[0] * (dims[0] + 1) // 2 if args.workload == "markov" else int(np.prod(dims))
     return n, dims
 
@@ -188,6 +195,8 @@ def build_rows(args, r0, r1, n, dims):
         return matrices.random_csr(n, args.per_row, 1234, row_range=(r0, r1))
     if args.workload == "banded":
         return matrices.banded_csr(n, args.per_row, 1234)[r0:r1]
+    if args.workload == "shell":
+        return matrices.shell_csr(dims[0], dims[1], 5, 1234)[r0:r1]
     if args.workload == "markov":
         rows = matrices.mark(dims[0])[r0:r1]      # every rank builds the chain and keeps its rows
     else:
@@ -237,6 +246,9 @@ def cpu_baseline(args):
         if args.workload == "markov":
             mm = grid_dims("markov", ns)[0]
             return matrices.mark(mm), f"mark({mm})"
+        if args.workload == "shell":
+            sx = grid_dims("shell", ns)[0]
+            return matrices.shell_csr(sx, sx, 5, 1234), f"shell CSR {sx} x {sx} nodes x 5 unknowns (same generator)"
         dims = grid_dims(args.workload, ns)
         return matrices.laplace_rows(dims, 0, int(np.prod(dims))), f"{args.workload} grid {dims}"
 
@@ -926,6 +938,8 @@ def run_rank(args, argv):
                                                    "--max-dim", "40"]),                       # BASELINE config 2
                                     ("banded", ["--workload", "banded", "--rows", "1500000", "--per-row", "35",
                                                 "--nev", "20", "--max-dim", "41"]),           # config 3 stand-in
+                                    ("shell", ["--workload", "shell", "--rows", "1507005", "--nev", "20",
+                                               "--max-dim", "41"]),                           # config 3, FEM-shell structure
                                     ("laplace3d", ["--workload", "laplace3d", "--rows", "16000000", "--nev", "10",
                                                    "--max-dim", "40"])):                      # config 4 on ONE GPU
                     leg = run_child(extra + base, 600)

@@ -6,7 +6,8 @@ size-independent properties and analytic answers:
   C2  2-D Laplace 1000 x 1001 (n ~ 1M), k=10, m=40, LM: solve to convergence; eigenvalues against
       the analytic spectrum, residuals ||Av - lv|| / |l| < 5 tol (the reference scripts' check,
       scripts/benchmark-partial-schur.py:97-100), Schur vectors orthonormal.
-  C3  af_shell10 stand-in (banded, n = 1,508,065, 35 per row), k=20 -> m=41, p=25 (defaults):
+  C3  af_shell10 stand-ins (banded: n = 1,508,065, 35 per row in one run; shell: 549 x 549 nodes x 5 unknowns, seven
+      5 x 5 blocks per row), k=20 -> m=41, p=25 (defaults):
       planted dominant eigenvalues, solve to convergence, residual check; exercises panel widths
       26..41 (widest fused kernels) and the 41 x 25 truncation.
   C4  3-D Laplace 251 x 252 x 253 (n ~ 16M, V = 10.5 GB): expansion + restarts on one GPU; Arnoldi
@@ -92,6 +93,38 @@ def test_config3_banded_stand_in(amd):
     assert np.all(np.abs(vals) > 25.0)              # the planted, dominant part of the spectrum
     np.testing.assert_allclose(Q.conj().T @ Q, np.eye(20), atol=1e-11)
     print(f"C3 stand-in: {st['restarts']} restarts, max rel residual {rel.max():.2e}")
+
+
+def test_config3_shell_structured_stand_in(amd):
+    """Config 3 once more with the STRUCTURE of the matrix it names (af_shell10: a shell finite-element model, 5 unknowns
+    per node, 34.65 entries per row): matrices.shell_csr, 549 x 549 nodes = 1 507 005 rows, 52.6M entries in seven
+    5 x 5 blocks per row a node row apart -- where the banded stand-in has one contiguous run."""
+    from arnoldi_amd import matrices
+
+    planted = tuple(60.0 - 1.5 * i for i in range(24))
+    As = matrices.shell_csr(80, 75, 5, 1234, planted=planted)            # small twin against the oracle
+    np.random.seed(0)
+    Qo, To, ho = oracle.krylov_schur(As, 20)
+    np.random.seed(0)
+    st = {}
+    Q, T, h = amd.partial_schur(As, 20, stats=st)
+    assert (st["max_dim"], st["p"]) == (41, 25)
+    np.testing.assert_array_equal(h.restarts, ho.restarts)
+    np.testing.assert_allclose(np.diag(T), np.diag(To), rtol=1e-9)
+    _, rel = _residuals(As, Q, T)
+    _, rel_o = _residuals(As, Qo, To)
+    assert rel.max() <= max(1.05 * rel_o.max(), 1e-13)
+
+    A = matrices.shell_csr(549, 549, 5, 1234, planted=planted)           # full size
+    assert A.shape[0] == 1_507_005 and A.nnz > 52_000_000
+    np.random.seed(0)
+    st = {}
+    Q, T, h = amd.partial_schur(A, 20, stats=st, max_restarts=300)
+    vals, rel = _residuals(A, Q, T)
+    assert rel.max() < 5 * np.sqrt(np.finfo(np.float64).eps), rel
+    assert np.all(np.abs(vals) > 25.0)              # the planted, dominant part of the spectrum
+    np.testing.assert_allclose(Q.conj().T @ Q, np.eye(20), atol=1e-11)
+    print(f"C3 shell stand-in: {st['restarts']} restarts, form {st['spmv_form']}, max rel residual {rel.max():.2e}")
 
 
 def test_config4_laplace3d_16m_invariants(amd):

@@ -139,6 +139,37 @@ def test_laplace_generators():
     assert (part - A3[17:80]).nnz == 0
 
 
+def test_shell_csr_has_the_structure_of_a_shell_fem_matrix():
+    """matrices.shell_csr (the structured stand-in for BASELINE config 3): 5 unknowns per node, dense 5 x 5 blocks to
+    the node itself and its six mesh neighbours -- against a brute-force assembly; symmetric pattern, canonical CSR,
+    35 entries per interior row, planted diagonal."""
+    from arnoldi_amd.matrices import shell_csr
+
+    nx, ny, dof = 7, 6, 5
+    A = shell_csr(nx, ny, dof, seed=3, planted=(50.0, 40.0))
+    n = nx * ny * dof
+    assert A.shape == (n, n) and A.has_canonical_format and A.indices.dtype == np.int32 and A.indptr.dtype == np.int32
+    want = np.zeros((n, n), bool)
+    for j in range(ny):
+        for i in range(nx):
+            for di, dj in ((0, 0), (1, 0), (-1, 0), (0, 1), (0, -1), (1, -1), (-1, 1)):
+                ii, jj = i + di, j + dj
+                if 0 <= ii < nx and 0 <= jj < ny:
+                    a, b = dof * (j * nx + i), dof * (jj * nx + ii)
+                    want[a:a + dof, b:b + dof] = True
+    got = np.zeros((n, n), bool)
+    got[A.nonzero()] = True
+    np.testing.assert_array_equal(got, want)
+    assert (want == want.T).all() and np.diff(A.indptr).max() == 7 * dof
+    assert abs(A - A.T).max() > 0.1                                   # values are not symmetric
+    d = A.diagonal()
+    assert sorted(d)[-2:] == [40.0, 50.0] and d.min() > 0
+    off = A.toarray()[~np.eye(n, dtype=bool) & want]
+    assert off.min() >= -1.0 and off.max() <= 1.0
+    B = shell_csr(nx, ny, dof, seed=3, planted=(50.0, 40.0))
+    assert (A != B).nnz == 0                                          # same seed, same matrix
+
+
 def test_random_csr_row_ranges_are_consistent():
     from arnoldi_amd.matrices import random_csr
 

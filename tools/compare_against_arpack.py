@@ -8,7 +8,7 @@ scripts/compare-against-arpack.py and scripts/stress-test.py (SLEPc leg omitted)
     python tools/compare_against_arpack.py laplace2d:300x301 --nev 10 --ncv 40
 
 Matrix argument: a .mat / .mtx / .npz file, or  mark:M | laplace2d:NXxNY | laplace3d:NXxNYxNZ |
-random:N[:per_row] | banded:N[:per_row].
+random:N[:per_row] | banded:N[:per_row] | shell:NXxNY (5 unknowns per node).
 """
 import argparse
 import os
@@ -32,6 +32,8 @@ def build(spec):
         return matrices.laplace2d(*(int(v) for v in arg.split("x")))
     if kind == "laplace3d":
         return matrices.laplace3d(*(int(v) for v in arg.split("x")))
+    if kind == "shell":
+        return matrices.shell_csr(*(int(v) for v in arg.split("x")))
     if kind in ("random", "banded"):
         parts = [int(v) for v in arg.split(":")]
         gen = matrices.random_csr if kind == "random" else matrices.banded_csr
