@@ -513,10 +513,19 @@ class ArnoldiContext:
             cap = max(Q.size, self.max_dim * self.max_dim)
             self._coef_stage = [mem.pinned_empty(cap, mem.c128) for _ in range(2)]
             self._coef_dev = [mem.empty(cap, mem.c128, b.device) for _ in range(2)]
+            self._coef_copied = [None, None]
         self._coef_turn ^= 1
         stage, out = self._coef_stage[self._coef_turn], self._coef_dev[self._coef_turn]
+        if self._coef_copied[self._coef_turn] is not None:
+            # the copy that last read this staging buffer: long finished in the drivers' restart loop (see above); a
+            # caller that compresses several times without waiting for the device in between is held here instead of
+            # overwriting bytes a copy engine is still reading
+            self._coef_copied[self._coef_turn].synchronize()
         stage[: Q.size].numpy()[:] = Q.reshape(-1)
         out[: Q.size].copy_(stage[: Q.size], non_blocking=True)
+        if self._coef_copied[self._coef_turn] is None:
+            self._coef_copied[self._coef_turn] = mem.Event()
+        self._coef_copied[self._coef_turn].record()
         return out[: Q.size]
 
     def truncate(self, Qp, m, p):

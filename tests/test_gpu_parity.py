@@ -652,6 +652,37 @@ def test_truncate(amd, m, p):
     np.testing.assert_array_equal(out[:, p + 1:], V[:, p + 1:])  # untouched columns
 
 
+def test_back_to_back_truncations_do_not_overwrite_a_staging_buffer_in_flight(amd):
+    """ArnoldiContext.truncate uploads its coefficients through two alternating pinned staging buffers with asynchronous
+    copies; the drivers wait for the device between two restarts, a caller of the context need not.  Eight compressions
+    enqueued without any wait in between (behind a long kernel queue, so the copies are still pending when the host
+    comes back) must each use its own coefficients."""
+    import scipy.sparse as sp
+    import torch
+    from arnoldi_amd.engine import ArnoldiContext, CsrOperator
+
+    n, m, p = 400_000, 20, 10
+    rng = np.random.default_rng(5)
+    op = CsrOperator(sp.identity(n, format="csr"))
+    ctx = ArnoldiContext(op, m)
+    V = (rng.standard_normal((n, m + 1)) + 1j * rng.standard_normal((n, m + 1))).astype(C128)
+    ctx.basis.set_cols(0, V)
+    Qs = [(rng.standard_normal((m, p)) + 1j * rng.standard_normal((m, p))).astype(C128) / 4 for _ in range(8)]
+    busy = torch.zeros(64_000_000, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(40):                       # ~10 ms of queued work: the uploads below are enqueued long before they run
+        busy.add_(1.0)
+    want = V.copy()
+    for Q in Qs:
+        ctx.truncate(Q, m, p)
+        new = want.copy()
+        new[:, :p] = want[:, :m] @ Q
+        new[:, p] = want[:, m]
+        want = new
+    out = ctx.basis.get_cols(0, m + 1)
+    assert _relerr(out[:, : p + 1], want[:, : p + 1]) < 1e-12
+
+
 # ---------------------------------------------------------------------------- full solves
 def _solve_and_compare(amd, A, g, prefix, seed, expect_same_restarts=True, residual_matrix=None, **kw):
     np.random.seed(seed)
