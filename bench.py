@@ -514,7 +514,7 @@ def pmc_traffic(res, args, world=1):
     doubled for coalesced streams (gfx950 counts their 128-B requests as 64 B, MI355X_MICROARCH.md "HBM"): the binned
     and sliced kernels; the CSR kernel's 16-B gathers are reported raw."""
     shape = {"random": (10_000_000, 5), "markov": (10_000_000, None), "laplace2d": (1_000_000, None),
-             "banded": (1_500_000, 35), "laplace3d": (16_000_000, None)}.get(args.workload)
+             "banded": (1_500_000, 35), "shell": (1_507_005, None), "laplace3d": (16_000_000, None)}.get(args.workload)
     if shape is None or world != 1 or args.arithmetic != "complex" or args.n != shape[0] or \
             (shape[1] is not None and args.per_row != shape[1]):
         return None, None

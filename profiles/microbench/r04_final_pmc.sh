@@ -1,7 +1,7 @@
 #!/bin/bash
 # final measurement campaign of round 4: rocprofv3 stats + PMC passes (profiles/collect_pmc.sh) of the named workloads;
 # the summaries land in gpurun_out/prof_<name>/pmc_summary.json (copied to profiles/pmc_summary[_<name>].json afterwards)
-#   bash profiles/microbench/r04_final_pmc.sh c5 markov | laplace2d banded laplace3d
+#   bash profiles/microbench/r04_final_pmc.sh c5 markov | laplace2d banded shell laplace3d
 cd $GRAFT_REPO_ROOT
 for name in "$@"; do
   case $name in
@@ -9,6 +9,7 @@ for name in "$@"; do
     markov) args="--workload markov --rows 10000000" ;;
     laplace2d) args="--workload laplace2d --rows 1000000 --nev 10 --max-dim 40" ;;
     banded) args="--workload banded --rows 1500000 --per-row 35 --nev 20 --max-dim 41" ;;
+    shell) args="--workload shell --rows 1507005 --nev 20 --max-dim 41" ;;
     laplace3d) args="--workload laplace3d --rows 16000000 --nev 10 --max-dim 40" ;;
   esac
   AKS_PMC_OUT=prof_$name bash profiles/collect_pmc.sh $args > gpurun_out/r04_final_pmc_$name.log 2>&1; echo "$name pmc rc $?"
