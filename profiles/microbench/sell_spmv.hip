@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -183,6 +184,59 @@ __global__ __launch_bounds__(256) void k_sell_ab(int64_t n_rows, const int64_t *
     if (row < n_rows) y[row] = make_double2(sr, si);
 }
 
+// Round 4, second experiment: 16-bit column deltas.  In a sliced layout slot k of the 64 rows of a slice holds nearly the
+// same diagonal of a structured matrix, so a column is  base[slice][k] + delta  with a 16-bit delta (0xFFFF = padding);
+// two deltas share one 32-bit word ([pair][lane]): 2 instead of 4 bytes per entry AND one column load per two entries.
+// Matrix bytes 12 -> 10 per entry (+ 4 bytes per 64 entries of bases).  Same values, same summation order.
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_sell16(int64_t n_rows, const int64_t *__restrict__ slice_ptr, const int64_t *__restrict__ pair_ptr,
+                                               const uint32_t *__restrict__ cpair, const int32_t *__restrict__ base,
+                                               const double *__restrict__ val, const c128 *__restrict__ x, c128 *__restrict__ y) {
+    static_assert(U % 2 == 0, "pairs");
+    const int lane = threadIdx.x & 63;
+    const int64_t per = (gridDim.x + 7) / 8;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int64_t slice = wg * 4 + (threadIdx.x >> 6);
+    const int64_t row = slice * 64 + lane;
+    if (slice * 64 >= n_rows) return;
+    const int64_t p0 = slice_ptr[slice], p1 = slice_ptr[slice + 1];
+    const int W = (int)((p1 - p0) >> 6);
+    double sr = 0.0, si = 0.0;
+    const uint32_t *c = cpair + pair_ptr[slice] + lane;
+    const double *v = val + p0 + lane;
+    const int32_t *b = base + (p0 >> 6);
+    int k = 0;
+    for (; k + U <= W; k += U) {
+        uint32_t pp[U / 2];
+        double vv[U];
+        int32_t cc[U];
+#pragma unroll
+        for (int h = 0; h < U / 2; ++h) pp[h] = NT ? __builtin_nontemporal_load(&c[(int64_t)(k / 2 + h) * 64]) : c[(int64_t)(k / 2 + h) * 64];
+#pragma unroll
+        for (int u = 0; u < U; ++u) vv[u] = NT ? __builtin_nontemporal_load(&v[(int64_t)(k + u) * 64]) : v[(int64_t)(k + u) * 64];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t d = (u & 1) ? pp[u / 2] >> 16 : pp[u / 2] & 0xFFFFu;
+            cc[u] = d == 0xFFFFu ? -1 : b[k + u] + (int32_t)d;
+        }
+        c128 xx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xx[u] = cc[u] >= 0 ? x[cc[u]] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { sr = fma(vv[u], xx[u].x, sr); si = fma(vv[u], xx[u].y, si); }
+    }
+    for (; k < W; ++k) {
+        const uint32_t pw = c[(int64_t)(k / 2) * 64];
+        const uint32_t d = (k & 1) ? pw >> 16 : pw & 0xFFFFu;
+        const int32_t cc = d == 0xFFFFu ? -1 : b[k] + (int32_t)d;
+        const double vv = v[(int64_t)k * 64];
+        const c128 xx = cc >= 0 ? x[cc] : make_double2(0.0, 0.0);
+        sr = fma(vv, xx.x, sr);
+        si = fma(vv, xx.y, si);
+    }
+    if (row < n_rows) y[row] = make_double2(sr, si);
+}
+
 struct Csr { int64_t n; std::vector<int64_t> ptr; std::vector<int32_t> idx; std::vector<double> val; };
 
 static Csr laplace3d(int nx, int ny, int nz) {
@@ -298,6 +352,40 @@ static void run(const char *name, const Csr &A) {
             time_it([&] { hipLaunchKernelGGL((k_sell_grp<2, 4, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_cg, d_vg, x, y); }, "g2 u4 nt");
         }
         CK(hipFree(d_cg)); CK(hipFree(d_vg));
+    }
+    {   // 16-bit deltas against a base per (slice, slot); two deltas per 32-bit word
+        std::vector<int64_t> pp(ns + 1, 0);
+        for (int64_t sl = 0; sl < ns; ++sl) pp[sl + 1] = pp[sl] + (((sp[sl + 1] - sp[sl]) / 64 + 1) / 2) * 64;
+        std::vector<uint32_t> cpair(pp[ns], 0xFFFFFFFFu);
+        std::vector<int32_t> base(sp[ns] / 64, 0);
+        bool fits = true;
+        for (int64_t sl = 0; sl < ns; ++sl) {
+            const int64_t W = (sp[sl + 1] - sp[sl]) / 64;
+            for (int64_t k = 0; k < W; ++k) {
+                int64_t lo = INT64_MAX, hi = -1;
+                for (int l = 0; l < 64; ++l) { const int32_t cq = col[sp[sl] + k * 64 + l]; if (cq >= 0) { lo = std::min<int64_t>(lo, cq); hi = std::max<int64_t>(hi, cq); } }
+                if (hi < 0) lo = 0;
+                if (hi - lo > 65534) fits = false;
+                base[sp[sl] / 64 + k] = (int32_t)lo;
+                for (int l = 0; l < 64; ++l) {
+                    const int32_t cq = col[sp[sl] + k * 64 + l];
+                    const uint32_t d = cq >= 0 ? (uint32_t)(cq - lo) & 0xFFFFu : 0xFFFFu;
+                    uint32_t &w = cpair[pp[sl] + (k / 2) * 64 + l];
+                    w = (k & 1) ? (w & 0x0000FFFFu) | (d << 16) : (w & 0xFFFF0000u) | d;
+                }
+            }
+        }
+        if (!fits) printf("   16-bit deltas: a (slice, slot) spans more than 65534 columns -- not representable\n");
+        else {
+            int64_t *d_pp = upload(pp); uint32_t *d_cp = upload(cpair); int32_t *d_b = upload(base);
+            printf("   (16-bit deltas: matrix bytes %.1f MB instead of %.1f MB)\n", (sp[ns] * 8.0 + pp[ns] * 4.0 + base.size() * 4.0) / 1e6, sp[ns] * 12.0 / 1e6);
+            time_it([&] { hipLaunchKernelGGL((k_sell16<4, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_pp, d_cp, d_b, d_val, x, y); }, "d16 u4 nt");
+            time_it([&] { hipLaunchKernelGGL((k_sell16<8, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_pp, d_cp, d_b, d_val, x, y); }, "d16 u8 nt");
+            time_it([&] { hipLaunchKernelGGL((k_sell16<4, false>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_pp, d_cp, d_b, d_val, x, y); }, "d16 u4");
+            time_it([&] { hipLaunchKernelGGL((k_sell<4, true, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_col, d_val, x, y); }, "u4 XCD nt");
+            time_it([&] { hipLaunchKernelGGL((k_sell16<4, true>), dim3(grid8), dim3(256), 0, 0, n, d_sp, d_pp, d_cp, d_b, d_val, x, y); }, "d16 u4 nt");
+            CK(hipFree(d_pp)); CK(hipFree(d_cp)); CK(hipFree(d_b));
+        }
     }
     // check against the host CSR product on a sample of rows
     std::vector<double> hy(2 * n);
