@@ -1273,8 +1273,8 @@ def test_bench_contract_line():
     assert cb["n"] == 300000 and cb["full_size"] is True            # the CPU baseline ran at the bench's own size
     assert d["real_arithmetic"]["value"] > 0 and d["real_arithmetic"]["spmv_frac"] > 0
     wl = {w["name"]: w for w in d["workloads"]}
-    assert set(wl) == {"markov", "laplace2d", "banded", "laplace3d"}
+    assert set(wl) == {"markov", "laplace2d", "banded", "shell", "laplace3d"}
     for w in wl.values():                                           # north star: Markov / Laplace, fraction of the roofline
         assert "error" not in w, w
         assert w["restarts_per_s"] > 0 and 0 < w["spmv_frac"] < 1 and 0 < w["ortho_frac"] < 1
-    assert wl["laplace2d"]["second_pass_fraction"] == 1.0 and wl["markov"]["n"] > 9_000_000
+    assert wl["laplace2d"]["second_pass_fraction"] == 1.0 and wl["markov"]["n"] > 9_000_000 and wl["shell"]["n"] == 1_507_005
