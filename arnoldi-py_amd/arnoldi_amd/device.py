@@ -67,7 +67,8 @@ def canonical_csr(A):
     """scipy sparse / dense ndarray -> canonical CSR (sorted, duplicates summed),
     int32 indices, float64 or complex128 values.  Returns None for opaque operators."""
     if sp.issparse(A):
-        M = sp.csr_matrix(A)
+        # (a CSR input is used as it is: a new csr_matrix object would forget what scipy already knows about its format)
+        M = A if getattr(A, "format", None) == "csr" and isinstance(A, (sp.csr_matrix, sp.csr_array)) else sp.csr_matrix(A)
     elif isinstance(A, np.ndarray) and A.ndim == 2:
         M = sp.csr_matrix(A)
     else:
@@ -78,9 +79,13 @@ def canonical_csr(A):
     if M.nnz >= 2**31 - 1 or max(M.shape) >= 2**31 - 1:
         raise _hip.HipLibraryError("matrices with >= 2^31 rows or non-zeros are not supported")
     dt = C128 if np.iscomplexobj(M.data) else np.float64
-    return sp.csr_matrix(
+    out = sp.csr_matrix(
         (np.ascontiguousarray(M.data, dtype=dt), M.indices.astype(np.int32, copy=False),
          M.indptr.astype(np.int32, copy=False)), shape=M.shape)
+    out.has_canonical_format = True      # just established: the next canonical_csr() of this object need not scan it again
+    if M is A and M.data.dtype == dt and M.indices.dtype == np.int32 and M.indptr.dtype == np.int32:
+        return A                         # already in the library's form: no new object either
+    return out
 
 
 def choose_lanes_per_row(n_rows, nnz):

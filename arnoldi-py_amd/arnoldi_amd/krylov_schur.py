@@ -12,7 +12,7 @@ import numpy as np
 
 from .engine import ArnoldiContext, as_operator, default_comm
 from .history import History
-from .utils import arg_largest_magnitude, complex_schur, host_blas_threads, rand_normalized_vector, reorder_schur
+from .utils import StartVector, arg_largest_magnitude, complex_schur, host_blas_threads, reorder_schur
 
 WORK_DTYPE = np.complex128  # krylov_schur.py:38: complex128 whatever A.dtype is
 
@@ -26,11 +26,15 @@ class KrylovSchurSolver:
         n = A.shape[0]
         self.n, self.nev, self.max_dim, self.p = n, nev, max_dim, p
         self.tol, self.sort_function = tol, sort_function
-        self.op = as_operator(A, comm=comm, device=device)
-        self.ctx = ArnoldiContext(self.op, max_dim, device)
         # every rank draws the full vector so that the shards agree bit for bit with the
-        # single-GPU (and the reference's) start vector
-        start = rand_normalized_vector(n, WORK_DTYPE) if v0 is None else np.asarray(v0, dtype=WORK_DTYPE)
+        # single-GPU (and the reference's) start vector; the draw runs while the operator is set up (utils.StartVector)
+        drawn = StartVector(n, WORK_DTYPE, v0)
+        try:
+            self.op = as_operator(A, comm=comm, device=device)
+            self.ctx = ArnoldiContext(self.op, max_dim, device)
+        finally:
+            start = drawn.get()
+        start = np.asarray(start, dtype=WORK_DTYPE)
         assert start.shape == (n,)
         self.ctx.set_start_vector(start)
         self.H = np.zeros((max_dim + 1, max_dim), dtype=WORK_DTYPE)

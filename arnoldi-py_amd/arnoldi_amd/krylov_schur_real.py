@@ -23,7 +23,7 @@ from scipy.linalg.lapack import dtrexc, strexc
 
 from .engine import ArnoldiContext, as_operator
 from .history import History
-from .utils import rand_normalized_vector
+from .utils import StartVector
 
 
 def real_blocks(T):
@@ -88,11 +88,13 @@ class RealKrylovSchurSolver:
         n = A.shape[0]
         self.n, self.nev, self.max_dim, self.p = n, nev, max_dim, p
         self.tol, self.sort_function = tol, sort_function
-        self.op = as_operator(A, comm=comm, device=device, real=True)
-        self.ctx = ArnoldiContext(self.op, max_dim, device)
-        if v0 is None:
-            start = rand_normalized_vector(n)              # the reference's draw (its imaginary part is 0)
-        else:
+        drawn = StartVector(n, np.float64, v0)             # the reference's draw (its imaginary part is 0), made while
+        try:                                               # the operator is set up
+            self.op = as_operator(A, comm=comm, device=device, real=True)
+            self.ctx = ArnoldiContext(self.op, max_dim, device)
+        finally:
+            start = drawn.get()
+        if v0 is not None:
             start = np.asarray(v0)
             if np.iscomplexobj(start):
                 if start.imag.any():

@@ -47,9 +47,12 @@
 #include <cstring>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -1640,15 +1643,77 @@ int apply_block(const aks_csr_block &B, const void *x, void *y, int accumulate, 
     return csr_spmv_any(B, x, y, accumulate, d_ws, stream, real, ev);
 }
 
+// ---- host threads of the planners.  A plan is a pure function of the matrix: every pass below is split into contiguous
+// ranges of row blocks whose outputs are disjoint (or are concatenated in range order), so the plan is the same bytes
+// for any number of threads.  AKS_PLAN_THREADS overrides the default min(hardware threads, 16).
+static int plan_threads(int64_t work_items, int64_t nnz) {
+    if (nnz < (int64_t)1 << 20) return 1;          // a millisecond of work: not worth starting threads for
+    int nt = 0;
+    if (const char *e = getenv("AKS_PLAN_THREADS")) nt = atoi(e);
+    if (nt <= 0) {
+        nt = (int)std::thread::hardware_concurrency();
+        if (nt > 16) nt = 16;
+    }
+    if (nt > 64) nt = 64;
+    if ((int64_t)nt > work_items) nt = (int)work_items;
+    return nt < 1 ? 1 : nt;
+}
+
+struct PlanClock {      // AKS_PLAN_TIMING=1: the planner's phases on stderr
+    bool on = getenv("AKS_PLAN_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[aks plan] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+// f(t, begin, end) on nt threads over [0, n) in contiguous ranges; the first exception is rethrown in the caller
+template <typename F>
+static void plan_parallel(int64_t n, int nt, F f) {
+    if (nt <= 1 || n <= 1) { f(0, (int64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> errs(nt);
+    for (int t = 0; t < nt; ++t)
+        pool.emplace_back([&, t] {
+            try { f(t, n * t / nt, n * (t + 1) / nt); } catch (...) { errs[t] = std::current_exception(); }
+        });
+    for (auto &th : pool) th.join();
+    for (auto &e : errs) if (e) std::rethrow_exception(e);
+}
+
 // ---- tile-binned SpMV: host-side plan and launcher
+// the big arrays of a plan: allocated WITHOUT being written (a std::vector would zero-fill -- and first-touch -- hundreds of
+// megabytes on one thread); every element is written exactly once by the pass that owns it
+template <typename T>
+struct RawArray {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    void alloc(size_t count) { p.reset(new T[count]); n = count; }
+    T *data() { return p.get(); }
+    const T *data() const { return p.get(); }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
 struct PbPlan {
     aks_pb_sizes sz;
     int32_t values_complex;
-    std::vector<double> val;             // nnz_pad (x2 if complex)
-    std::vector<uint16_t> lcol, lrow;
+    RawArray<double> val;                // nnz_pad (x2 if complex)
+    RawArray<uint16_t> lcol, lrow;
     std::vector<int32_t> slab_begin, slab_end, rb_run_ptr;
-    std::vector<aks_pb_run> runs;
+    RawArray<aks_pb_run> runs;
 };
+
+static void plan_copy(void *dst, const void *src, size_t bytes) {        // memcpy on the planner's threads
+    const int nt = plan_threads((int64_t)(bytes >> 22), (int64_t)bytes);
+    plan_parallel((int64_t)bytes, nt, [&](int, int64_t b0, int64_t b1) {
+        memcpy(static_cast<char *>(dst) + b0, static_cast<const char *>(src) + b0, (size_t)(b1 - b0));
+    });
+}
 
 int check_pb(const aks_pb_matrix *A, const void *x, const void *y) {
     if (A == nullptr || x == nullptr || y == nullptr) return fail(AKS_ERR_ARG, "null pointer");
@@ -2073,16 +2138,26 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
     std::unique_ptr<PbPlan> guard(P);
     P->values_complex = values_complex ? 1 : 0;
     // tile sizes
+    PlanClock clock;
     std::vector<int32_t> cnt(n_ss * n_rb, 0), start(n_ss * n_rb);
-    for (int64_t r = 0; r < n_rows; ++r) {
-        const int64_t rb = r >> PB_RB_BITS;
-        if (indptr[r + 1] < indptr[r]) { fail(AKS_ERR_ARG, "indptr is not monotone"); return nullptr; }
-        for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
-            const int32_t c = indices[k];
-            if (c < 0 || c >= n_cols) { fail(AKS_ERR_ARG, "column index out of range"); return nullptr; }
-            ++cnt[(int64_t)(c / PB_CW) * n_rb + rb];
+    const int nt = plan_threads(n_rb, nnz);
+    std::atomic<int> bad{0};                       // 1: indptr not monotone, 2: column out of range
+    plan_parallel(n_rb, nt, [&](int, int64_t rb0, int64_t rb1) {        // a thread owns whole row blocks: disjoint counters
+        const int64_t r_end = std::min<int64_t>(n_rows, rb1 << PB_RB_BITS);
+        for (int64_t r = rb0 << PB_RB_BITS; r < r_end; ++r) {
+            const int64_t rb = r >> PB_RB_BITS;
+            if (indptr[r + 1] < indptr[r] || indptr[r] < 0 || (int64_t)indptr[r + 1] > nnz) { bad = 1; return; }
+            for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
+                const int32_t c = indices[k];
+                if (c < 0 || c >= n_cols) { bad = 2; return; }
+                ++cnt[(int64_t)(c / PB_CW) * n_rb + rb];
+            }
         }
-    }
+    });
+    if (bad == 1) { fail(AKS_ERR_ARG, "indptr is not monotone"); return nullptr; }
+    if (bad == 2) { fail(AKS_ERR_ARG, "column index out of range"); return nullptr; }
+    if (clock.on) fprintf(stderr, "[aks plan] %d thread(s), %lld row blocks x %lld sub-slabs\n", nt, (long long)n_rb, (long long)n_ss);
+    clock.lap("count");
     // phase-1 order: (sub-slab, row block, row, column); a sub-slab's slots start on a multiple of 8
     P->slab_begin.resize(n_ss);
     P->slab_end.resize(n_ss);
@@ -2095,28 +2170,42 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
     }
     const int64_t nnz_pad = std::max<int64_t>((pos + 7) & ~(int64_t)7, 8);
     const int vw = values_complex ? 2 : 1;
-    P->val.assign((size_t)nnz_pad * vw, 0.0);
-    P->lcol.assign(nnz_pad, 0);
-    std::vector<uint16_t> row13(nnz_pad, 0);       // row inside its row block, phase-1 order
+    P->val.alloc((size_t)nnz_pad * vw);
+    P->lcol.alloc(nnz_pad);
+    RawArray<uint16_t> row13;                      // row inside its row block, phase-1 order
+    row13.alloc(nnz_pad);
+    for (int64_t s = 0; s < n_ss; ++s) {           // the padding slots behind a sub-slab (< 8 each): zero value, column 0
+        const int64_t stop = s + 1 < n_ss ? P->slab_begin[s + 1] : nnz_pad;
+        for (int64_t q = P->slab_end[s]; q < stop; ++q) {
+            for (int j = 0; j < vw; ++j) P->val[(size_t)q * vw + j] = 0.0;
+            P->lcol[q] = 0;
+            row13[q] = 0;
+        }
+    }
+    clock.lap("allocate");
     {
         std::vector<int32_t> cur(start);
         const double *vr = static_cast<const double *>(values);
-        for (int64_t r = 0; r < n_rows; ++r) {
-            const int64_t rb = r >> PB_RB_BITS;
-            for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
-                const int32_t c = indices[k];
-                const int32_t q = cur[(int64_t)(c / PB_CW) * n_rb + rb]++;
-                P->lcol[q] = (uint16_t)(c % PB_CW);
-                row13[q] = (uint16_t)(r & (PB_RB - 1));
-                if (values_complex) {
-                    P->val[2 * (size_t)q] = vr[2 * (size_t)k];
-                    P->val[2 * (size_t)q + 1] = vr[2 * (size_t)k + 1];
-                } else {
-                    P->val[q] = vr[k];
+        plan_parallel(n_rb, nt, [&](int, int64_t rb0, int64_t rb1) {    // tiles of a row block are filled by its owner only
+            const int64_t r_end = std::min<int64_t>(n_rows, rb1 << PB_RB_BITS);
+            for (int64_t r = rb0 << PB_RB_BITS; r < r_end; ++r) {
+                const int64_t rb = r >> PB_RB_BITS;
+                for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
+                    const int32_t c = indices[k];
+                    const int32_t q = cur[(int64_t)(c / PB_CW) * n_rb + rb]++;
+                    P->lcol[q] = (uint16_t)(c % PB_CW);
+                    row13[q] = (uint16_t)(r & (PB_RB - 1));
+                    if (values_complex) {
+                        P->val[2 * (size_t)q] = vr[2 * (size_t)k];
+                        P->val[2 * (size_t)q + 1] = vr[2 * (size_t)k + 1];
+                    } else {
+                        P->val[q] = vr[k];
+                    }
                 }
             }
-        }
+        });
     }
+    clock.lap("place");
     // phase-2 schedule: wave-loads (up to 64 entries from up to AKS_PB_PIECES contiguous pieces), rounds, levels
     struct Piece { uint32_t start, len; };
     struct Load { Piece pc[AKS_PB_PIECES]; int n_pc; uint32_t total; };
@@ -2128,19 +2217,26 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
         return 0u;
     };
     P->rb_run_ptr.resize(n_rb + 1);
-    // per row of the block: the last entry of the current round that adds to it
-    std::vector<int64_t> stamp(PB_RB, -1);
-    std::vector<uint8_t> last_wave(PB_RB, 0), last_level(PB_RB, 0);
-    std::vector<Load> loads;
-    int64_t round_id = 0;
     // row blocks are stored chunk by chunk, chunk c = row blocks c, c + n_chunks, ... (see k_pb_phase2)
     const int64_t n_chunks = std::min<int64_t>(n_rb, AKS_PB_CHUNKS);
     std::vector<int64_t> rb_at;
     for (int64_t c = 0; c < n_chunks; ++c)
         for (int64_t rb = c; rb < n_rb; rb += n_chunks) rb_at.push_back(rb);
-    for (int64_t pos = 0; pos < n_rb; ++pos) {
+    // every thread schedules a contiguous range of stored positions into arrays of its own; they are joined in order
+    struct Part { std::vector<aks_pb_run> runs; std::vector<uint16_t> lrow; std::vector<int64_t> runs_before; };
+    std::vector<Part> parts(nt);
+    plan_parallel(n_rb, nt, [&](int t, int64_t pos0, int64_t pos1) {
+    Part &part = parts[t];
+    std::vector<aks_pb_run> &p_runs = part.runs;
+    std::vector<uint16_t> &p_lrow = part.lrow;
+    // per row of the block: the last entry of the current round that adds to it
+    std::vector<int64_t> stamp(PB_RB, -1);
+    std::vector<uint8_t> last_wave(PB_RB, 0), last_level(PB_RB, 0);
+    std::vector<Load> loads;
+    int64_t round_id = 0;
+    for (int64_t pos = pos0; pos < pos1; ++pos) {
         const int64_t rb = rb_at[pos];
-        P->rb_run_ptr[pos] = (int32_t)P->runs.size();
+        part.runs_before.push_back((int64_t)p_runs.size());
         loads.clear();
         Load cur{};
         auto close = [&] { if (cur.total > 0) loads.push_back(cur); cur = Load{}; };
@@ -2163,15 +2259,15 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
             // entries of one row then run in wave order, one barrier-separated level per wave; inside a wave they
             // run in program order (a wave's LDS operations complete in order; lanes of one ds_add that hit the
             // same address are serialised by the LDS in a fixed order).  With PB_W = 8 waves a level fits 3 bits.
-            const size_t rr = P->runs.size(), wr = P->lrow.size();
+            const size_t rr = p_runs.size(), wr = p_lrow.size();
             ++round_id;
-            P->runs.resize(rr + PB_RPR, aks_pb_run{0u, 0u, 0u, 0u});
-            P->lrow.resize(wr + PB_RW, (uint16_t)0);
+            p_runs.resize(rr + PB_RPR, aks_pb_run{0u, 0u, 0u, 0u});
+            p_lrow.resize(wr + PB_RW, (uint16_t)0);
             uint32_t levels = 1;
             for (int slot = 0; slot < PB_RPR && next < loads.size(); ++slot, ++next) {
                 const Load &L = loads[next];
                 const int w = slot / PB_K;
-                aks_pb_run &run = P->runs[rr + slot];
+                aks_pb_run &run = p_runs[rr + slot];
                 const uint32_t l0 = L.pc[0].len, l01 = l0 + (L.n_pc > 1 ? L.pc[1].len : 0u);
                 run.start0 = L.pc[0].start;
                 run.start1 = L.n_pc > 1 ? L.pc[1].start - l0 : 0u;
@@ -2184,27 +2280,51 @@ void *aks_pb_plan_create(const int32_t *indptr, const int32_t *indices, const vo
                     stamp[row] = round_id;
                     last_wave[row] = (uint8_t)w;
                     last_level[row] = (uint8_t)lv;
-                    P->lrow[wr + (size_t)w * (PB_K * AKS_PB_RUN_MAX) + (size_t)l * PB_K + (slot % PB_K)] = (uint16_t)(row | (lv << 13));
+                    p_lrow[wr + (size_t)w * (PB_K * AKS_PB_RUN_MAX) + (size_t)l * PB_K + (slot % PB_K)] = (uint16_t)(row | (lv << 13));
                     levels = std::max(levels, lv + 1u);
                 }
             }
-            for (int j = 0; j < PB_RPR; ++j) P->runs[rr + j].info |= levels << 21;
+            for (int j = 0; j < PB_RPR; ++j) p_runs[rr + j].info |= levels << 21;
         }
-        if ((size_t)P->rb_run_ptr[pos] == P->runs.size()) {     // a row block without entries still owns one round
-            P->runs.resize(P->runs.size() + PB_RPR, aks_pb_run{0u, 0u, 0u, 1u << 21});
-            P->lrow.resize(P->lrow.size() + PB_RW, (uint16_t)0);
+        if ((size_t)part.runs_before.back() == p_runs.size()) {     // a row block without entries still owns one round
+            p_runs.resize(p_runs.size() + PB_RPR, aks_pb_run{0u, 0u, 0u, 1u << 21});
+            p_lrow.resize(p_lrow.size() + PB_RW, (uint16_t)0);
         }
-        for (int j = 0; j < PB_RPR; ++j) P->runs[P->runs.size() - PB_RPR + j].info |= 1u << 25;   // last round of the block
+        for (int j = 0; j < PB_RPR; ++j) p_runs[p_runs.size() - PB_RPR + j].info |= 1u << 25;   // last round of the block
     }
-    P->rb_run_ptr[n_rb] = (int32_t)P->runs.size();
-    // one all-empty round behind the last row block: what the kernels' clamped prefetches of a row block
-    // without rounds read
-    P->runs.resize(P->runs.size() + PB_RPR, aks_pb_run{0u, 0u, 0u, 0u});
-    P->lrow.resize(P->lrow.size() + PB_RW, (uint16_t)0);
-    if (P->runs.size() >= (size_t)INT32_MAX / 2 || P->lrow.size() >= (size_t)UINT32_MAX - 8) {
-        fail(AKS_ERR_UNSUPPORTED, "binned form: schedule too large");
-        return nullptr;
+    });
+    clock.lap("schedule");
+    {   // join the parts: positions keep their order, run indices become global
+        size_t n_runs_all = 0, n_lrow_all = 0;
+        for (const Part &pt : parts) { n_runs_all += pt.runs.size(); n_lrow_all += pt.lrow.size(); }
+        if (n_runs_all + PB_RPR >= (size_t)INT32_MAX / 2 || n_lrow_all + PB_RW >= (size_t)UINT32_MAX - 8) {
+            fail(AKS_ERR_UNSUPPORTED, "binned form: schedule too large");
+            return nullptr;
+        }
+        // one all-empty round behind the last row block: what the kernels' clamped prefetches of a row block
+        // without rounds read
+        P->runs.alloc(n_runs_all + PB_RPR);
+        P->lrow.alloc(n_lrow_all + PB_RW);
+        std::vector<size_t> run_at(nt + 1, 0), lrow_at(nt + 1, 0);
+        int64_t pos = 0;
+        for (int t = 0; t < nt; ++t) {
+            for (int64_t before : parts[t].runs_before) P->rb_run_ptr[pos++] = (int32_t)((int64_t)run_at[t] + before);
+            run_at[t + 1] = run_at[t] + parts[t].runs.size();
+            lrow_at[t + 1] = lrow_at[t] + parts[t].lrow.size();
+        }
+        plan_parallel(nt, nt, [&](int, int64_t t0, int64_t t1) {
+            for (int64_t t = t0; t < t1; ++t) {
+                if (!parts[t].runs.empty()) memcpy(P->runs.data() + run_at[t], parts[t].runs.data(), parts[t].runs.size() * sizeof(aks_pb_run));
+                if (!parts[t].lrow.empty()) memcpy(P->lrow.data() + lrow_at[t], parts[t].lrow.data(), parts[t].lrow.size() * sizeof(uint16_t));
+                std::vector<aks_pb_run>().swap(parts[t].runs);
+                std::vector<uint16_t>().swap(parts[t].lrow);
+            }
+        });
+        for (int j = 0; j < PB_RPR; ++j) P->runs[n_runs_all + j] = aks_pb_run{0u, 0u, 0u, 0u};
+        for (int j = 0; j < PB_RW; ++j) P->lrow[n_lrow_all + j] = (uint16_t)0;
+        P->rb_run_ptr[n_rb] = (int32_t)n_runs_all;
     }
+    clock.lap("join");
     P->sz.nnz_pad = nnz_pad;
     P->sz.n_runs = (int64_t)P->runs.size();
     P->sz.n_lrow = (int64_t)P->lrow.size();
@@ -2225,13 +2345,13 @@ int aks_pb_plan_export(const void *plan, void *val_out, uint16_t *lcol_out, int3
     const PbPlan *P = static_cast<const PbPlan *>(plan);
     if (!P || !val_out || !lcol_out || !slab_begin_out || !slab_end_out || !runs_out || !rb_run_ptr_out || !lrow_out)
         return fail(AKS_ERR_ARG, "null pointer");
-    memcpy(val_out, P->val.data(), P->val.size() * sizeof(double));
-    memcpy(lcol_out, P->lcol.data(), P->lcol.size() * sizeof(uint16_t));
+    plan_copy(val_out, P->val.data(), P->val.size() * sizeof(double));
+    plan_copy(lcol_out, P->lcol.data(), P->lcol.size() * sizeof(uint16_t));
     memcpy(slab_begin_out, P->slab_begin.data(), P->slab_begin.size() * sizeof(int32_t));
     memcpy(slab_end_out, P->slab_end.data(), P->slab_end.size() * sizeof(int32_t));
-    memcpy(runs_out, P->runs.data(), P->runs.size() * sizeof(aks_pb_run));
+    plan_copy(runs_out, P->runs.data(), P->runs.size() * sizeof(aks_pb_run));
     memcpy(rb_run_ptr_out, P->rb_run_ptr.data(), P->rb_run_ptr.size() * sizeof(int32_t));
-    memcpy(lrow_out, P->lrow.data(), P->lrow.size() * sizeof(uint16_t));
+    plan_copy(lrow_out, P->lrow.data(), P->lrow.size() * sizeof(uint16_t));
     return AKS_OK;
 }
 
@@ -2281,24 +2401,38 @@ int aks_sell_plan_fill(const int32_t *indptr, const int32_t *indices, const void
     const size_t vw = values_complex ? 2 : 1;
     const double *vin = static_cast<const double *>(values);
     double *vout = static_cast<double *>(val_out);
-    for (int64_t i = 0; i < total; ++i) col_out[i] = -1;
-    for (int64_t i = 0; i < total * (int64_t)vw; ++i) vout[i] = 0.0;
     int64_t p = 0;
-    for (int64_t s = 0; s < n_slices; ++s) {
+    for (int64_t s = 0; s < n_slices; ++s) {              // slice widths -> offsets (indptr only: a few milliseconds)
         slice_ptr_out[s] = p;
         int64_t w = 0;
-        for (int64_t r = s * 64; r < std::min(n_rows, s * 64 + 64); ++r) {
-            const int64_t len = indptr[r + 1] - indptr[r];
-            w = std::max(w, len);
-            for (int64_t k = 0; k < len; ++k) {
-                const int64_t q = p + k * 64 + (r - s * 64), src = indptr[r] + k;
-                col_out[q] = indices[src];
-                for (size_t c = 0; c < vw; ++c) vout[q * vw + c] = vin[src * vw + c];
-            }
-        }
+        for (int64_t r = s * 64; r < std::min(n_rows, s * 64 + 64); ++r) w = std::max<int64_t>(w, indptr[r + 1] - indptr[r]);
         p += 64 * w;
     }
     slice_ptr_out[n_slices] = p;
+    // every slice is written by one thread, entries and padding alike (no separate fill pass over the outputs)
+    try {
+        plan_parallel(n_slices, plan_threads(n_slices >> 4, indptr[n_rows]), [&](int, int64_t s0, int64_t s1) {
+            for (int64_t s = s0; s < s1; ++s) {
+                const int64_t p0 = slice_ptr_out[s], w = (slice_ptr_out[s + 1] - p0) >> 6;
+                for (int64_t lane = 0; lane < 64; ++lane) {
+                    const int64_t r = s * 64 + lane;
+                    const int64_t len = r < n_rows ? (int64_t)indptr[r + 1] - indptr[r] : 0;
+                    for (int64_t k = 0; k < len; ++k) {
+                        const int64_t q = p0 + k * 64 + lane, src = indptr[r] + k;
+                        col_out[q] = indices[src];
+                        for (size_t c = 0; c < vw; ++c) vout[q * vw + c] = vin[src * vw + c];
+                    }
+                    for (int64_t k = len; k < w; ++k) {
+                        const int64_t q = p0 + k * 64 + lane;
+                        col_out[q] = -1;
+                        for (size_t c = 0; c < vw; ++c) vout[q * vw + c] = 0.0;
+                    }
+                }
+            }
+        });
+    } catch (const std::exception &e) {
+        return fail(AKS_ERR_ARG, e.what());
+    }
     return AKS_OK;
 }
 
