@@ -78,6 +78,12 @@ class PbSizes(C.Structure):
     _fields_ = [("nnz_pad", _I64), ("n_runs", _I64), ("n_lrow", _I64), ("n_slabs", _I32), ("n_rowblocks", _I32)]
 
 
+class PbPlanArrays(C.Structure):
+    """Mirror of ``aks_pb_plan_arrays`` (host pointers into a plan, valid until it is destroyed)."""
+
+    _fields_ = [(name, _P) for name in ("val", "lcol", "slab_begin", "slab_end", "runs", "rb_run_ptr", "lrow")]
+
+
 class PbMatrix(C.Structure):
     """Mirror of ``aks_pb_matrix`` (device pointers of the tile-binned SpMV form)."""
 
@@ -135,6 +141,7 @@ SIGNATURES = {
     "aks_pb_params": (C.c_int, [C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "aks_pb_plan_create": (_P, [_P, _P, _P, _I32, _I64, _I64, C.POINTER(PbSizes)]),
     "aks_pb_plan_export": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "aks_pb_plan_view": (C.c_int, [_P, C.POINTER(PbPlanArrays)]),
     "aks_pb_plan_destroy": (None, [_P]),
     "aks_pb_spmv": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),
     "aks_sell_plan_size": (_I64, [_P, _I64]),

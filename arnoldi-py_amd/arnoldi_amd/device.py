@@ -63,6 +63,24 @@ class cached_stream:
         return False
 
 
+def host_scratch(count, dtype):
+    """Uninitialised host array for planner output that is uploaded and dropped.  Large ones live on an anonymous mapping
+    with MADV_HUGEPAGE: with transparent huge pages in "madvise" mode a 600 MB array is 300 pages instead of 150 000, and
+    neither its first touch (by the planner's threads) nor its release shows up in the set-up time any more."""
+    count = int(count)
+    nbytes = count * np.dtype(dtype).itemsize
+    if nbytes < (8 << 20):
+        return np.empty(count, dtype)
+    import mmap
+
+    mm = mmap.mmap(-1, nbytes)
+    try:
+        mm.madvise(mmap.MADV_HUGEPAGE)
+    except (AttributeError, OSError, ValueError):           # no THP on this kernel / platform: an ordinary mapping
+        pass
+    return np.frombuffer(mm, dtype=dtype, count=count)
+
+
 def canonical_csr(A):
     """scipy sparse / dense ndarray -> canonical CSR (sorted, duplicates summed),
     int32 indices, float64 or complex128 values.  Returns None for opaque operators."""
@@ -307,8 +325,8 @@ class SlicedCSR:
         nnz_pad = int(_hip.check(lib.aks_sell_plan_size(indptr.ctypes.data, n_rows), "aks_sell_plan_size"))
         n_slices = (n_rows + 63) // 64
         slice_ptr = np.empty(n_slices + 1, np.int64)
-        col = np.empty(max(nnz_pad, 1), np.int32)
-        val = np.empty(max(nnz_pad, 1), values.dtype)
+        col = host_scratch(max(nnz_pad, 1), np.int32)
+        val = host_scratch(max(nnz_pad, 1), values.dtype)
         _hip.check(lib.aks_sell_plan_fill(indptr.ctypes.data, indices.ctypes.data, values.ctypes.data, cplx, n_rows,
                                           slice_ptr.ctypes.data, col.ctypes.data, val.ctypes.data), "aks_sell_plan_fill")
         self.slice_ptr, self.col, self.val = (mem.upload(a, device) for a in (slice_ptr, col, val))
@@ -339,30 +357,41 @@ class BinnedCSR:
             msg = lib.aks_last_error()
             raise _hip.HipLibraryError(f"aks_pb_plan_create failed: {msg.decode() if msg else '?'}")
         try:
-            val = np.empty(sz.nnz_pad, values.dtype)
-            lcol = np.empty(sz.nnz_pad, np.uint16)
-            slab_begin = np.empty(sz.n_slabs, np.int32)
-            slab_end = np.empty(sz.n_slabs, np.int32)
-            runs = np.empty((sz.n_runs, 4), np.uint32)
-            rb_run_ptr = np.empty(sz.n_rowblocks + 1, np.int32)
-            lrow = np.empty(sz.n_lrow, np.uint16)
-            rc = lib.aks_pb_plan_export(plan, val.ctypes.data, lcol.ctypes.data, slab_begin.ctypes.data,
-                                        slab_end.ctypes.data, runs.ctypes.data, rb_run_ptr.ctypes.data,
-                                        lrow.ctypes.data)
-            _hip.check(rc, "aks_pb_plan_export")
+            # the plan's own arrays, uploaded straight from where the planner wrote them (aks_pb_plan_view: no second
+            # host copy of 0.6 GB at n = 10M); the views die with the plan
+            arrs = _hip.PbPlanArrays()
+            _hip.check(lib.aks_pb_plan_view(plan, C.byref(arrs)), "aks_pb_plan_view")
+
+            def view(ptr, count, dtype):
+                count = int(count)
+                if count == 0:
+                    return np.empty(0, dtype)
+                buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+                return np.frombuffer(buf, dtype=dtype, count=count)
+
+            val = view(arrs.val, sz.nnz_pad, values.dtype)
+            lcol = view(arrs.lcol, sz.nnz_pad, np.uint16)
+            slab_begin = view(arrs.slab_begin, sz.n_slabs, np.int32)
+            slab_end = view(arrs.slab_end, sz.n_slabs, np.int32)
+            runs = view(arrs.runs, 4 * sz.n_runs, np.uint32).reshape(-1, 4)
+            rb_run_ptr = view(arrs.rb_run_ptr, sz.n_rowblocks + 1, np.int32)
+            lrow = view(arrs.lrow, sz.n_lrow, np.uint16)
+            narrow = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32}     # torch has no unsigned 16/32
+            aliasing = getattr(device, "type", "cuda") == "cpu"     # CPU "device" of tests/fake_hip.py: no copy is made
+            up = lambda a: mem.upload((a.copy() if aliasing else a).view(narrow.get(a.dtype, a.dtype)), device)  # noqa: E731
+            self.val, self.lcol, self.lrow, self.runs = up(val), up(lcol), up(lrow), up(runs)
+            self.slab_begin, self.slab_end, self.rb_run_ptr = up(slab_begin), up(slab_end), up(rb_run_ptr)
+            rpr = _hip.PB_RUNS_PER_ROUND
+            info = runs[:-rpr, 3]                                   # (the last round is the planner's empty one)
+            self.levels_per_round = float(((info[::rpr] >> 21) & 15).mean()) if len(info) else 0.0
+            filled = np.count_nonzero((info >> 14) & 127)
+            self.lanes_per_load = nnz / filled if filled else 0.0   # of 64
+            # (mem.upload is synchronous for pageable host memory: the plan's arrays have been read when it returns)
+            del val, lcol, slab_begin, slab_end, runs, rb_run_ptr, lrow, info
         finally:
             lib.aks_pb_plan_destroy(plan)
-        narrow = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32}     # torch has no unsigned 16/32
-        up = lambda a: mem.upload(a.view(narrow.get(a.dtype, a.dtype)), device)  # noqa: E731
-        self.val, self.lcol, self.lrow, self.runs = up(val), up(lcol), up(lrow), up(runs)
-        self.slab_begin, self.slab_end, self.rb_run_ptr = up(slab_begin), up(slab_end), up(rb_run_ptr)
         self.prod = mem.zeros(int(sz.nnz_pad), mem.c128, device)
         self.n_slabs, self.n_rowblocks = int(sz.n_slabs), int(sz.n_rowblocks)
-        rpr = _hip.PB_RUNS_PER_ROUND
-        info = runs[:-rpr, 3]                                   # (the last round is the planner's empty one)
-        self.levels_per_round = float(((info[::rpr] >> 21) & 15).mean()) if len(info) else 0.0
-        filled = np.count_nonzero((info >> 14) & 127)
-        self.lanes_per_load = nnz / filled if filled else 0.0   # of 64
         d = _hip.PbMatrix()
         d.n_rows, d.n_cols, d.nnz, d.nnz_pad = n_rows, n_cols, nnz, int(sz.nnz_pad)
         d.n_runs, d.n_lrow = int(sz.n_runs), int(sz.n_lrow)

@@ -53,9 +53,11 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include <rccl/rccl.h>
+#include <sys/mman.h>
 
 #include "arnoldi_hip.h"
 
@@ -1687,16 +1689,34 @@ static void plan_parallel(int64_t n, int nt, F f) {
 // ---- tile-binned SpMV: host-side plan and launcher
 // the big arrays of a plan: allocated WITHOUT being written (a std::vector would zero-fill -- and first-touch -- hundreds of
 // megabytes on one thread); every element is written exactly once by the pass that owns it
+// Large ones sit on 2 MiB boundaries with MADV_HUGEPAGE: with transparent huge pages in "madvise" mode (these hosts) a
+// 400 MB array is 200 pages instead of 100 000 -- its first touch and, above all, its release (75-90 ms for the plan
+// of the 10M-row matrix with 4 KiB pages) stop being visible.
 template <typename T>
 struct RawArray {
-    std::unique_ptr<T[]> p;
+    static_assert(std::is_trivially_default_constructible<T>::value && std::is_trivially_destructible<T>::value, "raw storage");
+    struct Free { void operator()(T *q) const { free(q); } };
+    std::unique_ptr<T, Free> p;
     size_t n = 0;
-    void alloc(size_t count) { p.reset(new T[count]); n = count; }
+    void alloc(size_t count) {
+        const size_t bytes = std::max<size_t>(count * sizeof(T), 1), huge = (size_t)2 << 20;
+        void *q = nullptr;
+        if (bytes >= 2 * huge) {
+            const size_t len = (bytes + huge - 1) / huge * huge;
+            if (posix_memalign(&q, huge, len) != 0) q = nullptr;
+            if (q != nullptr) (void)madvise(q, len, MADV_HUGEPAGE);
+        } else {
+            q = malloc(bytes);
+        }
+        if (q == nullptr) throw std::bad_alloc();
+        p.reset(static_cast<T *>(q));
+        n = count;
+    }
     T *data() { return p.get(); }
     const T *data() const { return p.get(); }
     size_t size() const { return n; }
-    T &operator[](size_t i) { return p[i]; }
-    const T &operator[](size_t i) const { return p[i]; }
+    T &operator[](size_t i) { return p.get()[i]; }
+    const T &operator[](size_t i) const { return p.get()[i]; }
 };
 
 struct PbPlan {
@@ -2345,6 +2365,7 @@ int aks_pb_plan_export(const void *plan, void *val_out, uint16_t *lcol_out, int3
     const PbPlan *P = static_cast<const PbPlan *>(plan);
     if (!P || !val_out || !lcol_out || !slab_begin_out || !slab_end_out || !runs_out || !rb_run_ptr_out || !lrow_out)
         return fail(AKS_ERR_ARG, "null pointer");
+    PlanClock clock;
     plan_copy(val_out, P->val.data(), P->val.size() * sizeof(double));
     plan_copy(lcol_out, P->lcol.data(), P->lcol.size() * sizeof(uint16_t));
     memcpy(slab_begin_out, P->slab_begin.data(), P->slab_begin.size() * sizeof(int32_t));
@@ -2352,6 +2373,20 @@ int aks_pb_plan_export(const void *plan, void *val_out, uint16_t *lcol_out, int3
     plan_copy(runs_out, P->runs.data(), P->runs.size() * sizeof(aks_pb_run));
     memcpy(rb_run_ptr_out, P->rb_run_ptr.data(), P->rb_run_ptr.size() * sizeof(int32_t));
     plan_copy(lrow_out, P->lrow.data(), P->lrow.size() * sizeof(uint16_t));
+    clock.lap("export (copies)");
+    return AKS_OK;
+}
+
+int aks_pb_plan_view(const void *plan, aks_pb_plan_arrays *out) {
+    const PbPlan *P = static_cast<const PbPlan *>(plan);
+    if (!P || !out) return fail(AKS_ERR_ARG, "null pointer");
+    out->val = P->val.data();
+    out->lcol = P->lcol.data();
+    out->slab_begin = P->slab_begin.data();
+    out->slab_end = P->slab_end.data();
+    out->runs = P->runs.data();
+    out->rb_run_ptr = P->rb_run_ptr.data();
+    out->lrow = P->lrow.data();
     return AKS_OK;
 }
 

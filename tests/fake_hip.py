@@ -35,7 +35,7 @@ class FakeHip:
     def __init__(self, real):
         self._real = real
         for name in ("aks_last_error", "aks_abi_version", "aks_workspace_layout", "aks_csr_plan_tiles",
-                     "aks_pb_params", "aks_pb_plan_create", "aks_pb_plan_export", "aks_pb_plan_destroy",
+                     "aks_pb_params", "aks_pb_plan_create", "aks_pb_plan_export", "aks_pb_plan_view", "aks_pb_plan_destroy",
                      "aks_sell_plan_size", "aks_sell_plan_fill"):
             setattr(self, name, getattr(real, name))
         self.calls = []
