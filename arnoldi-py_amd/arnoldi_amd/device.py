@@ -63,24 +63,6 @@ class cached_stream:
         return False
 
 
-def host_scratch(count, dtype):
-    """Uninitialised host array for planner output that is uploaded and dropped.  Large ones live on an anonymous mapping
-    with MADV_HUGEPAGE: with transparent huge pages in "madvise" mode a 600 MB array is 300 pages instead of 150 000, and
-    neither its first touch (by the planner's threads) nor its release shows up in the set-up time any more."""
-    count = int(count)
-    nbytes = count * np.dtype(dtype).itemsize
-    if nbytes < (8 << 20):
-        return np.empty(count, dtype)
-    import mmap
-
-    mm = mmap.mmap(-1, nbytes)
-    try:
-        mm.madvise(mmap.MADV_HUGEPAGE)
-    except (AttributeError, OSError, ValueError):           # no THP on this kernel / platform: an ordinary mapping
-        pass
-    return np.frombuffer(mm, dtype=dtype, count=count)
-
-
 def canonical_csr(A):
     """scipy sparse / dense ndarray -> canonical CSR (sorted, duplicates summed),
     int32 indices, float64 or complex128 values.  Returns None for opaque operators."""
@@ -325,8 +307,8 @@ class SlicedCSR:
         nnz_pad = int(_hip.check(lib.aks_sell_plan_size(indptr.ctypes.data, n_rows), "aks_sell_plan_size"))
         n_slices = (n_rows + 63) // 64
         slice_ptr = np.empty(n_slices + 1, np.int64)
-        col = host_scratch(max(nnz_pad, 1), np.int32)
-        val = host_scratch(max(nnz_pad, 1), values.dtype)
+        col = np.empty(max(nnz_pad, 1), np.int32)
+        val = np.empty(max(nnz_pad, 1), values.dtype)
         _hip.check(lib.aks_sell_plan_fill(indptr.ctypes.data, indices.ctypes.data, values.ctypes.data, cplx, n_rows,
                                           slice_ptr.ctypes.data, col.ctypes.data, val.ctypes.data), "aks_sell_plan_fill")
         self.slice_ptr, self.col, self.val = (mem.upload(a, device) for a in (slice_ptr, col, val))
