@@ -94,10 +94,66 @@ def host_blas_threads():
                 _blas_limit = None
 
 
+_NATIVE_RANDN_FROM = 1_000_000      # below this NumPy's own loop is a few milliseconds
+_native_randn = None                # ctypes function, False once known to be unavailable
+
+
+def legacy_randn(n):
+    """``np.random.randn(n)`` -- the same bits, the same generator state afterwards -- computed by
+    ``aks_legacy_randn`` (csrc/aks_host_rng.cpp: the Mersenne Twister sequentially, the polar-method arithmetic on host
+    threads) when n is large: 3-4 x faster than NumPy's single-threaded loop at n = 10M, where that draw is the longest
+    single piece of a whole ``partial_schur`` call.  Falls back to NumPy itself -- the reference
+    implementation of this stream, not a stand-in for device work -- when the library (or a build of it without the helper:
+    tests/mock_rccl) does not export the symbol, when the global generator is not the legacy MT19937, or on any error."""
+    global _native_randn
+    n = int(n)
+    if n < _NATIVE_RANDN_FROM or _native_randn is False or os.environ.get("AKS_NATIVE_RANDN", "1") == "0":
+        return np.random.randn(n)
+    if _native_randn is None:
+        try:
+            import ctypes as C
+
+            from . import _hip
+
+            fn = C.CDLL(_hip.LIB_PATH).aks_legacy_randn
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p, C.c_int64]
+            _native_randn = fn
+        except (OSError, AttributeError):
+            _native_randn = False
+            return np.random.randn(n)
+    import ctypes as C
+
+    state = np.random.get_state()
+    if state[0] != "MT19937":
+        return np.random.randn(n)
+    key = np.array(state[1], dtype=np.uint32)                 # (a copy: the saved state stays intact)
+    pos, has_gauss, gauss = C.c_int32(int(state[2])), C.c_int32(int(state[3])), C.c_double(float(state[4]))
+    out = np.empty(n, np.float64)
+    rc = _native_randn(key.ctypes.data, C.byref(pos), C.byref(has_gauss), C.byref(gauss), out.ctypes.data, n)
+    if rc != 0:
+        np.random.set_state(state)
+        return np.random.randn(n)
+    np.random.set_state(("MT19937", key, pos.value, has_gauss.value, gauss.value))
+    return out
+
+
 def rand_normalized_vector(n, dtype=np.float64):
     """Unit 2-norm vector of ``n`` standard normals drawn from NumPy's *global* legacy
     generator, so ``np.random.seed(s)`` gives the reference's start vector bit for bit."""
-    draws = np.random.randn(n)
+    draws = legacy_randn(n)
+    if n >= _NATIVE_RANDN_FROM and np.dtype(dtype) == np.complex128:
+        # The reference's two statements (utils.py:10-11: astype, then ``v /= norm``) with the complex division spelled
+        # out: NumPy divides a complex array by a real scalar with Smith's formula, which for a divisor c + 0i is
+        # (a + b*0) * (1/c) and (b - a*0) * (1/c) -- for b = 0 the real part times the reciprocal and +0.  Same bits
+        # (tests/test_host_logic.py), a third of the time of the generic complex division at n = 10M.
+        vec = np.empty(n, np.complex128)
+        vec.real = draws
+        vec.imag = 0.0
+        norm = np.linalg.norm(vec)
+        re = vec.real
+        np.multiply(re, 1.0 / norm, out=re)
+        return vec
     vec = draws.astype(dtype)
     vec /= np.linalg.norm(vec)
     return vec

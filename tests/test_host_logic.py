@@ -603,6 +603,66 @@ def test_host_planners_under_address_and_ub_sanitizers():
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
 
 
+def test_native_legacy_randn_is_numpys_stream_bit_for_bit(monkeypatch):
+    """utils.legacy_randn / aks_legacy_randn (csrc/aks_host_rng.cpp, include/arnoldi_hostrng.h): the reference's start
+    vector is ONE np.random.randn(n) on the global legacy generator (src/arnoldi/utils.py:10); the native helper must
+    return the same bits AND leave the generator where NumPy would -- for any position in the Mersenne Twister's block,
+    with and without a cached gaussian, odd and even n, around its block sizes, for 1 and several threads."""
+    import ctypes as C
+
+    from arnoldi_amd import _hip, utils
+
+    fn = C.CDLL(_hip.LIB_PATH).aks_legacy_randn
+    fn.restype = C.c_int
+
+    def native(n):
+        st = np.random.get_state()
+        key = np.array(st[1], dtype=np.uint32)
+        pos, hg, g = C.c_int32(st[2]), C.c_int32(st[3]), C.c_double(st[4])
+        out = np.empty(n)
+        assert fn(C.c_void_p(key.ctypes.data), C.byref(pos), C.byref(hg), C.byref(g), C.c_void_p(out.ctypes.data), C.c_int64(n)) == 0
+        np.random.set_state(("MT19937", key, pos.value, hg.value, g.value))
+        return out
+
+    for threads in ("1", "5"):
+        monkeypatch.setenv("AKS_PLAN_THREADS", threads)
+        for seed, skip in ((0, 0), (7, 3), (123, 623)):
+            for n in (0, 1, 2, 3, 8191, 8192, 8193, 8194, 50_001, 300_000):
+                np.random.seed(seed)
+                np.random.rand(skip)                         # somewhere inside the generator's block of 624 words
+                if n % 3 == 1:
+                    np.random.randn(1)                       # leaves a cached second value
+                st = np.random.get_state()
+                want, after = np.random.randn(n), np.random.randn(3)
+                np.random.set_state(st)
+                got, after2 = native(n), np.random.randn(3)
+                assert np.array_equal(want, got) and np.array_equal(after, after2), (threads, seed, n)
+    # the product's entry: native from 1M entries on, NumPy below; the start vector of the reference either way
+    np.random.seed(3)
+    want = np.random.randn(1_200_001)
+    tail = np.random.rand(2)
+    np.random.seed(3)
+    got = utils.legacy_randn(1_200_001)
+    assert utils._native_randn not in (None, False)          # the in-tree library exports the helper
+    assert np.array_equal(want, got) and np.array_equal(tail, np.random.rand(2))
+    for seed, n in ((0, 1_000_000), (5, 1_000_003)):         # the reference's two statements, verbatim, against the fast spelling
+        np.random.seed(seed)
+        v = utils.rand_normalized_vector(n, C128)
+        np.random.seed(seed)
+        w = np.random.randn(n).astype(C128)
+        w /= np.linalg.norm(w)
+        assert np.array_equal(v.view(np.uint64), w.view(np.uint64))      # bits, signs of zeros included
+        np.random.seed(seed)
+        r = utils.rand_normalized_vector(n)
+        np.random.seed(seed)
+        wr = np.random.randn(n).astype(np.float64)
+        wr /= np.linalg.norm(wr)
+        assert np.array_equal(r, wr)
+    monkeypatch.setenv("AKS_NATIVE_RANDN", "0")               # switch: NumPy's own loop
+    np.random.seed(3)
+    assert np.array_equal(utils.legacy_randn(1_200_001), want)
+
+
 def test_host_planners_are_thread_count_independent_and_race_free():
     """The binned and sliced planners split their passes over host threads (``AKS_PLAN_THREADS``, default
     min(hardware threads, 16): 0.64 -> 0.10 s for the 10M-row headline matrix, most of a call's time to solution).
