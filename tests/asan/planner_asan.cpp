@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE (CPU only): drives the HOST-SIDE planner entry points of libarnoldi_hip -- index-heavy C++
 // that nothing but functional tests had looked at -- in a build with -fsanitize=address,undefined on the host code
 // (the device code is compiled as usual and never launched here: no GPU is needed).
-//   aks_workspace_layout, aks_csr_plan_tiles, aks_pb_plan_create / _export / _destroy, aks_sell_plan_size / _fill
+//   aks_workspace_layout, aks_csr_plan_tiles, aks_pb_plan_create / _export / _view / _destroy, aks_sell_plan_size / _fill
 // on the shapes of tests/test_gpu_parity.py::test_spmv_forms_agree_on_random_shapes plus degenerate ones
 // (no entries, one row, rows of every length incl. empty ones and a hub row, non-square blocks, complex values,
 // more row blocks than AKS_PB_CHUNKS, a tile count the binned form must refuse).  Every planned array is also
@@ -100,6 +100,15 @@ static void check(const Csr &A, const char *what) {
         std::vector<int32_t> sb(sz.n_slabs), se(sz.n_slabs), rbp(sz.n_rowblocks + 1);
         std::vector<aks_pb_run> runs(sz.n_runs);
         REQUIRE(aks_pb_plan_export(plan, v.data(), lcol.data(), sb.data(), se.data(), runs.data(), rbp.data(), lrow.data()) == AKS_OK);
+        {   // the zero-copy view names the same bytes
+            aks_pb_plan_arrays pa;
+            REQUIRE(aks_pb_plan_view(plan, &pa) == AKS_OK && aks_pb_plan_view(nullptr, &pa) != AKS_OK);
+            REQUIRE(aks_pb_plan_view(plan, &pa) == AKS_OK);
+            REQUIRE(memcmp(pa.val, v.data(), v.size() * sizeof(v[0])) == 0 && memcmp(pa.lcol, lcol.data(), lcol.size() * 2) == 0);
+            REQUIRE(memcmp(pa.slab_begin, sb.data(), sb.size() * 4) == 0 && memcmp(pa.slab_end, se.data(), se.size() * 4) == 0);
+            REQUIRE(memcmp(pa.runs, runs.data(), runs.size() * sizeof(aks_pb_run)) == 0 && memcmp(pa.rb_run_ptr, rbp.data(), rbp.size() * 4) == 0);
+            REQUIRE(memcmp(pa.lrow, lrow.data(), lrow.size() * 2) == 0);
+        }
         aks_pb_plan_destroy(plan);
         int32_t slab_bits, rb_bits, rpr;
         REQUIRE(aks_pb_params(&slab_bits, &rb_bits, &rpr) == AKS_OK);
