@@ -339,7 +339,22 @@ def _measure(args, comm, world, rank):
     r0, r1 = int(offsets[rank]), int(offsets[rank + 1])
     t_setup = time.perf_counter()
     rows = build_rows(args, r0, r1, n, dims)
+    t_rows = time.perf_counter() - t_setup
+    prof = None
+    if os.environ.get("AKS_PROFILE_SETUP") and rank == 0:        # where the operator set-up spends its host time (stderr)
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     op = CsrOperator(local_rows=rows, offsets=offsets, comm=comm, real=real)
+    if prof is not None:
+        import io
+        import pstats
+
+        prof.disable()
+        text = io.StringIO()
+        pstats.Stats(prof, stream=text).sort_stats("cumulative").print_stats(30)
+        sys.stderr.write(f"[bench] rows built in {t_rows:.2f} s; CsrOperator set-up on rank 0:\n" + text.getvalue()[:7000])
     del rows
     nnz_local = op.nnz
 
