@@ -122,10 +122,11 @@ class DeviceCSR:
         _hip.check(nt, "aks_csr_plan_tiles")
         self.n_tiles = int(nt)
         self.lanes_per_row = lanes_per_row or choose_lanes_per_row(self.n_rows, self.nnz)
-        self.indptr = mem.upload(indptr, device)
-        self.indices = mem.upload(np.ascontiguousarray(M.indices, dtype=np.int32), device)
-        self.values = mem.upload(np.ascontiguousarray(M.data), device)
-        self.tiles = mem.upload(tiles[: self.n_tiles + 1].copy(), device)
+        # The arrays of the CSR-stream kernel go to the device when that form is first needed (``_csr_arrays``): a
+        # matrix that ends up in the binned or sliced form never uploads them (0.6 GB of HBM and of host-to-device
+        # traffic at n = 10M).
+        self._tiles_host = tiles[: self.n_tiles + 1].copy()
+        self.indptr = self.indices = self.values = self.tiles = None
 
         self._host = M            # kept until the SpMV form has been chosen (autotune)
         self.binned = None        # BinnedCSR once built
@@ -140,12 +141,31 @@ class DeviceCSR:
     def use_binned(self, flag):
         self.form = "binned" if flag else "csr"
 
+    def _csr_arrays(self):
+        """Upload the CSR-stream kernel's arrays on first use (needs the host copy: before ``autotune`` releases it,
+        or -- after it -- only if the CSR-stream form was the one chosen)."""
+        if self.indptr is None:
+            M = self._host
+            if M is None:
+                raise _hip.HipLibraryError("the CSR-stream form of this matrix was not kept: another form was chosen "
+                                           "and the host copy released (build the DeviceCSR with force='csr')")
+            self.indptr = mem.upload(np.ascontiguousarray(M.indptr, dtype=np.int32), self.device)
+            self.indices = mem.upload(np.ascontiguousarray(M.indices, dtype=np.int32), self.device)
+            self.values = mem.upload(np.ascontiguousarray(M.data), self.device)
+            self.tiles = mem.upload(self._tiles_host, self.device)
+        return self.indptr, self.indices, self.values, self.tiles
+
     def block(self, out=None):
         """Fill (and return) an ``aks_csr_block`` for this matrix with the SpMV form in use."""
         b = out if out is not None else _hip.CsrBlock()
         b.n_rows, b.n_cols = self.n_rows, self.n_cols
-        b.d_indptr, b.d_indices, b.d_values = self.indptr.data_ptr(), self.indices.data_ptr(), self.values.data_ptr()
-        b.d_tiles, b.n_tiles = self.tiles.data_ptr(), self.n_tiles
+        if self.form == "csr":
+            indptr, indices, values, tiles = self._csr_arrays()
+            b.d_indptr, b.d_indices, b.d_values = indptr.data_ptr(), indices.data_ptr(), values.data_ptr()
+            b.d_tiles, b.n_tiles = tiles.data_ptr(), self.n_tiles
+        else:                                   # (apply_block dispatches on pb / sell first: these are never read)
+            b.d_indptr = b.d_indices = b.d_values = b.d_tiles = None
+            b.n_tiles = self.n_tiles
         b.values_complex, b.lanes_per_row = self.values_complex, self.lanes_per_row
         b.pb = C.pointer(self.binned.desc) if self.form == "binned" else None
         b.sell = C.pointer(self.sliced.desc) if self.form == "sliced" else None
@@ -262,6 +282,10 @@ class DeviceCSR:
         if choice != "sliced":
             self.sliced = None
         self.form = choice
+        if choice == "csr":
+            self._csr_arrays()                  # (while the host copy is still there)
+        else:
+            self.indptr = self.indices = self.values = self.tiles = None     # (a measured tuning run uploaded them)
         self._host = None
         return choice
 
@@ -283,10 +307,12 @@ class DeviceCSR:
         elif self.form == "sliced":
             rc = getattr(lib, "aks_sell_spmv" + sfx)(C.byref(self.sliced.desc), _ptr(x), _ptr(y), int(accumulate), wsp, _stream())
         elif real:
+            self._csr_arrays()
             rc = lib.aks_csr_spmv_real(self.n_rows, _ptr(self.indptr), _ptr(self.indices), _ptr(self.values),
                                        _ptr(self.tiles), self.n_tiles, self.lanes_per_row, _ptr(x), _ptr(y),
                                        int(accumulate), wsp, _stream())
         else:
+            self._csr_arrays()
             rc = lib.aks_csr_spmv(self.n_rows, _ptr(self.indptr), _ptr(self.indices), _ptr(self.values),
                                   self.values_complex, _ptr(self.tiles), self.n_tiles, self.lanes_per_row, _ptr(x),
                                   _ptr(y), int(accumulate), wsp, _stream())
