@@ -50,6 +50,7 @@
 #include <atomic>
 #include <chrono>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -57,6 +58,7 @@
 #include <vector>
 
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <sys/mman.h>
 
 #include "arnoldi_hip.h"
@@ -1609,8 +1611,62 @@ struct Comm {
     int rank = 0, size = 1;
 };
 
+// RCCL is loaded when the first communicator is asked for, not with the library: librccl.so is hundreds of megabytes of
+// code objects whose registration costs a process 1.2 s at load time (5 s from a cold page cache) -- a single-GPU solve,
+// which never calls it, should not pay that (a torch process has it loaded already; the torch-free backend has not:
+// profiles/cold_process_probe.py).  Types and constants come from <rccl/rccl.h>; the nine entry points through this table.
+#ifdef AKS_RCCL_DIRECT             // tests/mock_rccl: the stand-in is linked in, its symbols renamed on the command line
+#define NCCL_CALL(name) nccl##name
+static int rccl_load() { return AKS_OK; }
+#else
+struct RcclApi {
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+};
+static RcclApi g_rccl;                  // filled once (std::call_once), read-only afterwards
+static std::once_flag g_rccl_once;
+static std::string g_rccl_error;        // why loading failed (written once, inside call_once)
+#define NCCL_CALL(name) g_rccl.name
+static int rccl_load() {
+    std::call_once(g_rccl_once, [] {
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h != nullptr) break;
+        }
+        if (h == nullptr) {
+            const char *why = dlerror();
+            g_rccl_error = std::string("librccl.so could not be loaded: ") + (why ? why : "?");
+            return;
+        }
+        bool ok = true;
+        auto sym = [&](const char *name) { void *p = dlsym(h, name); if (p == nullptr) { ok = false; g_rccl_error = std::string("librccl.so lacks ") + name; } return p; };
+        RcclApi api;
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+        api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+        api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+        if (ok) g_rccl = api;
+    });
+    if (g_rccl.AllReduce == nullptr) return fail(AKS_ERR_HIP, g_rccl_error.empty() ? "librccl.so could not be loaded" : g_rccl_error.c_str());
+    return AKS_OK;
+}
+#endif
+
 int nccl_fail(ncclResult_t r, const char *where) {
-    g_err = std::string(where) + ": " + ncclGetErrorString(r);
+    g_err = std::string(where) + ": " + NCCL_CALL(GetErrorString)(r);
     return AKS_ERR_HIP;
 }
 
@@ -2485,8 +2541,9 @@ int aks_sell_spmv_real(const aks_sell_matrix *A, const double *d_x, double *d_y,
 int aks_comm_unique_id(void *id_out) {
     static_assert(sizeof(ncclUniqueId) <= AKS_COMM_ID_BYTES, "AKS_COMM_ID_BYTES too small");
     if (id_out == nullptr) return fail(AKS_ERR_ARG, "null pointer");
+    if (rccl_load() != AKS_OK) return AKS_ERR_HIP;
     ncclUniqueId id;
-    ncclResult_t r = ncclGetUniqueId(&id);
+    ncclResult_t r = NCCL_CALL(GetUniqueId)(&id);
     if (r != ncclSuccess) return nccl_fail(r, "ncclGetUniqueId");
     memset(id_out, 0, AKS_COMM_ID_BYTES);
     memcpy(id_out, &id, sizeof id);
@@ -2496,13 +2553,14 @@ int aks_comm_unique_id(void *id_out) {
 int aks_comm_create(const void *id, int32_t rank, int32_t size, void **comm_out) {
     if (id == nullptr || comm_out == nullptr) return fail(AKS_ERR_ARG, "null pointer");
     if (size < 1 || rank < 0 || rank >= size) return fail(AKS_ERR_ARG, "need 0 <= rank < size");
+    if (rccl_load() != AKS_OK) return AKS_ERR_HIP;
     Comm *c = new (std::nothrow) Comm();
     if (c == nullptr) return fail(AKS_ERR_ARG, "out of host memory");
     c->rank = rank;
     c->size = size;
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
-    ncclResult_t r = ncclCommInitRank(&c->nccl, size, uid, rank);
+    ncclResult_t r = NCCL_CALL(CommInitRank)(&c->nccl, size, uid, rank);
     if (r != ncclSuccess) { delete c; return nccl_fail(r, "ncclCommInitRank"); }
     hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->packed, hipEventDisableTiming);
@@ -2518,7 +2576,7 @@ int aks_comm_destroy(void *comm) {
     if (c->packed) (void)hipEventDestroy(c->packed);
     if (c->arrived) (void)hipEventDestroy(c->arrived);
     if (c->side) (void)hipStreamDestroy(c->side);
-    if (c->nccl) (void)ncclCommDestroy(c->nccl);
+    if (c->nccl) (void)NCCL_CALL(CommDestroy)(c->nccl);
     delete c;
     return AKS_OK;
 }
@@ -2526,7 +2584,7 @@ int aks_comm_destroy(void *comm) {
 int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *stream) {
     Comm *c = static_cast<Comm *>(comm);
     if (c == nullptr || d_buf == nullptr || count < 1) return fail(AKS_ERR_ARG, "bad argument");
-    ncclResult_t r = ncclAllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->nccl, static_cast<hipStream_t>(stream));
+    ncclResult_t r = NCCL_CALL(AllReduce)(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->nccl, static_cast<hipStream_t>(stream));
     if (r != ncclSuccess) return nccl_fail(r, "ncclAllReduce");
     return AKS_OK;
 }
@@ -2587,16 +2645,16 @@ static int shard_apply(const aks_shard *A, const void *d_x, void *d_y, const voi
         const size_t words = real ? 1 : 2;
         const double *sb = static_cast<const double *>(A->d_sendbuf);
         double *gb = static_cast<double *>(A->d_ghostbuf);
-        ncclResult_t r = ncclGroupStart();
+        ncclResult_t r = NCCL_CALL(GroupStart)();
         int64_t so = 0, ro = 0;
         for (int peer = 0; peer < c->size && r == ncclSuccess; ++peer) {
             const int64_t ns = A->send_counts[peer], nr = A->recv_counts[peer];
-            if (ns > 0) r = ncclSend(sb + so * words, (size_t)ns * words, ncclDouble, peer, c->nccl, c->side);
-            if (nr > 0 && r == ncclSuccess) r = ncclRecv(gb + ro * words, (size_t)nr * words, ncclDouble, peer, c->nccl, c->side);
+            if (ns > 0) r = NCCL_CALL(Send)(sb + so * words, (size_t)ns * words, ncclDouble, peer, c->nccl, c->side);
+            if (nr > 0 && r == ncclSuccess) r = NCCL_CALL(Recv)(gb + ro * words, (size_t)nr * words, ncclDouble, peer, c->nccl, c->side);
             so += ns;
             ro += nr;
         }
-        const ncclResult_t r2 = ncclGroupEnd();
+        const ncclResult_t r2 = NCCL_CALL(GroupEnd)();
         if (r != ncclSuccess) return nccl_fail(r, "ncclSend/ncclRecv");
         if (r2 != ncclSuccess) return nccl_fail(r2, "ncclGroupEnd");
     }
