@@ -1,3 +1,6 @@
+"""cProfile of the FIRST partial_schur call of a process (README example); run with AKS_HOST_ALLOC=hip to see what a torch-free
+process pays before its first solve (round 4: 4.97 s of 5.29 s were dlopen of the library -> librccl.so; now loaded lazily).
+    AKS_HOST_ALLOC=hip python profiles/hip_first_call_profile.py"""
 import os, sys, time, cProfile, pstats, io
 ROOT=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
 sys.path.insert(0, os.path.join(ROOT,"arnoldi-py_amd"))
