@@ -178,34 +178,18 @@ __device__ __forceinline__ void transpose_reduce_step(double (&v)[KP], int lane)
     }
 }
 
-// ---- second stage of the reductions inside the producing kernel (round 4) ------------------------------------------
-// Rounds 1-3 summed the per-workgroup partial rows with a kernel of their own (k_reduce, one workgroup per column):
-// three extra launches per Arnoldi step, ~10 % of the device's busy time at the 8-GPU shard sizes (1.25M rows,
-// profiles/r03_small_trace.txt).  Now the LAST workgroup of a panel kernel to finish does it: every workgroup stores
-// its partial row write-through (sc1), drains (s_waitcnt vmcnt(0)), and one lane draws a ticket with an agent-scope
-// atomic add; the workgroup that draws gridDim.x - 1 reads all rows back with sc1 loads (they bypass its L1, which
-// no other CU's store ever refreshes) and sums them in EXACTLY k_reduce's order -- thread t takes rows t, t + 256, ...
-// in increasing order, then the wave butterfly (the transpose form below is the same balanced tree: partners differ
-// in lane bit 5, then 4, ..., and addition commutes), then the four wave totals in wave order starting from 0.0 -- so
-// H and every other number are bit for bit what the separate kernel produced.  (Hand-off form: MI355X_MICROARCH.md,
-// "Workgroup dispatch, XCD placement & inter-workgroup visibility", valid-forms table row 1: one lane's agent-scope
-// add per storing workgroup after every storing wave's drain and a workgroup barrier, the last arriver told by the
-// value its add returned, every handed-off byte stored and loaded sc1.)  The ticket words live in the control block;
-// the last arriver zeroes its word again, aks_workspace_init zeroes them all.
-//
-// MEASURED (profiles/r04_tail_ab.txt, whole restarts, builds interleaved on one box): on the two wide panel kernels this
-// is a LOSS -- restarts/s -4 % at n = 1.25M (random CSR and Markov, m = 20), -4 % on a 2M-row 3-D Laplacian (m = 40),
-// -0.6 % at n = 10M: a streaming kernel's 256 workgroups finish within a microsecond of each other, their 256 arrivals
-// queue on the one counter (11 - 13 ns each, MI355X_MICROARCH.md "fanin": 3.6 - 4.5 us under streaming load), and the
-// last arriver then still has a dependent round of sc1 reads in front of it -- more than the kernel boundary (~2 us)
-// plus the 21-workgroup k_reduce it replaces.  (The 4.4 - 4.9 us per one-block launch that profiles/r03_small_trace.txt
-// shows, and VERDICT r03 counted, is rocprofv3's per-dispatch overhead; in an un-profiled stream a Gram-Schmidt
-// step's five small launches cost ~10 us together.)  So the panel kernels keep their k_reduce (AKS_TAIL_PANEL = 0;
-// build with 1 for the in-kernel form), and the mechanism serves the place where it removes launches without adding
-// arrivals to the common path: the second-pass kernel, see FIN_* below (AKS_FOLD_FINISH).
-#ifndef AKS_TAIL_PANEL
-#define AKS_TAIL_PANEL 0
-#endif
+// ---- last-arriver hand-off: the second stage of a reduction inside the producing kernel ---------------------------------
+// The panel kernels sum their per-workgroup partial rows with a kernel of their own (k_reduce).  The second-pass kernel
+// (k_update<true>) instead lets the LAST workgroup to finish do it when it also books the step (FIN_* below), which
+// removes two launches (k_reduce<true> and k_finish) from every step that takes the second pass: every workgroup stores
+// its partial write-through (sc1), drains (s_waitcnt vmcnt(0)), and one lane draws a ticket with an agent-scope atomic
+// add behind the workgroup barrier; the workgroup that draws gridDim.x - 1 performs an agent-scope acquire, reads all
+// partials back with sc1 loads and sums them in EXACTLY k_reduce's order -- thread t takes rows t, t + 256, ... in
+// increasing order, then block_sum -- so H and every other number are bit for bit what the separate kernels produced.
+// The ticket words live in the control block; the last arriver zeroes its word again, aks_workspace_init zeroes them all.
+// (The same mechanism inside the two wide panel kernels was measured a LOSS -- 256 arrivals queue on one counter behind a
+// streaming kernel whose workgroups all finish within a microsecond -- and is not in this file: profiles/HISTORY.md,
+// profiles/r04_tail_ab.txt, profiles/r05_removed_variants.patch.)
 #ifndef AKS_FOLD_FINISH
 #define AKS_FOLD_FINISH 1
 #endif
@@ -222,27 +206,33 @@ __device__ __forceinline__ c128 ld_partial(const c128 *p) {
 }
 // All threads of the workgroup call this after their partial-row stores.  True in every thread of the workgroup that
 // arrived last (all rows of `partial` written by this launch are then complete and readable with ld_partial).
+// The hand-off in the documented release / acquire form (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement &
+// inter-workgroup visibility"):
+//   producer  every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, then ONE lane
+//             issues an agent-scope RELEASE (buffer_wbl2 sc1 + wait) and draws its ticket with an agent-scope add;
+//   consumer  the lane whose add returned gridDim.x - 1 issues an agent-scope ACQUIRE (buffer_inv sc1), waits for it,
+//             and only then releases the workgroup's other waves through the second barrier.
+// The partials are in addition stored and loaded write-through / L1-bypassing (st_partial / ld_partial: sc1), which the
+// guide measures as valid on its own only with one workgroup per CU -- the second-pass kernel runs two, and round 4's
+// tree, which had neither fence, once in a while summed one STALE partial at full size (beta off by 1/512: residual
+// 2.2e-3 instead of 8.7e-9).  tests/test_gpu_parity.py::test_ticket_hand_off_books_the_step pins the hand-off.
+#ifndef AKS_TICKET_RELEASE
+#define AKS_TICKET_RELEASE 1
+#endif
 __device__ __forceinline__ bool last_block_arrives(unsigned *ticket) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // EVERY storing wave: its sc1 stores have left the CU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // EVERY storing wave: its stores have left the CU
     __shared__ int s_last;
     __syncthreads();
     if (threadIdx.x == 0) {
+#if AKS_TICKET_RELEASE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
         const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = old + 1u == gridDim.x;
         if (last) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // for the next launch
-            // the consumer's agent-scope acquire (MI355X_MICROARCH.md, "Consumer, always"): sc1 loads alone are only
-            // measured valid with ONE workgroup per CU, and the second-pass kernel runs two -- without this fence a
-            // full-size solve once in a while summed one STALE partial (a 1/512 error in beta: the residual 2.2e-3
-            // instead of 8.7e-9 of tests/test_gpu_sharded_full.py's one-GPU leg, round 4).  One lane fences, its
-            // s_waitcnt holds the barrier below until the invalidate has completed; ~1.7 us, on the last workgroup only.
-#ifndef AKS_TICKET_ACQUIRE
-#define AKS_TICKET_ACQUIRE 1
-#endif
-#if AKS_TICKET_ACQUIRE
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // holds the barrier below until the invalidate is complete
         }
         s_last = last;
     }
@@ -253,12 +243,10 @@ __device__ __forceinline__ bool last_block_arrives(unsigned *ticket) {
 // Block-wide sums of the 2 NC + 1 accumulators of the panel kernels:
 //   out[c] = (sum ar[c], sum ai[c]) for c < NC, and *nrm_out = sum nrm (if nrm_out != nullptr).
 // Fixed evaluation order => bitwise reproducible.  Must be called by all 256 threads.
-// FINAL = false: `out` is this workgroup's partial row (write-through stores, see above).  FINAL = true: the inputs are
-// sums over partial rows and `out` is the reduction slot the next stage reads (plain stores; `drop_im`: real-packed
-// panels keep Re only, as k_reduce does).
-template <int NC, bool FINAL = false>
+// `out` is this workgroup's partial row, which k_reduce sums.
+template <int NC>
 __device__ __forceinline__ void block_reduce_panel(const double (&ar)[NC], const double (&ai)[NC], double nrm,
-                                                   c128 *__restrict__ out, c128 *__restrict__ nrm_out, bool drop_im = false) {
+                                                   c128 *__restrict__ out, c128 *__restrict__ nrm_out) {
     constexpr int K = 2 * NC + 1;
     constexpr int ROUNDS = (K + 63) / 64;
     constexpr int KP = ROUNDS == 1 ? next_pow2(K) : 64;   // values per round
@@ -283,39 +271,14 @@ __device__ __forceinline__ void block_reduce_panel(const double (&ar)[NC], const
         double sr = 0.0, si = 0.0;
 #pragma unroll
         for (int k = 0; k < WAVES; ++k) { sr += red[k][2 * t]; si += red[k][2 * t + 1]; }
-        if (FINAL) out[t] = make_double2(sr, drop_im ? 0.0 : si);
-        else st_partial(&out[t], sr, si);
+        out[t] = make_double2(sr, si);
     }
     if (nrm_out != nullptr && t == 64) {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < WAVES; ++k) s += red[k][2 * NC];
-        if (FINAL) *nrm_out = make_double2(s, 0.0);
-        else st_partial(nrm_out, s, 0.0);
+        *nrm_out = make_double2(s, 0.0);
     }
-}
-
-// The last workgroup's part: red_out[0 .. NC] = sum over the launch's partial rows of columns 0 .. NC (NC projections
-// + the norm slot), k_reduce's order (see above).  `zero_slot` as in k_reduce.
-template <int NC>
-__device__ __forceinline__ void tail_reduce_panel(const c128 *partial, int ldp, c128 *__restrict__ red_out,
-                                                  c128 *__restrict__ zero_slot, bool real_mode) {
-    double ar[NC], ai[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) ar[c] = ai[c] = 0.0;
-    double nrm = 0.0;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += BLOCK) {
-        const c128 *row = partial + (int64_t)b * ldp;
-        c128 pv[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) pv[c] = ld_partial(&row[c]);
-        const c128 pn = ld_partial(&row[NC]);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { ar[c] += pv[c].x; ai[c] += pv[c].y; }
-        nrm += pn.x;
-    }
-    block_reduce_panel<NC, true>(ar, ai, nrm, red_out, red_out + NC, real_mode);
-    if (zero_slot != nullptr && threadIdx.x == 0) zero_slot[0] = make_double2(0.0, 0.0);
 }
 
 // Deferred normalisation (AKS_EXPAND_DEFER_SCALE).  The reference normalises a new basis vector at once
@@ -337,14 +300,11 @@ __device__ __forceinline__ bool second_pass_needed(const c128 *red1, const c128 
 // ------------------------------------------------------------------ projection
 // partial[bx*ldp + c0 + c] = sum over this block's rows of conj(V[i, c0+c]) * w[i]
 // partial[bx*ldp + nrm_slot] = sum |w[i]|^2                    (only if nrm_slot >= 0)
-// red_out != nullptr (only with c0 == 0 and nrm_slot == NC: the one launch that covers the whole panel): the last
-// workgroup to finish also sums the partial rows into red_out[0 .. NC] (see "second stage ... inside the producing kernel").
 template <int NC>
 __global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *__restrict__ V, int64_t ldv,
                                                const c128 *__restrict__ w, c128 *partial,
                                                int ldp, int nrm_slot, const aks_ctrl *__restrict__ ctrl,
-                                               const double *__restrict__ cs, int raw0, c128 *__restrict__ red_out,
-                                               unsigned *ticket, c128 *__restrict__ zero_slot) {
+                                               const double *__restrict__ cs, int raw0) {
     if (ctrl->broken) return;
     __shared__ double ssc[NC];                            // scales of this group's columns (raw columns: >= raw0)
     if (threadIdx.x < NC) ssc[threadIdx.x] = cs[c0 + threadIdx.x];
@@ -372,8 +332,6 @@ __global__ __launch_bounds__(BLOCK) void k_proj(int64_t n, int c0, const c128 *_
     }
     c128 *row = partial + (int64_t)blockIdx.x * ldp;
     block_reduce_panel<NC>(ar, ai, nrm, row + c0, nrm_slot >= 0 ? row + nrm_slot : nullptr);
-    if (red_out == nullptr) return;                        // (kernel argument: uniform over the grid)
-    if (last_block_arrives(ticket)) tail_reduce_panel<NC>(partial, ldp, red_out, zero_slot, ctrl->real_mode != 0);
 }
 
 // ------------------------------------------------------------------ fused update + re-projection
@@ -386,8 +344,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__
                                                       c128 *__restrict__ w, const c128 *__restrict__ h,
                                                       c128 *partial, int ldp,
                                                       const aks_ctrl *__restrict__ ctrl,
-                                                      const double *__restrict__ cs, int raw0,
-                                                      c128 *__restrict__ red_out, unsigned *ticket) {
+                                                      const double *__restrict__ cs, int raw0) {
     if (ctrl->broken) return;
     __shared__ c128 hs[NC];
     __shared__ double ssc[NC];
@@ -429,8 +386,6 @@ __global__ __launch_bounds__(BLOCK) void k_update_proj(int64_t n, const c128 *__
     }
     c128 *row = partial + (int64_t)blockIdx.x * ldp;
     block_reduce_panel<NC>(ar, ai, nrm, row, row + NC);
-    if (red_out == nullptr) return;
-    if (last_block_arrives(ticket)) tail_reduce_panel<NC>(partial, ldp, red_out, nullptr, ctrl->real_mode != 0);
 }
 
 // ------------------------------------------------------------------ fused update + re-projection, wide panels
@@ -659,76 +614,14 @@ __global__ __launch_bounds__(BLOCK) void k_update(int64_t n, int J, const c128 *
     second_pass_tail(s, partial, ldp, nrm_slot, J, red1, red2, ctrl, fin, red_n);
 }
 
-// The same with the panel width as a template parameter (J <= 40): all NC column loads of a row are in flight at
-// once instead of four at a time -- the recipe of k_update_proj without its re-projection accumulators, so 4 NC
-// instead of 8 NC registers (the generic kernel ran at 5.7 - 6.1 TB/s where the projection reaches
-// 6.3 - 6.9; it is 27 - 30 % of the device time on the Laplacians, whose every step takes the second pass).  Same
-// arithmetic in the same order as k_update<true>: w comes out bit for bit the same.
-// MEASURED AND NOT SHIPPED (profiles/r04_update_nc_ab.txt, r04_tail_ab.txt "sep" against "sepgen"): at n = 16M the generic
-// kernel runs at 5.9 - 6.5 TB/s for J = 16 .. 40 and every geometry of this one (256 / 512 / 1024 / 2048 workgroups,
-// coefficients in registers or in LDS) at 5.7 - 6.3, 0 - 2 % behind width by width (2M rows: +-1 %, ahead only at
-// J = 40); whole restarts 9.12 against 9.31 (3-D Laplace 16M) and 66.7 against 67.4 restarts/s (2M).  The second pass
-// is a read stream with one rewritten column, like the fused update, and sits at that pattern's rate with
-// four loads in flight per lane as well as with forty.  Compiled only with -DAKS_UPDATE_EXACT_MAX=<widest J>.
-#ifndef AKS_UPDATE_EXACT_MAX
-#define AKS_UPDATE_EXACT_MAX 0        // widest exact-width second-pass kernel (0: the generic kernel at every width)
-#endif
-#if AKS_UPDATE_EXACT_MAX > 0
-template <int NC>
-__global__ __launch_bounds__(BLOCK) void k_update_nc(int64_t n, const c128 *__restrict__ V, int64_t ldv,
-                                                    c128 *__restrict__ w, const c128 *__restrict__ h,
-                                                    c128 *partial, int ldp, int nrm_slot,
-                                                    const c128 *red1, const c128 *red2, double eta, aks_ctrl *ctrl,
-                                                    const double *__restrict__ cs, int raw0, FinArgs fin) {
-    if (ctrl->broken) return;
-    if (!second_pass_needed(red1, red2, NC, eta)) {
-        if (fin.mode != FIN_NONE && blockIdx.x == 0)
-            finish_step(NC, fin.Hcol, fin.ldh, fin.tol, fin.normalize, red1, red2, false, 0.0, ctrl, fin.cs);
-        return;
-    }
-    __shared__ c128 hs[NC];
-    __shared__ double ssc[NC];
-    __shared__ double red_n[WAVES];
-    if (threadIdx.x < NC) { hs[threadIdx.x] = h[threadIdx.x]; ssc[threadIdx.x] = cs[threadIdx.x]; }
-    __syncthreads();
-    double nrm = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        // coefficients re-read from LDS per tile above this width (as in k_update_proj; without its accumulators the
-        // kernel then needs ~4 NC + 30 registers: 4 waves per SIMD at NC = 20, 2 at NC = 40)
-#ifndef AKS_UPDNC_HS_LDS_FROM
-#define AKS_UPDNC_HS_LDS_FROM 8
-#endif
-        if constexpr (NC > AKS_UPDNC_HS_LDS_FROM) asm volatile("" ::: "memory");
-        c128 wv = w[i];
-        c128 v[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = ld_panel(&V[i + (int64_t)c * ldv]);
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-            if (c >= raw0 && is_raw(ssc[c])) v[c] = unscale(v[c], ssc[c]);           // (wave-uniform)
-        double sr = 0.0, si = 0.0;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const c128 hc = hs[c];
-            sr = fma(v[c].x, hc.x, fma(-v[c].y, hc.y, sr));
-            si = fma(v[c].x, hc.y, fma(v[c].y, hc.x, si));
-        }
-        wv.x -= sr;
-        wv.y -= si;
-        w[i] = wv;
-        nrm = fma(wv.x, wv.x, fma(wv.y, wv.y, nrm));
-    }
-    const double s = block_sum(nrm, red_n);
-    second_pass_tail(s, partial, ldp, nrm_slot, NC, red1, red2, ctrl, fin, red_n);
-}
-#endif   // AKS_UPDATE_EXACT_MAX > 0
+// (An exact-width variant of this kernel -- the panel width a template parameter, all J column loads of a row in flight
+// at once -- was measured 0 - 2 % BEHIND this generic one at every width and is not in this file: the second pass is a
+// read stream with one rewritten column and sits at that pattern's rate with four loads in flight per lane as well as
+// with forty.  profiles/r04_update_nc_ab.txt, profiles/r05_removed_variants.patch.)
 
 // ------------------------------------------------------------------ second-stage reduction
 // out[c] = sum_b partial[b*ldp + first + c], c = blockIdx.x < count; fixed order => reproducible.
 // PRED as in k_update (skips when no second pass ran, leaving `out` untouched).
-// (The panel kernels' in-kernel alternative, -DAKS_TAIL_PANEL=1, was measured slower: see "second stage of the
-// reductions inside the producing kernel" above.)
 template <bool PRED>
 __global__ __launch_bounds__(BLOCK) void k_reduce(const c128 *__restrict__ partial, int n_blocks, int ldp,
                                                  int first, c128 *__restrict__ out, int J,
@@ -1391,7 +1284,7 @@ struct Ws {
     double *colscale;          // per basis column: 0 = normalised, else the column is raw and this is its divisor
     unsigned *ticket(int i) const { return reinterpret_cast<unsigned *>(ctrl->ticket) + i; }
 };
-enum { TICKET_PROJ = 0, TICKET_UPDATE_PROJ = 1, TICKET_UPDATE = 2 };
+enum { TICKET_UPDATE = 2 };      // (words 0 and 1 of aks_ctrl.ticket: unused since the panel kernels lost their tails)
 
 int bind_ws(void *d_ws, int64_t ws_bytes, int64_t n_rows, int32_t max_dim, Ws *out) {
     if (d_ws == nullptr) return fail(AKS_ERR_ARG, "workspace pointer is null");
@@ -1422,26 +1315,14 @@ int check_panel(int64_t n_rows, int32_t J, const void *V, int64_t ldv, const voi
 
 template <int NC>
 void launch_proj_nc(dim3 grid, hipStream_t s, int64_t n, int c0, const c128 *V, int64_t ldv, const c128 *w,
-                    c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0, hipEvent_t ev0,
-                    c128 *red_out, unsigned *ticket, c128 *zero_slot) {
-    launch_timed(k_proj<NC>, grid, dim3(BLOCK), 0, s, ev0, (hipEvent_t) nullptr, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0,
-                 red_out, ticket, zero_slot);
+                    c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0, hipEvent_t ev0) {
+    launch_timed(k_proj<NC>, grid, dim3(BLOCK), 0, s, ev0, (hipEvent_t) nullptr, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0);
 }
 template <int NC>
 void launch_update_proj_nc(dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
-                           const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0,
-                           c128 *red_out, unsigned *ticket) {
-    hipLaunchKernelGGL(k_update_proj<NC>, grid, dim3(BLOCK), 0, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0, red_out, ticket);
+                           const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0) {
+    hipLaunchKernelGGL(k_update_proj<NC>, grid, dim3(BLOCK), 0, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0);
 }
-#if AKS_UPDATE_EXACT_MAX > 0
-template <int NC>
-void launch_update_nc(dim3 grid, hipStream_t s, hipEvent_t ev1, int64_t n, const c128 *V, int64_t ldv, c128 *w, const c128 *h,
-                      c128 *partial, int ldp, const c128 *red1, const c128 *red2, double eta, aks_ctrl *ctrl,
-                      const double *cs, int raw0, FinArgs fin) {
-    launch_timed(k_update_nc<NC>, grid, dim3(BLOCK), 0, s, (hipEvent_t) nullptr, ev1, n, V, ldv, w, h, partial, ldp, 0, red1, red2, eta,
-                 ctrl, cs, raw0, fin);
-}
-#endif
 
 #define AKS_NC_CASES(M) \
     M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) \
@@ -1449,9 +1330,9 @@ void launch_update_nc(dim3 grid, hipStream_t s, hipEvent_t ev1, int64_t n, const
 
 void dispatch_proj(int nc, dim3 grid, hipStream_t s, int64_t n, int c0, const c128 *V, int64_t ldv,
                    const c128 *w, c128 *partial, int ldp, int nrm_slot, const aks_ctrl *ctrl, const double *cs, int raw0,
-                   hipEvent_t ev0, c128 *red_out, unsigned *ticket, c128 *zero_slot) {
+                   hipEvent_t ev0) {
     switch (nc) {
-#define M(N) case N: launch_proj_nc<N>(grid, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0, ev0, red_out, ticket, zero_slot); break;
+#define M(N) case N: launch_proj_nc<N>(grid, s, n, c0, V, ldv, w, partial, ldp, nrm_slot, ctrl, cs, raw0, ev0); break;
         AKS_NC_CASES(M)
 #if AKS_NC_MAX > 32
         M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40)
@@ -1469,30 +1350,15 @@ constexpr int FUSED_EXACT_MAX = AKS_FUSED_EXACT_MAX;
 
 #define AKS_NC_CASES_WIDE(M) M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40)
 void dispatch_update_proj(int nc, dim3 grid, hipStream_t s, int64_t n, const c128 *V, int64_t ldv, c128 *w,
-                          const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0,
-                          c128 *red_out, unsigned *ticket) {
+                          const c128 *h, c128 *partial, int ldp, const aks_ctrl *ctrl, const double *cs, int raw0) {
     switch (nc) {
-#define M(N) case N: launch_update_proj_nc<N>(grid, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0, red_out, ticket); break;
+#define M(N) case N: launch_update_proj_nc<N>(grid, s, n, V, ldv, w, h, partial, ldp, ctrl, cs, raw0); break;
         AKS_NC_CASES(M)
         AKS_NC_CASES_WIDE(M)
 #undef M
         default: break;
     }
 }
-
-#if AKS_UPDATE_EXACT_MAX > 0
-void dispatch_update_nc(int nc, dim3 grid, hipStream_t s, hipEvent_t ev1, int64_t n, const c128 *V, int64_t ldv, c128 *w,
-                        const c128 *h, c128 *partial, int ldp, const c128 *red1, const c128 *red2, double eta,
-                        aks_ctrl *ctrl, const double *cs, int raw0, const FinArgs &fin) {
-    switch (nc) {
-#define M(N) case N: launch_update_nc<N>(grid, s, ev1, n, V, ldv, w, h, partial, ldp, red1, red2, eta, ctrl, cs, raw0, fin); break;
-        AKS_NC_CASES(M)
-        AKS_NC_CASES_WIDE(M)
-#undef M
-        default: break;
-    }
-}
-#endif
 
 template <int NQ>
 void launch_update_proj_split(dim3 grid, hipStream_t s, int64_t n, int J, const c128 *V, int64_t ldv, c128 *w,
@@ -1537,18 +1403,15 @@ void enqueue_projection(hipStream_t s, const Ws &ws, int64_t n, int J, const c12
     const int base = J / groups, extra = J % groups;
     const int n_blocks = panel_blocks(ws, base);          // (every group writes the same rows of `partial`)
     const dim3 grid(n_blocks);
-    // one launch covers the panel (J <= 40): its last workgroup sums the partial rows itself; several groups: k_reduce
-    unsigned *ticket = (AKS_TAIL_PANEL && groups == 1) ? ws.ticket(TICKET_PROJ) : nullptr;
     int c0 = 0;
     for (int g = 0; g < groups; ++g) {
         const int nc = base + (g < extra ? 1 : 0);
         dispatch_proj(nc, grid, s, n, c0, V, ldv, w, ws.partial, ws.lay.ld_partial, g == 0 ? J : -1, ws.ctrl, ws.colscale, raw0,
-                      g == 0 ? ev0 : nullptr, ticket ? red_out : nullptr, ticket, zero_slot);
+                      g == 0 ? ev0 : nullptr);
         c0 += nc;
     }
-    if (ticket == nullptr)
-        hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
-                           ws.lay.ld_partial, 0, red_out, J, nullptr, nullptr, 0.0, zero_slot, ws.ctrl);
+    hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
+                       ws.lay.ld_partial, 0, red_out, J, nullptr, nullptr, 0.0, zero_slot, ws.ctrl);
 }
 
 // Dynamic LDS above the default limit has to be allowed per kernel AND per device: aks_device_init does that for
@@ -2062,16 +1925,14 @@ static int gs_update_project_(int64_t n_rows, int32_t J, const aks_c128 *d_V, in
 #endif
     const bool exact = J <= exact_max && J <= 40 && !(AKS_FUSED_SPLIT_LOW && J >= 5 && J <= 12);
     const int n_blocks = exact ? panel_blocks(ws, J) : ws.lay.n_blocks;
-    unsigned *ticket = (AKS_TAIL_PANEL && exact) ? ws.ticket(TICKET_UPDATE_PROJ) : nullptr;   // (the kernel sums its own partial rows)
     if (exact)
         dispatch_update_proj(J, dim3(n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
-                             ws.lay.ld_partial, ws.ctrl, ws.colscale, raw0, ticket ? ws.red2 : nullptr, ticket);
+                             ws.lay.ld_partial, ws.ctrl, ws.colscale, raw0);
     else
         dispatch_update_proj_split(J, dim3(n_blocks), s, n_rows, V, ldv, w, ws.red1, ws.partial,
                                    ws.lay.ld_partial, ws.ctrl, ws.colscale, raw0);
-    if (ticket == nullptr)
-        hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
-                           ws.lay.ld_partial, 0, ws.red2, J, nullptr, nullptr, 0.0, nullptr, ws.ctrl);
+    hipLaunchKernelGGL(k_reduce<false>, dim3(J + 1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
+                       ws.lay.ld_partial, 0, ws.red2, J, nullptr, nullptr, 0.0, nullptr, ws.ctrl);
     AKS_CHECK_LAUNCH("aks_gs_update_project");
     return AKS_OK;
 }
@@ -2108,14 +1969,8 @@ static int gs_update_norm_(int64_t n_rows, int32_t J, const aks_c128 *d_V, int64
     fin.mode = fin_mode;
     const c128 *V = reinterpret_cast<const c128 *>(d_V);
     c128 *w = reinterpret_cast<c128 *>(d_w);
-#if AKS_UPDATE_EXACT_MAX > 0
-    if (J <= AKS_UPDATE_EXACT_MAX && J <= 40)
-        dispatch_update_nc(J, dim3(n_blocks), s, ev1, n_rows, V, ldv, w, ws.red2, ws.partial, ws.lay.ld_partial, ws.red1, ws.red2,
-                           eta, ws.ctrl, ws.colscale, raw0, fin);
-    else
-#endif
-        launch_timed(k_update<true>, dim3(n_blocks), dim3(BLOCK), 0, s, (hipEvent_t) nullptr, ev1, n_rows, (int)J, V, ldv, w, ws.red2,
-                     ws.partial, ws.lay.ld_partial, 0, ws.red1, ws.red2, eta, ws.ctrl, ws.colscale, raw0, fin);
+    launch_timed(k_update<true>, dim3(n_blocks), dim3(BLOCK), 0, s, (hipEvent_t) nullptr, ev1, n_rows, (int)J, V, ldv, w, ws.red2,
+                 ws.partial, ws.lay.ld_partial, 0, ws.red1, ws.red2, eta, ws.ctrl, ws.colscale, raw0, fin);
     if (fin.ticket == nullptr)
         hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(BLOCK), 0, s, ws.partial, n_blocks,
                            ws.lay.ld_partial, 0, ws.red3, J, ws.red1, ws.red2, eta, nullptr, ws.ctrl);

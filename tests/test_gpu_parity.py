@@ -543,6 +543,70 @@ def test_dgks_gs_widths(amd, J, n):
         assert np.abs(V.conj().T @ w).max() < 1e-12 * max(1.0, np.linalg.norm(w0))
 
 
+def test_ticket_hand_off_books_the_step(amd):
+    """The last-arriver hand-off of the second-pass kernel (k_update<true> under FIN_ALWAYS: last_block_arrives /
+    second_pass_tail in csrc/aks_kernels.hip), pinned in one run: ``aks_dgks_gs`` with ``normalize = 0`` on
+    vectors that NEED the second pass, at a size where the kernel runs two workgroups per CU (512 partials), so that
+    the step's beta and H column are booked by the workgroup that drew the last ticket.  A stale partial in its sum
+    is an error of ~1/512 in beta^2 (round 4's bug: 2.2e-3 instead of 8.7e-9 in a residual); here beta must equal the
+    norm of the vector the kernel left behind to rounding.  Forty calls on ONE workspace, each with another scale, so
+    that a partial left over from the call before is wrong by orders of magnitude."""
+    import torch
+    from arnoldi_amd import device as dev, mem
+
+    n, J = 1 << 20, 12
+    rng = np.random.default_rng(5)
+    Vh, _ = np.linalg.qr(rng.standard_normal((n, J)) + 1j * rng.standard_normal((n, J)))
+    Vh = np.asfortranarray(Vh.astype(C128))
+    basis = dev.KrylovBasis(n, J)
+    ws = dev.Workspace(n, J)
+    basis.set_cols(0, Vh)
+    Vd = basis.V[:J, :n]
+    hdev = mem.zeros(J + 1, mem.c128, basis.device)
+    noise = torch.from_numpy(rng.standard_normal(n) + 1j * rng.standard_normal(n)).cuda()
+    noise /= torch.linalg.norm(noise)
+    coef = torch.from_numpy(rng.standard_normal(J) + 1j * rng.standard_normal(J)).cuda()
+    inside = coef @ Vd                                           # a vector of span(V), norm ~ sqrt(J)
+    for rep in range(40):
+        scale = 10.0 ** (-(rep % 8) - 1)                         # 1e-1 .. 1e-8 of noise: every call takes the second pass
+        w0 = inside + scale * noise
+        basis.col(J)[:n].copy_(w0)
+        before = int(ws.read_ctrl().second_passes)
+        dev.dgks_gs_device(basis, J, basis.col(J), hdev.data_ptr(), 1, 1e-300, ws, normalize=False)
+        ctrl = ws.read_ctrl()
+        assert int(ctrl.second_passes) == before + 1, rep
+        w = basis.col(J)[:n]
+        beta_true = float(torch.linalg.norm(w))
+        assert abs(float(ctrl.beta) - beta_true) <= 1e-12 * beta_true, (rep, float(ctrl.beta), beta_true)
+        h_true = Vd.conj() @ w0                                  # both passes together: h = V^H w0 to rounding
+        err = float((hdev[:J] - h_true).abs().max())
+        assert err <= 1e-12 * float(torch.linalg.norm(w0)), (rep, err)
+        assert float((Vd.conj() @ w).abs().max()) <= 1e-11 * float(torch.linalg.norm(w0)), rep
+
+
+def test_ticket_hand_off_with_deferred_normalisation(amd):
+    """The same hand-off with ``normalize = 2`` (columns stay raw; only ``aks_arnoldi_expand`` may ask for it): a 2-D
+    Laplacian takes the second pass in EVERY step, so all m book-keepings of an expansion go through the last-arriver
+    ticket; H against the CPU oracle on the same start vector."""
+    from arnoldi_amd import matrices
+    from arnoldi_amd.engine import ArnoldiContext, as_operator
+
+    A = matrices.laplace2d(1000, 1001)
+    n, m = A.shape[0], 12                       # (expansions of up to AKS_DEFER_MAX_STEPS = 12 steps defer)
+    np.random.seed(3)
+    v0 = oracle.random_unit_vector(n, C128)
+    ctx = ArnoldiContext(as_operator(A), m)
+    ctx.set_start_vector(v0)
+    H = np.zeros((m + 1, m), C128)
+    assert ctx.expand(H, 0, m, 1e-8, defer_scale=True) == m
+    assert ctx.deferred_expansions == 1 and int(ctx.last_ctrl.second_passes) >= m // 2, int(ctx.last_ctrl.second_passes)
+    Vo = np.zeros((n, m + 1), C128, order="F")
+    Ho = np.zeros((m + 1, m), C128)
+    Vo[:, 0] = v0
+    oracle.arnoldi_expand(A, Vo, Ho, 1e-8)
+    np.testing.assert_allclose(H, Ho, rtol=1e-9, atol=1e-12)
+
+
 # ---------------------------------------------------------------------------- Arnoldi seam
 def test_arnoldi_decomposition_golden(amd):
     from arnoldi_amd.decomposition import arnoldi_decomposition

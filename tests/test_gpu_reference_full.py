@@ -1,0 +1,143 @@
+"""BASELINE.json configurations 2-5 at FULL size against numbers produced by RUNNING THE REFERENCE on the same inputs
+(``pytest -m gpu``; fixtures ``tests/golden/g11_*_full.npz`` from ``tests/golden/make_golden_large.py``, which imports
+/root/reference/src in the build container).
+
+The Schur vectors of these runs are GBs, so a fixture holds the reference's scalars: restart count, ``History``, T,
+per-pair residuals and the sha256 of the start vector.  Each test solves the same matrix from the same seed on the HIP path
+and asserts
+
+  * ``rand_normalized_vector(n)`` has the reference's bytes (this is what pins the native ``aks_legacy_randn`` + reciprocal
+    normalisation of n >= 1M ON THE GPU BOX: another NumPy build, another libm than the container's);
+  * the same restart count and the same ``History`` (matvecs and restarts per eigenvalue);
+  * diag(T) to 1e-9;
+  * max ||A v - l v|| / |l|  <=  1.05 x the reference's own (north_star's bar; 1e-13 floor).
+
+c2 / c4 use the loose ``stopping_criterion`` the fixture records (the reference needs hours to days at the default one;
+the iteration is the same until it stops); ``c2full`` is config 2 at the default tolerance, all the way.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+C128 = np.complex128
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PLANTED_C3 = tuple(60.0 - 1.5 * i for i in range(24))
+PLANTED_C5 = (4.0, 3.7, 3.4, 3.1, 2.8, 2.5)
+
+
+def _matrix(name):
+    from arnoldi_amd import matrices
+
+    return {
+        "c5": lambda: matrices.random_csr(10_000_000, 5, 1234, planted=PLANTED_C5),
+        "c3b": lambda: matrices.banded_csr(1_508_065, 35, 1234, planted=PLANTED_C3),
+        "c3s": lambda: matrices.shell_csr(549, 549, 5, 1234, planted=PLANTED_C3),
+        "c2": lambda: matrices.laplace2d(1000, 1001),
+        "c2full": lambda: matrices.laplace2d(1000, 1001),
+        "c4": lambda: matrices.laplace3d(251, 252, 253),
+    }[name]()
+
+
+def _fixture(name):
+    path = os.path.join(GOLDEN, f"g11_{name}_full.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} has not been generated (tests/golden/make_golden_large.py {name})")
+    return np.load(path)
+
+
+def _sha(v):
+    return hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c5", "c3b", "c3s", "c2", "c4", "c2full"])
+def test_full_size_solve_matches_the_reference_run(name):
+    import torch
+
+    assert torch.cuda.is_available()
+    import arnoldi_amd
+    from arnoldi_amd.utils import rand_normalized_vector
+
+    g = _fixture(name)
+    A = _matrix(name)
+    n, nev, seed = int(g["n"]), int(g["nev"]), int(g["seed"])
+    assert A.shape == (n, n) and A.nnz == int(g["nnz"])
+
+    np.random.seed(seed)
+    v0 = rand_normalized_vector(n, C128)
+    assert _sha(v0) == str(g["v0_sha256"]), "start vector differs from the reference's"
+    del v0
+
+    tol_default = float(np.sqrt(np.finfo(np.float64).eps))
+    kw = {} if float(g["tol"]) == tol_default else {"stopping_criterion": float(g["tol"])}
+    np.random.seed(seed)
+    st = {}
+    Q, T, hist = arnoldi_amd.partial_schur(A, nev, max_dim=int(g["max_dim"]), max_restarts=int(g["restarts"]) + 50,
+                                           stats=st, **kw)
+    assert st["restarts"] == int(g["restarts"]), (st["restarts"], int(g["restarts"]))
+    np.testing.assert_array_equal(hist.restarts, g["hist_restarts"])
+    np.testing.assert_array_equal(hist.matvecs, g["hist_matvecs"])
+    np.testing.assert_allclose(np.diag(T), g["diagT"], rtol=1e-9, atol=1e-12)
+
+    dvals, _, drel = st["solver"].true_residuals()            # on the device: no n-vector leaves the GPU
+    bound = max(1.05 * float(g["rel_residuals"].max()), 1e-13)
+    assert drel.max() <= bound, (drel.max(), float(g["rel_residuals"].max()))
+    if n <= 2_000_000 or name == "c5":                         # and once more on the host from the returned Q, as the
+        vals, S = np.linalg.eig(T)                             # reference's README does (README.md:47-48)
+        vecs = Q @ S
+        rel = np.linalg.norm(A @ vecs - vecs * vals, axis=0) / np.abs(vals)
+        assert rel.max() <= bound, (rel.max(), float(g["rel_residuals"].max()))
+    np.testing.assert_allclose(Q.conj().T @ Q, np.eye(nev), atol=1e-11)
+    print(f"{name}: {st['restarts']} restarts (reference {int(g['restarts'])}), max rel residual {drel.max():.3e} "
+          f"(reference {float(g['rel_residuals'].max()):.3e}, {float(g['ref_wall_s']):.0f} s on {int(g['ref_cores'])} cores), "
+          f"form {st['spmv_form']}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1_200_001, 999_999, 1_000_000])
+def test_start_vector_bytes_equal_numpy_on_this_box(n):
+    """``rand_normalized_vector`` around the size where the native draw takes over (n >= 1M), against the oracle's two
+    NumPy statements (oracle.random_unit_vector = utils.py:10-11 of the reference) on THIS machine's NumPy, and the
+    generator state afterwards."""
+    from arnoldi_amd.utils import rand_normalized_vector
+
+    for seed in (0, 7):
+        np.random.seed(seed)
+        want = oracle.random_unit_vector(n, C128)
+        after_want = np.random.randn(3)
+        np.random.seed(seed)
+        got = rand_normalized_vector(n, C128)
+        after_got = np.random.randn(3)
+        assert _sha(got) == _sha(want)
+        np.testing.assert_array_equal(after_got, after_want)
+
+
+@pytest.mark.parametrize("name", ["c5", "c3b", "c3s", "c2", "c4", "c2full"])
+def test_large_fixture_is_self_consistent(name):
+    """(CPU) what a fixture must hold for the GPU test to mean something: the reference converged, its History carries the
+    last restart for every eigenvalue (krylov_schur.py:94-97), T is upper triangular with the eigenvalues on its diagonal."""
+    g = _fixture(name)
+    k, m, r = int(g["nev"]), int(g["max_dim"]), int(g["restarts"])
+    assert np.all(g["hist_restarts"] == r)
+    assert np.all(g["hist_matvecs"] == (r - 1) * (m - k) + (m - k))          # krylov_schur.py:63 at restart r - 1
+    assert np.all(g["rel_residuals"] < 5 * float(g["tol"]))                   # scripts/benchmark-partial-schur.py:97-100
+    T = g["T"]
+    assert np.abs(np.tril(T, -1)).max() == 0.0
+    np.testing.assert_allclose(np.sort_complex(g["eigvals"]), np.sort_complex(np.diag(T)), rtol=1e-10)
+    assert float(g["ortho"]) < 1e-11 and len(str(g["v0_sha256"])) == 64
+
+
+def test_start_vector_of_the_c5_fixture_on_the_cpu():
+    """(CPU) the start vector of the 10M-row fixture: the host-side draw needs no GPU, so the build container checks the
+    same hash the GPU box does."""
+    from arnoldi_amd.utils import rand_normalized_vector
+
+    g = _fixture("c5")
+    np.random.seed(int(g["seed"]))
+    v0 = rand_normalized_vector(int(g["n"]), C128)
+    assert _sha(v0) == str(g["v0_sha256"])
+    np.testing.assert_array_equal(v0[:4], g["v0_head"])

@@ -1033,8 +1033,12 @@ def test_locking_gives_the_oracles_eigenpairs(fake, case):
 def test_scalar_load_hazard_lint():
     """csrc/check_scalar_hazards.py (``make -C arnoldi-py_amd hazards``): (1) it flags the ISA round 3's
     ``k_colscale_after_truncate`` compiled to -- a scalar load of ``cs[m]`` waited for only behind the vector stores that
-    clear ``cs[m]``: the lost carried scale of deferred normalisation, found at full size in round 4; (2) the kernels
-    of the current tree compile to ISA without any such candidate."""
+    clear ``cs[m]``: the lost carried scale of deferred normalisation, found at full size in round 4; (2) synthetic
+    listings for each rule: fields of one struct pass, overlapping bytes / a rewritten base / a lane offset / an address
+    that cannot be followed do not; a scalar load that FOLLOWS a store of the same argument is found through a loop's back
+    edge and through s_mul- and s_lshl-formed offsets; (3) the kernels of the current tree compile
+    to ISA without any candidate, with EVERY scalar data load and vector store followed to a kernel argument."""
+    import re
     import subprocess
     import sys
 
@@ -1043,19 +1047,16 @@ def test_scalar_load_hazard_lint():
     tool = os.path.join(ROOT, "arnoldi-py_amd", "csrc", "check_scalar_hazards.py")
     bad = subprocess.run([sys.executable, tool, os.path.join(ROOT, "tests", "golden", "k_colscale_r03.s")], capture_output=True, text=True)
     assert bad.returncode == 1 and "k_colscale_after_truncate" in bad.stdout and "can overtake it" in bad.stdout, bad.stdout + bad.stderr
-    # the rootless half: a store with a scalar load outstanding must be explained.  Fields of one struct through the same,
-    # unmodified base pair with disjoint bytes pass; overlapping bytes, a rewritten base or an address that cannot be
-    # related to the load do not.  (Synthetic listings: the load's base comes from memory, so no argument is known.)
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("check_scalar_hazards", tool)
     lint = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lint)
-    head = ["s_load_dwordx2 s[4:5], s[0:1], 0x0", "s_waitcnt lgkmcnt(0)", "s_load_dwordx2 s[16:17], s[4:5], 0x40", "s_waitcnt lgkmcnt(0)",
-            "s_load_dwordx2 s[12:13], s[16:17], 0x8", "v_mov_b32_e32 v6, 0"]
+    # argument 0 is a pointer P (s[16:17]); the scalar data load reads bytes 8..15 of *P
+    head = ["s_load_dwordx2 s[16:17], s[0:1], 0x0", "s_waitcnt lgkmcnt(0)", "s_load_dwordx2 s[12:13], s[16:17], 0x8", "v_mov_b32_e32 v6, 0"]
 
-    def verdict(*tail):
-        body = list(enumerate(head + list(tail) + ["s_waitcnt lgkmcnt(0)", "s_endpgm"], 1))
+    def verdict(*tail, head=head):
+        body = list(enumerate(list(head) + list(tail) + ["s_waitcnt lgkmcnt(0)", "s_endpgm"], 1))
         return [f[2] for f in lint.check_kernel("k", body)]
 
     assert verdict("global_store_dwordx4 v6, v[2:5], s[16:17] offset:16", "global_store_dword v6, v7, s[16:17] offset:36") == []
@@ -1063,12 +1064,41 @@ def test_scalar_load_hazard_lint():
     assert len(verdict("global_store_dword v6, v7, s[16:17] offset:8")) == 1
     assert len(verdict("s_add_u32 s16, s16, 8", "global_store_dword v6, v7, s[16:17] offset:36")) == 1   # base rewritten
     assert len(verdict("v_mov_b32_e32 v6, v9", "global_store_dword v6, v7, s[16:17] offset:36")) == 1    # lane offset not 0
-    assert len(verdict("global_store_dword v[8:9], v7, off")) == 1                                 # unrelated address
+    unfollowed = verdict("global_store_dword v[8:9], v7, off")                                     # an address from nowhere:
+    assert any("cannot be told apart" in f for f in unfollowed) and any("could be followed" in f for f in unfollowed)
     assert verdict("s_waitcnt lgkmcnt(0)", "global_store_dword v6, v7, s[16:17] offset:8") == []   # waited for first
+    # a store through another argument is unrelated, whatever the order
+    assert verdict("s_load_dwordx2 s[18:19], s[0:1], 0x8", "s_waitcnt lgkmcnt(0)", "global_store_dword v6, v7, s[18:19] offset:8",
+                   "s_load_dword s30, s[16:17], 0x8") == []
+    # rule (A) through a loop: iteration i stores to P + 24 i + 8, iteration i + 1 scalar-loads P + 24 (i + 1) -- the offset
+    # is s_mul-formed and the base is redefined inside the loop, so nothing proves the bytes disjoint
+    loop = ["s_load_dwordx2 s[16:17], s[0:1], 0x0", "s_load_dword s20, s[0:1], 0x8", "s_waitcnt lgkmcnt(0)", "s_mov_b32 s21, 0",
+            ".LBB0_1:", "s_mul_i32 s22, s21, 24", "s_mul_hi_u32 s23, s21, 24", "s_add_u32 s24, s16, s22", "s_addc_u32 s25, s17, s23",
+            "s_load_dwordx2 s[12:13], s[24:25], 0x0", "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v2, s12", "v_mov_b32_e32 v3, s13",
+            "v_mov_b32_e32 v6, 0", "global_store_dwordx2 v6, v[2:3], s[24:25] offset:8", "s_add_i32 s21, s21, 1",
+            "s_cmp_lt_i32 s21, s20", "s_cbranch_scc1 .LBB0_1"]
+    found = verdict(head=loop)
+    assert len(found) == 1 and "can execute AFTER the vector store" in found[0], found
+    straight = [x for x in loop if not x.startswith((".LBB", "s_cbranch"))]                         # once, no back edge: the load is
+    assert verdict(head=straight) == []                                                            # complete before the store, never after
+    # rule (A) behind an s_lshl-formed offset: store to P + 8 n, then a scalar load of P[0]
+    after = ["s_load_dwordx2 s[16:17], s[0:1], 0x0", "s_load_dwordx2 s[20:21], s[0:1], 0x8", "s_waitcnt lgkmcnt(0)",
+             "s_lshl_b64 s[22:23], s[20:21], 3", "s_add_u32 s24, s16, s22", "s_addc_u32 s25, s17, s23", "v_mov_b32_e32 v6, 0",
+             "global_store_dwordx2 v6, v[2:3], s[24:25]", "s_load_dwordx2 s[12:13], s[16:17], 0x0"]
+    found = verdict(head=after)
+    assert len(found) == 1 and "can execute AFTER the vector store" in found[0], found
+    # SGPRs spilled to VGPR lanes keep their argument (v_writelane / v_readlane)
+    spill = ["s_load_dwordx2 s[16:17], s[0:1], 0x0", "s_waitcnt lgkmcnt(0)", "v_writelane_b32 v40, s16, 0", "v_writelane_b32 v40, s17, 1",
+             "s_mov_b64 s[16:17], 0", "v_readlane_b32 s30, v40, 0", "v_readlane_b32 s31, v40, 1", "v_mov_b32_e32 v6, 0",
+             "global_store_dword v6, v7, s[30:31]", "s_load_dword s33, s[30:31], 0x0"]
+    found = verdict(head=spill)
+    assert len(found) == 1 and "argument +0x0" in found[0], found
     if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
         pytest.skip("no hipcc here: the current tree cannot be compiled to ISA")
     now = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
     assert now.returncode == 0 and " 0 candidate hazard(s)" in now.stdout, now.stdout[-3000:] + now.stderr[-2000:]
+    m = re.search(r"(\d+) of (\d+) scalar data loads, (\d+) of (\d+) vector stores", now.stdout)
+    assert m and m.group(1) == m.group(2) and m.group(3) == m.group(4) and int(m.group(2)) > 100 and int(m.group(4)) > 1000, now.stdout[-600:]
 
 
 def test_complex_schur_takes_the_real_route_only_when_it_is_a_complex_schur_form(monkeypatch):
