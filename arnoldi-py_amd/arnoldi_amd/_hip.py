@@ -154,6 +154,7 @@ SIGNATURES = {
     "aks_comm_create": (C.c_int, [_P, _I32, _I32, C.POINTER(_P)]),
     "aks_comm_destroy": (C.c_int, [_P]),
     "aks_comm_allreduce_sum": (C.c_int, [_P, _P, _I64, _P]),
+    "aks_comm_alltoallv": (C.c_int, [_P, _P, C.POINTER(_I64), C.POINTER(_I64), _P, C.POINTER(_I64), C.POINTER(_I64), _P]),
     "aks_workspace_set_real": (C.c_int, [_P, _I32, _P]),
     "aks_csr_spmv_real": (C.c_int, [_I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _P]),
     "aks_pb_spmv_real": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),

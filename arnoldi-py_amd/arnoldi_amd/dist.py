@@ -9,18 +9,30 @@ The reference has no distributed code; this is the layout SURVEY 8(e) fixes:
     of the x entries other shards need before each SpMV (all-to-all of packed
     "ghost" entries; the local (diagonal-block) SpMV runs while it is in flight).
 
-Everything in this file is host logic (numpy planning + set-up exchanges over torch.distributed);
+Everything in this file is host logic (numpy planning + set-up exchanges);
 it never touches matrix values on the CPU after the plan is built.  On the data path of an RCCL
 group the collectives are issued by libarnoldi_hip.so itself (``Comm.native()`` hands it a
-communicator, ``aks_shard_apply`` / ``aks_arnoldi_expand`` do the rest); the torch.distributed
-data-path calls below serve gloo groups (CPU tests, several test ranks on one GPU) and
-AKS_DIST_PATH=python.
+communicator, ``aks_shard_apply`` / ``aks_arnoldi_expand`` do the rest).
+
+Two interchangeable rank-to-rank layers carry the SET-UP (communicator id, partition sizes, ghost requests, the
+final row gather):
+
+``Comm``       over a torch.distributed process group (nccl = RCCL, or gloo for CPU tests / ranks sharing a GPU); its
+               torch.distributed data-path calls serve gloo groups and AKS_DIST_PATH=python.
+``HostComm``   torch-free (round 5): a TCP rendezvous among the ranks (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE, or
+               ``AKS_RENDEZVOUS=host:port``) carries the 128-byte communicator id and the few-byte control messages;
+               the bulk exchanges -- ghost requests, Schur-vector row blocks -- go through the library's own
+               communicator (``aks_comm_alltoallv``: grouped ncclSend / ncclRecv).  With ``AKS_HOST_ALLOC=hip`` a
+               multi-rank solve then needs numpy + scipy + the ROCm runtime, like the reference (pyproject.toml:9-13).
 """
 from __future__ import annotations
 
 import atexit
-
 import importlib
+import os
+import socket
+import struct
+import time
 
 import numpy as np
 import scipy.sparse as sp
@@ -369,3 +381,320 @@ class Comm:
     def barrier(self):
         if self.size > 1:
             dist.barrier(group=self.group)
+
+
+# --------------------------------------------------------------------------- torch-free communicator
+class _Hub:
+    """Star of TCP connections: rank 0 listens, every other rank connects; ``gather`` / ``alltoall`` of byte strings in
+    lock step (every rank makes the same sequence of calls -- they are collectives).  Control plane only: the messages
+    are bytes to a few MB; a lost peer is a time-out (``AKS_COMM_TIMEOUT_S``, default 300), never a silent hang."""
+
+    def __init__(self, rank, size, host, port, timeout):
+        self.rank, self.size, self.timeout = rank, size, timeout
+        self.peers = {}                      # rank 0: peer rank -> socket; others: {0: socket}
+        if size == 1:
+            return
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((host if host not in ("", "localhost") else "127.0.0.1", port))
+            srv.listen(size)
+            srv.settimeout(timeout)
+            try:
+                while len(self.peers) < size - 1:
+                    conn, _ = srv.accept()
+                    conn.settimeout(timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    (peer,) = struct.unpack("<q", self._recv_exact(conn, 8))
+                    if not 0 < peer < size or peer in self.peers:
+                        raise RuntimeError(f"rendezvous: unexpected peer rank {peer}")
+                    self.peers[peer] = conn
+            except socket.timeout:
+                raise RuntimeError(f"rendezvous at {host}:{port}: only {len(self.peers) + 1} of {size} ranks arrived "
+                                   f"within {timeout:.0f} s") from None
+            finally:
+                srv.close()
+        else:
+            deadline = time.monotonic() + timeout
+            while True:
+                try:
+                    conn = socket.create_connection((host, port), timeout=min(5.0, timeout))
+                    break
+                except OSError:
+                    if time.monotonic() > deadline:
+                        raise RuntimeError(f"rendezvous: rank 0 not reachable at {host}:{port} within {timeout:.0f} s") from None
+                    time.sleep(0.05)
+            conn.settimeout(timeout)
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            conn.sendall(struct.pack("<q", rank))
+            self.peers[0] = conn
+
+    @staticmethod
+    def _recv_exact(conn, n):
+        buf = bytearray(n)
+        view, got = memoryview(buf), 0
+        while got < n:
+            k = conn.recv_into(view[got:], n - got)
+            if k == 0:
+                raise RuntimeError("rendezvous: a peer closed its connection")
+            got += k
+        return bytes(buf)
+
+    def _send_blobs(self, conn, blobs):
+        conn.sendall(struct.pack(f"<q{len(blobs)}q", len(blobs), *(len(b) for b in blobs)))
+        for b in blobs:
+            if len(b):
+                conn.sendall(b)
+
+    def _recv_blobs(self, conn):
+        (k,) = struct.unpack("<q", self._recv_exact(conn, 8))
+        sizes = struct.unpack(f"<{k}q", self._recv_exact(conn, 8 * k)) if k else ()
+        return [self._recv_exact(conn, n) if n else b"" for n in sizes]
+
+    def alltoall(self, blobs):
+        """``blobs[r]`` goes to rank r; returns the list of what every rank sent here, in rank order."""
+        assert len(blobs) == self.size
+        if self.size == 1:
+            return [bytes(blobs[0])]
+        if self.rank != 0:
+            self._send_blobs(self.peers[0], blobs)
+            return self._recv_blobs(self.peers[0])
+        table = [None] * self.size
+        table[0] = [bytes(b) for b in blobs]
+        for peer in range(1, self.size):
+            table[peer] = self._recv_blobs(self.peers[peer])
+            if len(table[peer]) != self.size:
+                raise RuntimeError("rendezvous: ranks made different calls")
+        for peer in range(1, self.size):
+            self._send_blobs(self.peers[peer], [table[src][peer] for src in range(self.size)])
+        return [table[src][0] for src in range(self.size)]
+
+    def gather(self, blob):
+        """Every rank's ``blob`` on every rank, in rank order."""
+        return self.alltoall([blob] * self.size)
+
+    def close(self):
+        for conn in self.peers.values():
+            try:
+                conn.close()
+            except OSError:
+                pass
+        self.peers = {}
+
+
+def rendezvous_address():
+    """(host, port) of the torch-free rendezvous: ``AKS_RENDEZVOUS=host:port``, else MASTER_ADDR and MASTER_PORT + 1
+    (the launcher's own store listens on MASTER_PORT itself when the ranks were started by torch.distributed.run)."""
+    spec = os.environ.get("AKS_RENDEZVOUS")
+    if spec:
+        host, _, port = spec.rpartition(":")
+        return host or "127.0.0.1", int(port)
+    return os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29400")) + 1
+
+
+class HostComm:
+    """The ``Comm`` interface without torch: set-up exchanges over a TCP rendezvous (control) and over the library's own
+    communicator (bulk); see the module docstring.  Device staging buffers come from ``mem`` (either backend)."""
+
+    backend = "aks"
+
+    def __init__(self, rank=None, size=None, address=None, force=False):
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.size = int(os.environ.get("WORLD_SIZE", "1")) if size is None else int(size)
+        if not 0 <= self.rank < self.size:
+            raise ValueError(f"HostComm: rank {self.rank} of {self.size}")
+        host, port = address if address is not None else rendezvous_address()
+        self.force, self.group, self._native = bool(force), None, None
+        self._hub = _Hub(self.rank, self.size, host, port, float(os.environ.get("AKS_COMM_TIMEOUT_S", "300")))
+        _live_comms.add(self)
+
+    @property
+    def active(self):
+        return self.size > 1 or self.force
+
+    # -- control plane -----------------------------------------------------------------------------------
+    def allgather_int64(self, values):
+        blob = np.ascontiguousarray(values, dtype=np.int64).tobytes()
+        return [np.frombuffer(b, dtype=np.int64).copy() for b in self._hub.gather(blob)]
+
+    def max_float(self, x):
+        return float(max(struct.unpack("<d", b)[0] for b in self._hub.gather(struct.pack("<d", float(x)))))
+
+    def barrier(self):
+        self._hub.gather(b"")
+
+    def _agree(self, ok, what, err=None):
+        from . import _hip
+
+        votes = [v == b"y" for v in self._hub.gather(b"y" if ok else b"n")]
+        if not all(votes):
+            where = f"this rank ({err})" if err is not None else f"rank {votes.index(False)}"
+            raise _hip.HipLibraryError(f"RCCL communicator of the row-sharded solve: {what} failed on {where}")
+
+    # -- the library's communicator ------------------------------------------------------------------------
+    def native(self):
+        """``aks_comm`` handle, created on first use: rank 0 draws the id, the rendezvous hands it round, every rank
+        calls ``aks_comm_create`` and proves the communicator with one all-reduce; each step is voted on before the next
+        collective is entered (as ``Comm.native``).  None with AKS_DIST_PATH=python."""
+        if os.environ.get("AKS_DIST_PATH", "native") == "python":
+            return None
+        if self._native is not None:
+            return self._native
+        import ctypes as C
+
+        from . import _hip, mem
+
+        lib = _hip.load()
+        ident, err = b"", None
+        if self.rank == 0:
+            buf = (C.c_char * _hip.COMM_ID_BYTES)()
+            try:
+                _hip.check(lib.aks_comm_unique_id(C.cast(buf, C.c_void_p)), "aks_comm_unique_id")
+                ident = bytes(buf)
+            except _hip.HipLibraryError as e:
+                err = e
+        ident = self._hub.gather(ident)[0]
+        self._agree(len(ident) == _hip.COMM_ID_BYTES, "aks_comm_unique_id", err)
+        handle, err = C.c_void_p(), None
+        buf = (C.c_char * _hip.COMM_ID_BYTES).from_buffer_copy(ident)
+        try:
+            _hip.check(lib.aks_comm_create(C.cast(buf, C.c_void_p), self.rank, self.size, C.byref(handle)), "aks_comm_create")
+        except _hip.HipLibraryError as e:
+            err = e
+        try:
+            self._agree(err is None, "aks_comm_create", err)
+            try:
+                probe = mem.upload(np.full(2, float(self.rank + 1)), mem.as_device(None))
+                _hip.check(lib.aks_comm_allreduce_sum(handle, C.c_void_p(probe.data_ptr()), 2, C.c_void_p(mem.stream_ptr())),
+                           "aks_comm_allreduce_sum")
+                got = np.asarray(probe.cpu().numpy())
+                if abs(float(got[0]) - self.size * (self.size + 1) / 2) > 1e-9:
+                    raise _hip.HipLibraryError(f"all-reduce self-test gave {got.tolist()}")
+            except _hip.HipLibraryError as e:
+                err = e
+            self._agree(err is None, "the all-reduce self-test", err)
+        except _hip.HipLibraryError:
+            if handle:
+                lib.aks_comm_destroy(handle)
+            raise
+        self._native = handle
+        return handle
+
+    def _device_alltoallv(self, send, send_off, send_n, recv_n):
+        """Bytes of the host array ``send`` (uint8) through ``aks_comm_alltoallv``: rank r gets ``send[send_off[r] :
+        send_off[r] + send_n[r]]``; returns the received bytes, peer after peer."""
+        import ctypes as C
+
+        from . import _hip, mem
+
+        device = mem.as_device(None)
+        recv_off = np.concatenate([[0], np.cumsum(recv_n)]).astype(np.int64)
+        d_send = mem.upload(np.ascontiguousarray(send) if send.size else np.zeros(8, np.uint8), device)
+        d_recv = mem.empty(max(int(recv_off[-1]), 8), mem.u8, device)
+        arr = lambda a: np.ascontiguousarray(a, dtype=np.int64)            # noqa: E731
+        so, sn, ro, rn = arr(send_off), arr(send_n), arr(recv_off[:-1]), arr(recv_n)
+        p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))             # noqa: E731
+        _hip.check(_hip.load().aks_comm_alltoallv(self._native, C.c_void_p(d_send.data_ptr()), p64(so), p64(sn),
+                                                  C.c_void_p(d_recv.data_ptr()), p64(ro), p64(rn), C.c_void_p(mem.stream_ptr())),
+                   "aks_comm_alltoallv")
+        out = np.asarray(d_recv.cpu().numpy()).reshape(-1)[: int(recv_off[-1])]
+        return out, recv_off
+
+    def exchange_requests(self, ghost_cols, recv_counts):
+        """As ``Comm.exchange_requests``: per peer, the global ids that peer needs from this rank.  Counts travel over the
+        rendezvous; the ids (millions at BASELINE config 5) through the library's communicator, every message led by
+        its own length so that no pair of ranks is ever without one (an empty group would leave a rank out of the
+        collective)."""
+        ghost_cols = np.ascontiguousarray(ghost_cols, dtype=np.int64)
+        recv_counts = np.asarray(recv_counts, dtype=np.int64)
+        asked = [int(np.frombuffer(b, np.int64)[0])
+                 for b in self._hub.alltoall([struct.pack("<q", int(c)) for c in recv_counts])]
+        lo = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
+        if self.size == 1:
+            return [ghost_cols[: int(recv_counts[0])].copy()]
+        if self.native() is None:
+            blobs = self._hub.alltoall([ghost_cols[lo[r]: lo[r + 1]].tobytes() for r in range(self.size)])
+            return [np.frombuffer(b, np.int64).copy() for b in blobs]
+        parts = []
+        for r in range(self.size):                                         # [count, ids...] per peer
+            parts.append(np.array([recv_counts[r]], np.int64))
+            parts.append(ghost_cols[lo[r]: lo[r + 1]])
+        send = np.concatenate(parts).view(np.uint8)
+        send_n = 8 * (recv_counts + 1)
+        send_off = np.concatenate([[0], np.cumsum(send_n)])[:-1]
+        got, off = self._device_alltoallv(send, send_off, send_n, 8 * (np.asarray(asked, np.int64) + 1))
+        words = got.view(np.int64)
+        out = []
+        for r in range(self.size):
+            block = words[off[r] // 8: off[r + 1] // 8]
+            if int(block[0]) != asked[r]:
+                raise RuntimeError(f"exchange_requests: rank {r} announced {asked[r]} ids and sent {int(block[0])}")
+            out.append(block[1:].copy())
+        return out
+
+    def allgather_rows(self, local):
+        """Row blocks of a (n_local, k) host array from every rank, stacked in rank order, on every rank."""
+        local = np.ascontiguousarray(local)
+        if self.size == 1:
+            return local
+        k, item = int(local.shape[1]), local.dtype.itemsize
+        rows = [int(v[0]) for v in self.allgather_int64([local.shape[0]])]
+        if self.native() is None:
+            blobs = self._hub.gather(local.tobytes())
+            return np.concatenate([np.frombuffer(b, local.dtype).reshape(-1, k) for b in blobs], axis=0)
+        mine = local.shape[0] * k * item
+        got, _ = self._device_alltoallv(local.reshape(-1).view(np.uint8), np.zeros(self.size, np.int64),
+                                        np.full(self.size, mine, np.int64), np.asarray(rows, np.int64) * k * item)
+        return got.view(local.dtype).reshape(-1, k)
+
+    # -- data-path collectives of the Python-chained path (AKS_DIST_PATH=python: functional, staged through the host) ----
+    def allreduce_sum_(self, t):
+        if not self.active:
+            return
+        from . import mem
+
+        h = t.cpu()
+        a = np.ascontiguousarray(h.numpy() if hasattr(h, "numpy") else h)
+        parts = [np.frombuffer(b, a.dtype) for b in self._hub.gather(a.tobytes())]
+        total = parts[0].copy()
+        for p_ in parts[1:]:                                               # rank order: the same bits on every rank
+            total += p_
+        t.copy_(mem.host(total.reshape(a.shape)))
+
+    def alltoallv_start(self, send, send_counts, recv, recv_counts, words=2):
+        from . import mem
+
+        h = send.cpu()
+        a = np.ascontiguousarray(h.numpy() if hasattr(h, "numpy") else h).reshape(-1).view(np.float64)
+        lo = np.concatenate([[0], np.cumsum([words * int(c) for c in send_counts])]).astype(np.int64)
+        blobs = self._hub.alltoall([a[lo[r]: lo[r + 1]].tobytes() for r in range(self.size)])
+        got = np.concatenate([np.frombuffer(b, np.float64) for b in blobs]) if blobs else np.zeros(0)
+        if got.size != words * int(sum(int(c) for c in recv_counts)):
+            raise RuntimeError("alltoallv: received another size than announced")
+        if got.size:
+            recv[: got.size].copy_(mem.host(got))          # (``recv`` is the float64 view of the ghost buffer, engine.py)
+        return None
+
+    @staticmethod
+    def alltoallv_finish(handle):
+        return None
+
+    def close(self):
+        if self._native is not None:
+            from . import _hip
+
+            _hip.load().aks_comm_destroy(self._native)
+            self._native = None
+        self._hub.close()
+        _live_comms.discard(self)
+
+
+_host_comm = None
+
+
+def host_comm_from_env():
+    """One ``HostComm`` per process for the ranks an environment describes (RANK / WORLD_SIZE / MASTER_*)."""
+    global _host_comm
+    if _host_comm is None:
+        _host_comm = HostComm()
+    return _host_comm

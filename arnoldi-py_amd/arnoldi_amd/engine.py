@@ -739,9 +739,14 @@ class ArnoldiContext:
 
 
 def default_comm():
-    """Comm over the default process group when torch.distributed is up with > 1 rank."""
+    """Comm over the default process group when torch.distributed is up with > 1 rank; or, with ``AKS_COMM=host`` and
+    WORLD_SIZE > 1 in the environment, the torch-free ``dist.HostComm`` (TCP rendezvous + the library's communicator)."""
     import sys
 
+    if os.environ.get("AKS_COMM") == "host" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from .dist import host_comm_from_env
+
+        return host_comm_from_env()
     if "torch.distributed" not in sys.modules:          # nobody can have initialised what was never imported
         return None
     import torch.distributed as dist

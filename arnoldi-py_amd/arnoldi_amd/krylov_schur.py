@@ -41,6 +41,7 @@ class KrylovSchurSolver:
         self.history = History.from_k(nev)
         self.m = 0
         self.restarts_run = 0
+        self.schur_memo = {}          # utils.complex_schur: remembers that the real route met 2 x 2 blocks
 
     def start(self):
         """Initial m-step expansion (krylov_schur.py:51-54)."""
@@ -58,7 +59,7 @@ class KrylovSchurSolver:
         # triangular matrix and returns (T, I) unchanged, so one call followed by the same
         # ?trexc sequence gives the same (T, Q).  (complex_schur: zgees, or dgees while H is exactly real
         # and its spectrum is -- a third of the time, utils.py.)
-        T, Q = complex_schur(H[:m, :m])
+        T, Q = complex_schur(H[:m, :m], self.schur_memo)
         T, Q = reorder_schur(T, Q, self.sort_function(np.diag(T)))
 
         # truncation on the device: V[:, :p] <- V[:, :m] Q[:, :p];  V[:, p] <- V[:, m]
@@ -87,7 +88,7 @@ class KrylovSchurSolver:
         H, m, nev = self.H, self.m, self.nev
         if m < nev:
             raise ValueError(f"Happy breakdown: invariant subspace of dimension {m} < nev = {nev}")
-        T, Q = complex_schur(H[:m, :m])
+        T, Q = complex_schur(H[:m, :m], self.schur_memo)
         T, Q = reorder_schur(T, Q, self.sort_function(np.diag(T)))
         self.ctx.truncate(Q[:, :nev], m, nev)
         H[:nev, :nev] = T[:nev, :nev]

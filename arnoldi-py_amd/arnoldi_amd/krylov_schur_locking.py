@@ -46,7 +46,7 @@ class LockingKrylovSchurSolver(KrylovSchurSolver):
         booked = restart * (self.max_dim - nev) + (m - nev)          # as krylov_schur.py:63
 
         S = H[l:m, l:m]
-        T, Z = complex_schur(S)
+        T, Z = complex_schur(S, self.schur_memo)
         T, Z = reorder_schur(T, Z, self.sort_function(np.diag(T)))
         beta = H[m, m - 1]                                           # the residual row of H is beta e_m^T
         coupling = beta * Z[-1, :]

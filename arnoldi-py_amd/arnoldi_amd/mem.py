@@ -3,15 +3,17 @@
 The C ABI of libarnoldi_hip.so takes raw device pointers and a ``hipStream_t``; what the Python layer needs around it is
 small: allocate / zero / copy buffers, views of rows and sub-blocks, one stream, a few events, pinned staging memory.
 
-``AKS_HOST_ALLOC=torch`` (default)  torch tensors, torch's current stream -- the host layer then composes with whatever
+``AKS_HOST_ALLOC=torch`` (default when torch is importable)
+                                    torch tensors, torch's current stream -- the host layer then composes with whatever
                                     else the caller does in torch (torch.distributed carries the multi-rank set-up,
                                     hipGraph replay uses torch's capture API, tests use torch to inspect results).
 ``AKS_HOST_ALLOC=hip``              ``HipArray`` below: hipMalloc / hipMemcpyAsync / hipMemsetAsync / hipHostMalloc /
                                     events through ctypes on libamdhip64.so.  torch is never imported: the drop-in then
                                     needs what the reference needs -- numpy and scipy (the reference's
-                                    dependencies, pyproject.toml:9-13) -- plus the HIP runtime.  Single GPU; hipGraph
-                                    replay through the runtime's capture API; no torch.distributed (row-sharded
-                                    solves need the torch backend for their set-up exchanges).
+                                    dependencies, pyproject.toml:9-13) -- plus the HIP runtime.  hipGraph replay through
+                                    the runtime's capture API; row-sharded solves through ``dist.HostComm`` (TCP
+                                    rendezvous + the library's communicator; ``AKS_COMM=host``).  The default when
+                                    torch cannot be imported.
 
 Both backends expose the same handful of functions, and their arrays the same handful of methods (``data_ptr``, basic
 slicing, ``view``, ``copy_``, ``zero_``, ``cpu().numpy()``, ``item``), which is all device.py / engine.py use.
@@ -24,7 +26,14 @@ import threading
 
 import numpy as np
 
-BACKEND = os.environ.get("AKS_HOST_ALLOC", "torch")
+def _default_backend():
+    """torch when it can be imported (not imported here), else the HIP runtime alone -- the reference's own dependency set."""
+    import importlib.util
+
+    return "torch" if importlib.util.find_spec("torch") is not None else "hip"
+
+
+BACKEND = os.environ.get("AKS_HOST_ALLOC") or _default_backend()
 if BACKEND not in ("torch", "hip"):
     raise ValueError(f"AKS_HOST_ALLOC={BACKEND!r}: expected 'torch' or 'hip'")
 
@@ -157,13 +166,35 @@ else:
             return False
 
     def stream_ptr():
-        """One non-blocking stream per host thread (created on first use)."""
-        s = getattr(_tls, "stream", None)
+        """One non-blocking stream per host thread AND device (created on first use on the device that is current:
+        a stream belongs to the device it was created on)."""
+        streams = getattr(_tls, "streams", None)
+        if streams is None:
+            streams = _tls.streams = {}
+        dev = current_device()
+        s = streams.get(dev)
         if s is None:
             h = C.c_void_p()
             _ck(_rt().hipStreamCreateWithFlags(C.byref(h), 1), "hipStreamCreateWithFlags")     # hipStreamNonBlocking
-            s = _tls.stream = h.value
+            s = streams[dev] = h.value
         return s
+
+    class _on:
+        """Make ``device`` current for the duration of an allocation / copy when it is not already (a caller
+        passing another device must not silently get memory and a stream on the current one)."""
+
+        def __init__(self, device):
+            index = getattr(device, "index", None)
+            self.ctx = device_ctx(index) if index is not None and index != current_device() else None
+
+        def __enter__(self):
+            if self.ctx is not None:
+                self.ctx.__enter__()
+
+        def __exit__(self, *exc):
+            if self.ctx is not None:
+                self.ctx.__exit__(*exc)
+            return False
 
     def synchronize():
         _ck(_rt().hipDeviceSynchronize(), "hipDeviceSynchronize")
@@ -409,10 +440,14 @@ else:
         shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
         dtype = np.dtype(dtype)
         nbytes = int(np.prod(shape)) * dtype.itemsize
-        alloc = _Allocation(nbytes)
-        arr = HipArray(alloc, alloc.ptr.value, shape, shape[1] if len(shape) == 2 else 0, dtype, device)
-        if zero and nbytes:
-            _ck(_rt().hipMemsetAsync(alloc.ptr, 0, C.c_size_t(nbytes), C.c_void_p(stream_ptr())), "hipMemsetAsync")
+        device = as_device(device)
+        with _on(device):
+            alloc = _Allocation(nbytes)
+            arr = HipArray(alloc, alloc.ptr.value, shape, shape[1] if len(shape) == 2 else 0, dtype, device)
+            if zero and nbytes:
+                _ck(_rt().hipMemsetAsync(alloc.ptr, 0, C.c_size_t(nbytes), C.c_void_p(stream_ptr())), "hipMemsetAsync")
+                if _on(device).ctx is not None:      # zeroed on the OTHER device's stream: done before that stream is left
+                    _ck(_rt().hipStreamSynchronize(C.c_void_p(stream_ptr())), "hipStreamSynchronize")
         return arr
 
     def zeros(shape, dtype, device):
@@ -425,7 +460,8 @@ else:
         a = np.ascontiguousarray(a)
         out = _alloc_array(a.shape if a.ndim else (1,), a.dtype, device, False)
         if a.size:
-            out.copy_(a.reshape(out.shape))
+            with _on(out.device):
+                out.copy_(a.reshape(out.shape))      # (a pageable source: copy_ waits for the copy before it returns)
         return out
 
     def host(a):

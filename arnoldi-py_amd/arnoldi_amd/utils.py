@@ -96,6 +96,15 @@ def host_blas_threads():
 
 _NATIVE_RANDN_FROM = 1_000_000      # below this NumPy's own loop is a few milliseconds
 _native_randn = None                # ctypes function, False once known to be unavailable
+_randn_lock = threading.Lock()      # one native draw at a time: it reads, advances and writes back the GLOBAL generator
+
+
+def _numpy_generator_lock():
+    """The lock NumPy's own ``randn`` holds for its whole call (the global RandomState's bit-generator lock), or None."""
+    try:
+        return np.random.mtrand._rand._bit_generator.lock
+    except AttributeError:
+        return None
 
 
 def legacy_randn(n):
@@ -124,18 +133,27 @@ def legacy_randn(n):
             return np.random.randn(n)
     import ctypes as C
 
-    state = np.random.get_state()
-    if state[0] != "MT19937":
+    # get_state .. native draw (GIL released) .. set_state is one critical section: two solver constructors
+    # starting at once would otherwise read the same MT state and draw the same vector, and a ``np.random`` draw by any
+    # other thread during the native call would be overwritten by set_state.  NumPy's randn holds the generator's lock
+    # for its whole call; so does this (get_state / set_state themselves do not take it).
+    glock = _numpy_generator_lock()
+    if glock is None:
         return np.random.randn(n)
-    key = np.array(state[1], dtype=np.uint32)                 # (a copy: the saved state stays intact)
-    pos, has_gauss, gauss = C.c_int32(int(state[2])), C.c_int32(int(state[3])), C.c_double(float(state[4]))
-    out = np.empty(n, np.float64)
-    rc = _native_randn(key.ctypes.data, C.byref(pos), C.byref(has_gauss), C.byref(gauss), out.ctypes.data, n)
-    if rc != 0:
-        np.random.set_state(state)
-        return np.random.randn(n)
-    np.random.set_state(("MT19937", key, pos.value, has_gauss.value, gauss.value))
-    return out
+    with _randn_lock, glock:
+        state = np.random.get_state()
+        failed = state[0] != "MT19937"
+        if not failed:
+            key = np.array(state[1], dtype=np.uint32)                 # (a copy: the saved state stays intact)
+            pos, has_gauss, gauss = C.c_int32(int(state[2])), C.c_int32(int(state[3])), C.c_double(float(state[4]))
+            out = np.empty(n, np.float64)
+            rc = _native_randn(key.ctypes.data, C.byref(pos), C.byref(has_gauss), C.byref(gauss), out.ctypes.data, n)
+            failed = rc != 0
+            if failed:
+                np.random.set_state(state)
+            else:
+                np.random.set_state(("MT19937", key, pos.value, has_gauss.value, gauss.value))
+    return np.random.randn(n) if failed else out
 
 
 def rand_normalized_vector(n, dtype=np.float64):
@@ -205,7 +223,10 @@ def arg_largest_real(x):
     return np.argsort(-np.real(x))
 
 
-def complex_schur(a):
+_REAL_SCHUR_RETRY = 8       # after a real Schur form with 2 x 2 blocks: try the real route again at the 8th call
+
+
+def complex_schur(a, memo=None):
     """``(T, Z)`` with ``a = Z T Z^H``, T upper triangular, both complex128 -- what the reference gets from
     ``scipy.linalg.schur(a, output="complex")`` (``zgees``; krylov_schur.py:69, utils.py:45).
 
@@ -218,12 +239,22 @@ def complex_schur(a):
     ``a``, and it is returned as such.  A real matrix with complex pairs (2x2 blocks) and every complex matrix go
     through ``zgees`` as before.  The Schur form is unique up to the phases of the Schur vectors only, so ``(T, Z)`` may
     differ from ``zgees``' output by such phases; the invariant subspaces -- all the Krylov-Schur iteration uses -- and
-    hence History, eigenvalues and residuals do not.  ``AKS_REAL_SCHUR=0`` switches the shortcut off."""
+    hence History, eigenvalues and residuals do not.  ``AKS_REAL_SCHUR=0`` switches the shortcut off.
+
+    ``memo`` (a dict the caller keeps per solve): once the real attempt has produced 2 x 2 blocks it is skipped for the
+    next ``_REAL_SCHUR_RETRY - 1`` calls -- a real operator with complex Ritz pairs would otherwise pay dgees AND zgees
+    while H stays exactly real."""
     a = np.asarray(a)
     if np.iscomplexobj(a) and os.environ.get("AKS_REAL_SCHUR", "1") != "0" and not a.imag.any():
-        Tr, Zr = scipy.linalg.schur(np.ascontiguousarray(a.real), output="real")
-        if not np.diagonal(Tr, -1).any():                  # no 2 x 2 block: a triangular, i.e. complex, Schur form
-            return Tr.astype(np.complex128), Zr.astype(np.complex128)
+        if memo is not None and memo.get("skip_real", 0) > 0:
+            memo["skip_real"] -= 1
+        else:
+            Tr, Zr = scipy.linalg.schur(np.ascontiguousarray(a.real), output="real")
+            if not np.diagonal(Tr, -1).any():              # no 2 x 2 block: a triangular, i.e. complex, Schur form
+                return Tr.astype(np.complex128), Zr.astype(np.complex128)
+            if memo is not None:
+                memo["skip_real"] = _REAL_SCHUR_RETRY - 1
+                memo["real_attempts_wasted"] = memo.get("real_attempts_wasted", 0) + 1
     return scipy.linalg.schur(a, output="complex")
 
 

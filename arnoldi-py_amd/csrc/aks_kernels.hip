@@ -215,18 +215,15 @@ __device__ __forceinline__ c128 ld_partial(const c128 *p) {
 // The partials are in addition stored and loaded write-through / L1-bypassing (st_partial / ld_partial: sc1), which the
 // guide measures as valid on its own only with one workgroup per CU -- the second-pass kernel runs two, and round 4's
 // tree, which had neither fence, once in a while summed one STALE partial at full size (beta off by 1/512: residual
-// 2.2e-3 instead of 8.7e-9).  tests/test_gpu_parity.py::test_ticket_hand_off_books_the_step pins the hand-off.
-#ifndef AKS_TICKET_RELEASE
-#define AKS_TICKET_RELEASE 1
-#endif
+// 2.2e-3 instead of 8.7e-9).  tests/test_gpu_parity.py::test_ticket_hand_off_books_the_step pins the hand-off.  The
+// release costs nothing measurable: restarts of Laplacians (every step takes this path) 7.725 / 15.18 / 107.8 ms with it,
+// 7.765 / 15.17 / 109.8 ms without, builds interleaved on one box (profiles/r05_ticket_release_ab.txt).
 __device__ __forceinline__ bool last_block_arrives(unsigned *ticket) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // EVERY storing wave: its stores have left the CU
     __shared__ int s_last;
     __syncthreads();
     if (threadIdx.x == 0) {
-#if AKS_TICKET_RELEASE
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
         const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = old + 1u == gridDim.x;
         if (last) {
@@ -2441,6 +2438,41 @@ int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *strea
     if (c == nullptr || d_buf == nullptr || count < 1) return fail(AKS_ERR_ARG, "bad argument");
     ncclResult_t r = NCCL_CALL(AllReduce)(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->nccl, static_cast<hipStream_t>(stream));
     if (r != ncclSuccess) return nccl_fail(r, "ncclAllReduce");
+    return AKS_OK;
+}
+
+int aks_comm_alltoallv(void *comm, const void *d_send, const int64_t *send_offsets, const int64_t *send_bytes,
+                       void *d_recv, const int64_t *recv_offsets, const int64_t *recv_bytes, void *stream) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (c == nullptr || !send_offsets || !send_bytes || !recv_offsets || !recv_bytes) return fail(AKS_ERR_ARG, "null pointer");
+    int64_t total_s = 0, total_r = 0;
+    for (int peer = 0; peer < c->size; ++peer) {     // validate BEFORE anything is enqueued (as shard_apply does)
+        if (send_offsets[peer] < 0 || send_bytes[peer] < 0 || recv_offsets[peer] < 0 || recv_bytes[peer] < 0)
+            return fail(AKS_ERR_ARG, "negative offset or size");
+        total_s += send_bytes[peer];
+        total_r += recv_bytes[peer];
+    }
+    if ((total_s > 0 && d_send == nullptr) || (total_r > 0 && d_recv == nullptr)) return fail(AKS_ERR_ARG, "null buffer");
+    if (send_bytes[c->rank] != recv_bytes[c->rank]) return fail(AKS_ERR_ARG, "this rank's own slice: sizes differ");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const char *sb = static_cast<const char *>(d_send);
+    char *rb = static_cast<char *>(d_recv);
+    if (send_bytes[c->rank] > 0) {
+        hipError_t e = hipMemcpyAsync(rb + recv_offsets[c->rank], sb + send_offsets[c->rank], (size_t)send_bytes[c->rank],
+                                      hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return hip_fail(e, "aks_comm_alltoallv(own slice)");
+    }
+    if (c->size == 1) return AKS_OK;
+    ncclResult_t r = NCCL_CALL(GroupStart)();
+    for (int peer = 0; peer < c->size && r == ncclSuccess; ++peer) {
+        if (peer == c->rank) continue;
+        if (send_bytes[peer] > 0) r = NCCL_CALL(Send)(sb + send_offsets[peer], (size_t)send_bytes[peer], ncclInt8, peer, c->nccl, s);
+        if (recv_bytes[peer] > 0 && r == ncclSuccess)
+            r = NCCL_CALL(Recv)(rb + recv_offsets[peer], (size_t)recv_bytes[peer], ncclInt8, peer, c->nccl, s);
+    }
+    const ncclResult_t r2 = NCCL_CALL(GroupEnd)();
+    if (r != ncclSuccess) return nccl_fail(r, "ncclSend/ncclRecv");
+    if (r2 != ncclSuccess) return nccl_fail(r2, "ncclGroupEnd");
     return AKS_OK;
 }
 

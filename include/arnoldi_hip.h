@@ -325,6 +325,16 @@ int aks_comm_create(const void *id, int32_t rank, int32_t size, void **comm_out)
 int aks_comm_destroy(void *comm);
 /* In-place sum over the ranks of `count` doubles on `stream` (the Gram-Schmidt reductions). */
 int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *stream);
+/* Personalised exchange of BYTES between all ranks on `stream`, one group of sends / receives: rank r receives
+ * send_bytes[r] bytes starting at d_send + send_offsets[r] of every peer into d_recv + recv_offsets[peer]
+ * (recv_bytes[peer] must equal what that peer sends here; this rank's own slice is a device copy).  The arrays are
+ * host arrays of `size` entries.  This is what carries the host layer's SET-UP exchanges -- which ghost entries each
+ * rank needs from which owner, the row blocks of the final Schur vectors -- over the library's own communicator, so
+ * that a multi-rank solve needs no other transport than the few bytes of the communicator id (the reference's only
+ * distributed comparator gathers through MPI: scripts/utils.py:212-235).  An all-gather is the call with every
+ * send_offsets[r] = 0 and send_bytes[r] = this rank's block. */
+int aks_comm_alltoallv(void *comm, const void *d_send, const int64_t *send_offsets, const int64_t *send_bytes,
+                       void *d_recv, const int64_t *recv_offsets, const int64_t *recv_bytes, void *stream);
 
 /* y = A x for this rank's rows: pack, exchange overlapped with the diagonal block, off-diagonal block.
  * flags: AKS_EXPAND_REAL_PACKED for float64 vectors.  A no-op on the device once the control block of

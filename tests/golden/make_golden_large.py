@@ -58,7 +58,34 @@ CASES = {
 }
 
 
+def start_vector_record(n, seed):
+    """sha256 of the reference's start vector, its first entries and sum, and -- to tell WHERE another machine's NumPy
+    departs from this container's, if it does -- the sha256 of the raw draws and the 2-norm they were divided by."""
+    np.random.seed(seed)
+    v0 = rand_normalized_vector(n, np.complex128)
+    sha, head, total = hashlib.sha256(v0.tobytes()).hexdigest(), v0[:4].copy(), float(np.sum(v0.real))
+    del v0
+    np.random.seed(seed)
+    draws = np.random.randn(n)
+    return sha, head, total, hashlib.sha256(draws.tobytes()).hexdigest(), float(np.linalg.norm(draws.astype(np.complex128)))
+
+
+def augment():
+    """Add the start-vector diagnostics to fixtures written before they existed (no reference solve is repeated)."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(HERE, "g11_*_full.npz"))):
+        g = dict(np.load(path))
+        sha, head, total, draws_sha, norm = start_vector_record(int(g["n"]), int(g["seed"]))
+        assert sha == str(g["v0_sha256"]), path
+        g.update(draws_sha256=np.array(draws_sha), v0_norm=np.float64(norm))
+        np.savez_compressed(path, **g)
+        print(os.path.basename(path), draws_sha[:16], repr(norm))
+
+
 def main():
+    if sys.argv[1] == "augment":
+        return augment()
     name = sys.argv[1]
     build, kw, seed = CASES[name]
     kw = dict(kw)
@@ -72,12 +99,7 @@ def main():
     Ac = A.astype(np.complex128)
     print(f"{name}: n={n} nnz={A.nnz} built in {time.time() - t0:.1f}s", flush=True)
 
-    np.random.seed(seed)
-    v0 = rand_normalized_vector(n, np.complex128)
-    v0_sha = hashlib.sha256(v0.tobytes()).hexdigest()
-    v0_head = v0[:4].copy()
-    v0_sum = float(np.sum(v0.real))
-    del v0
+    v0_sha, v0_head, v0_sum, draws_sha, v0_norm = start_vector_record(n, seed)
 
     np.random.seed(seed)
     t0 = time.time()
@@ -98,6 +120,7 @@ def main():
         restarts=np.int64(hist.restarts.max()), hist_matvecs=hist.matvecs, hist_restarts=hist.restarts,
         T=T, diagT=np.diag(T).copy(), eigvals=vals, rel_residuals=rel, ortho=np.float64(ortho),
         v0_sha256=np.array(v0_sha), v0_head=v0_head, v0_sum=np.float64(v0_sum),
+        draws_sha256=np.array(draws_sha), v0_norm=np.float64(v0_norm),
         ref_wall_s=np.float64(wall), ref_cores=np.int64(os.cpu_count()),
         matrix_dtype_given=np.array("complex128"),
     )

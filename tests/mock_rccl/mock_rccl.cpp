@@ -210,18 +210,20 @@ ncclResult_t ncclGroupEnd() {
     return ncclSuccess;
 }
 
+static size_t dt_width(ncclDataType_t dt) { return dt == ncclDouble ? 8 : (dt == ncclInt8 ? 1 : 0); }   // (what the library sends)
+
 ncclResult_t ncclSend(const void *buf, size_t count, ncclDataType_t dt, int peer, ncclComm_t comm, hipStream_t stream) {
     MockComm *c = reinterpret_cast<MockComm *>(comm);
-    if (dt != ncclDouble || peer < 0 || peer >= c->nranks) return ncclInvalidArgument;
-    g_ops.push_back(Op{true, const_cast<void *>(buf), count * 8, peer, c, stream});
+    if (dt_width(dt) == 0 || peer < 0 || peer >= c->nranks) return ncclInvalidArgument;
+    g_ops.push_back(Op{true, const_cast<void *>(buf), count * dt_width(dt), peer, c, stream});
     if (g_depth == 0) run_group(g_ops);
     return ncclSuccess;
 }
 
 ncclResult_t ncclRecv(void *buf, size_t count, ncclDataType_t dt, int peer, ncclComm_t comm, hipStream_t stream) {
     MockComm *c = reinterpret_cast<MockComm *>(comm);
-    if (dt != ncclDouble || peer < 0 || peer >= c->nranks) return ncclInvalidArgument;
-    g_ops.push_back(Op{false, buf, count * 8, peer, c, stream});
+    if (dt_width(dt) == 0 || peer < 0 || peer >= c->nranks) return ncclInvalidArgument;
+    g_ops.push_back(Op{false, buf, count * dt_width(dt), peer, c, stream});
     if (g_depth == 0) run_group(g_ops);
     return ncclSuccess;
 }

@@ -985,6 +985,23 @@ def test_row_sharded_c_driven_path_ranks_share_the_gpu(amd, tmp_path, ranks):
             del os.environ["AKS_SPMV_FORM"]
 
 
+@pytest.mark.parametrize("ranks", [2, 3, 4])
+def test_row_sharded_torch_free_process_ranks(amd, tmp_path, ranks):
+    """The same cases with NO torch in the rank processes: plain processes, ``dist.HostComm`` -- the
+    communicator id and the control messages over a TCP rendezvous, ghost requests and Schur-vector rows through the
+    library's own communicator (``aks_comm_alltoallv``) --, device memory from the HIP runtime (AKS_HOST_ALLOC=hip).
+    The ranks share GPU 0, so the library is the build against tests/mock_rccl, as above."""
+    import subprocess
+
+    from test_host_logic import ROOT, check_dist_verdicts, run_hostcomm_worker
+
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    verdicts = run_hostcomm_worker(tmp_path, ranks, "solve")
+    assert not any(v.pop("torch_imported") for v in verdicts)
+    check_dist_verdicts(verdicts, native=True)
+
+
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_row_sharded_c_driven_path_over_rccl(amd, tmp_path, ranks):
     """The same cases through RCCL ITSELF, rank r on GPU r: only runs on a box that has the GPUs (the one-GPU boxes of

@@ -134,6 +134,28 @@ def test_sharded_full_size_solve_is_bitwise_reproducible(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,args,forms,deferred", [
+    ("config5_one_gpu_binned", ["--ranks", "1"], ["binned", None], True),
+    ("markov_10m_one_gpu_sliced", ["--ranks", "1", "--workload", "markov"], ["sliced", None], True),
+    ("config5_real_packed_one_gpu", ["--ranks", "1", "--real"], ["binned", None], True),
+    ("config4_eight_ranks", ["--ranks", "8", "--workload", "laplace3d", "--rows", "16000000"], ["sliced", "csr"], None),
+])
+def test_full_size_drivers_are_bitwise_repeatable(tmp_path, name, args, forms, deferred):
+    """The sweep round 4 ran by hand (profiles/r04_repro_sweep.txt), in the suite: each driver at a
+    BASELINE size, solved twice in ONE process with a 128 MB cache sweep between the launches -- H after every expansion and
+    every contraction must be the same bits both times.  Both silent wrong-H bugs of round 3 (a scalar load overtaken by
+    the kernel's own stores; a last-arriver summing a stale partial) showed only at these sizes, a few times in a hundred
+    restarts, and as a difference between two runs of the same solve."""
+    r = _worker(tmp_path, "repro", args + ["--repeats", "2", "--sweep"], timeout=600)
+    assert r["forms"][0] == forms[0] and (forms[1] is None or r["forms"][1] == forms[1]), r["forms"]
+    if deferred is not None:
+        assert (r["info"][-1][3] >= 3) == deferred, r["info"]        # deferred normalisation in every re-expansion
+    assert len(set(r["sha"])) == 1, (r["sha"], r["report"])
+    assert all(x["first_differing_snapshot"] is None and x["snapshots"] >= 8 for x in r["report"]), r["report"]
+    print(name, r["n"], r["forms"], r["info"][-1], r["sha"])
+
+
+@pytest.mark.gpu
 def test_carried_scale_survives_the_truncation():
     """The restart compression with a raw last column, thousands of times: column p must inherit the scale of column m
     and every other scale must be cleared, every time (the regression test of the bug described above, on one GPU and

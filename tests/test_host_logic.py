@@ -514,6 +514,44 @@ def run_dist_worker(tmp_path, nproc, backend, device, timeout=600, extra=()):
     return [json.load(open(os.path.join(tmp_path, f"rank{r}.json"))) for r in range(nproc)]
 
 
+def run_hostcomm_worker(tmp_path, nproc, case, timeout=600):
+    """``nproc`` plain processes (no launcher, no torch): tests/hostcomm_worker.py over ``dist.HostComm``."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(OMP_NUM_THREADS="2", WORLD_SIZE=str(nproc), AKS_RENDEZVOUS=f"127.0.0.1:{_free_port()}", AKS_COMM_TIMEOUT_S="120")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "hostcomm_worker.py"), "--case", case, "--out", str(tmp_path)],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(nproc)]
+    outs = []
+    for p_ in procs:
+        try:
+            outs.append(p_.communicate(timeout=timeout)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p_.returncode == 0 for p_ in procs), "\n".join(o[-3000:] for o in outs)
+    return [json.load(open(os.path.join(tmp_path, f"rank{r}.json"))) for r in range(nproc)]
+
+
+@pytest.mark.parametrize("ranks", [2, 5])
+def test_torch_free_ranks_set_up_over_the_tcp_rendezvous(tmp_path, ranks):
+    """dist.HostComm: process ranks without torch.distributed -- and without torch in the process at
+    all -- carry the set-up exchanges of the row-sharded solve (all-gather, ghost requests, row gather, max, barrier,
+    and the chained path's all-reduce / all-to-all) over a TCP rendezvous."""
+    verdicts = run_hostcomm_worker(tmp_path, ranks, "setup")
+    assert all(v == {"setup": "ok", "size": ranks, "torch_imported": False} for v in verdicts), verdicts
+
+
+def test_rendezvous_fails_loudly_when_a_rank_is_missing(tmp_path):
+    """A rank that never arrives is a RuntimeError after the time-out on the ranks that did, not a hang."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", AKS_RENDEZVOUS=f"127.0.0.1:{_free_port()}", AKS_COMM_TIMEOUT_S="2")
+    code = ("import sys; sys.path.insert(0, %r); from arnoldi_amd.dist import HostComm\n"
+            "try:\n    HostComm()\nexcept RuntimeError as e:\n    print('RuntimeError:', e); sys.exit(7)" % os.path.join(ROOT, "arnoldi-py_amd"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 7 and "only 1 of 2 ranks arrived" in r.stdout, r.stdout + r.stderr
+
+
 def check_dist_verdicts(verdicts, native=False):
     for v in verdicts:
         assert all(c["native_comm"] == native for c in v.values() if "native_comm" in c), "unexpected collective path"
@@ -658,6 +696,19 @@ def test_native_legacy_randn_is_numpys_stream_bit_for_bit(monkeypatch):
         wr = np.random.randn(n).astype(np.float64)
         wr /= np.linalg.norm(wr)
         assert np.array_equal(r, wr)
+    # two threads drawing at once (two solver constructors): the draws are serialised, so together they are
+    # the two consecutive draws of the stream -- in either order -- never the same vector twice
+    import threading
+
+    np.random.seed(11)
+    first, second = np.random.randn(1_000_001), np.random.randn(1_000_001)
+    np.random.seed(11)
+    out = [None, None]
+    ts = [threading.Thread(target=lambda k=k: out.__setitem__(k, utils.legacy_randn(1_000_001))) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert (np.array_equal(out[0], first) and np.array_equal(out[1], second)) or \
+           (np.array_equal(out[1], first) and np.array_equal(out[0], second))
     monkeypatch.setenv("AKS_NATIVE_RANDN", "0")               # switch: NumPy's own loop
     np.random.seed(3)
     assert np.array_equal(utils.legacy_randn(1_200_001), want)
@@ -1123,5 +1174,19 @@ def test_complex_schur_takes_the_real_route_only_when_it_is_a_complex_schur_form
     np.testing.assert_array_equal(Z2, Zz)
     cplx = sym + 1e-3j * S                                      # not real: zgees
     np.testing.assert_array_equal(complex_schur(cplx)[0], scipy.linalg.schur(cplx, output="complex")[0])
+    # a solver's memo: after a real attempt that met 2 x 2 blocks the next 7 calls go straight to zgees, the 8th tries again
+    calls = []
+    real_schur = scipy.linalg.schur
+    monkeypatch.setattr(scipy.linalg, "schur", lambda a, output="real", **kw: (calls.append(output), real_schur(a, output=output, **kw))[1])
+    memo = {}
+    for _ in range(9):
+        np.testing.assert_array_equal(complex_schur(rot, memo)[0], Tz)
+    assert calls.count("real") == 2 and calls.count("complex") == 9 and memo["real_attempts_wasted"] == 2
+    calls.clear()
+    memo = {}
+    for _ in range(3):                                         # a real spectrum never arms the memo
+        complex_schur(sym, memo)
+    assert calls == ["real"] * 3 and not memo
+    monkeypatch.undo()
     monkeypatch.setenv("AKS_REAL_SCHUR", "0")
     np.testing.assert_array_equal(complex_schur(sym)[0], scipy.linalg.schur(sym, output="complex")[0])

@@ -230,13 +230,17 @@ def case_graphguard(ranks):
     return {"ranks": out}
 
 
-def case_repro(ranks, n, repeats=3, workload="random", real=False):
+def case_repro(ranks, n, repeats=3, workload="random", real=False, sweep=False):
     """The same sharded solve ``repeats`` times in one process: H after the initial expansion and after every restart
     must be the SAME BITS every time (fixed-order reductions, rank-ordered all-reduces): where a run first departs from
     the first one (which snapshot, which columns of H = which Arnoldi steps), and by how much.  This is the test that
     found round 3's lost carried scale (k_colscale_after_truncate: a scalar load overtaken by the kernel's own vector
-    stores, a few restarts in a hundred at 2 ranks x 5M rows) -- a defect no small case had shown."""
+    stores, a few restarts in a hundred at 2 ranks x 5M rows) -- a defect no small case had shown.
+    ``sweep``: rank 0 rewrites a 128 MB buffer after every expansion and every contraction, so that no launch finds
+    the caches the way the launch before left them (tests/test_gpu_sharded_full.py::test_carried_scale_survives_the_truncation)."""
     import hashlib
+
+    import torch
 
     from arnoldi_amd import matrices
     from arnoldi_amd.dist import row_offsets
@@ -266,8 +270,13 @@ def case_repro(ranks, n, repeats=3, workload="random", real=False):
     np.random.seed(0)
     v0 = rand_normalized_vector(n, np.float64 if real else C128)
     runs = []
+    big = torch.empty(1 << 24, dtype=torch.float64, device="cuda") if sweep else None
     for rep in range(repeats):
         def rank_fn(comm, rank):
+            def wipe(tag):
+                if big is not None and rank == 0:
+                    big.fill_(float(tag))
+
             op = CsrOperator(local_rows=A[int(offs[rank]): int(offs[rank + 1])], offsets=offs, comm=comm, real=real)
             if real:
                 from arnoldi_amd.krylov_schur_real import RealKrylovSchurSolver
@@ -279,10 +288,12 @@ def case_repro(ranks, n, repeats=3, workload="random", real=False):
             s.start()
             Hs.append(s.H.copy())
             for r in range(6):
+                wipe(2 * r)
                 done = s.contract(r)
                 Hs.append(s.H.copy())
                 if done:
                     break
+                wipe(2 * r + 1)
                 s.expand()
                 Hs.append(s.H.copy())
                 c = s.ctx.last_ctrl
@@ -406,6 +417,8 @@ def main():
     ap.add_argument("--leg-rows", type=int, default=None)
     ap.add_argument("--workload", default="random", choices=["random", "markov", "laplace3d"])
     ap.add_argument("--real", action="store_true")
+    ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--sweep", action="store_true", help="(repro) a 128 MB cache sweep between the launches of a solve")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch
@@ -421,7 +434,7 @@ def main():
     elif a.case == "c5":
         res = case_c5([a.ranks, 2] if a.ranks != 2 else [2], a.rows or 10_000_000)
     elif a.case == "repro":
-        res = case_repro(a.ranks, a.rows or 10_000_000, workload=a.workload, real=a.real)
+        res = case_repro(a.ranks, a.rows or 10_000_000, repeats=a.repeats, workload=a.workload, real=a.real, sweep=a.sweep)
     elif a.case == "graphguard":
         res = case_graphguard(a.ranks)
     elif a.case == "breakdown":
