@@ -10,7 +10,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_DIM = 128          # AKS_MAX_DIM
 MAX_TRUNC = 96         # AKS_MAX_TRUNC
 SPMV_TILE_NNZ = 256    # AKS_SPMV_TILE_NNZ
@@ -154,6 +154,7 @@ SIGNATURES = {
     "aks_comm_create": (C.c_int, [_P, _I32, _I32, C.POINTER(_P)]),
     "aks_comm_destroy": (C.c_int, [_P]),
     "aks_comm_allreduce_sum": (C.c_int, [_P, _P, _I64, _P]),
+    "aks_comm_allreduce_path": (C.c_int, [_P, C.c_char_p, _I64]),
     "aks_comm_alltoallv": (C.c_int, [_P, _P, C.POINTER(_I64), C.POINTER(_I64), _P, C.POINTER(_I64), C.POINTER(_I64), _P]),
     "aks_workspace_set_real": (C.c_int, [_P, _I32, _P]),
     "aks_csr_spmv_real": (C.c_int, [_I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _P]),
@@ -236,7 +237,7 @@ def device_init(index):
         _devices_ready.add(index)
 
 
-PROBE_SPMV, PROBE_ORTHO, PROBE_PACK, PROBE_EXCHANGE, PROBE_DIAG, PROBE_OFFDIAG = range(6)   # AKS_PROBE_*
+PROBE_SPMV, PROBE_ORTHO, PROBE_PACK, PROBE_EXCHANGE, PROBE_DIAG, PROBE_OFFDIAG, PROBE_ALLREDUCE = range(7)   # AKS_PROBE_*
 
 
 class Probe:

@@ -60,6 +60,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include "arnoldi_hip.h"
 
@@ -800,7 +801,10 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(int64_t n_tiles, const int32_t *
 // Workgroups with the same blockIdx % 8 share an XCD (observed placement; speed only): each XCD gets a
 // contiguous eighth of the slices, so the x entries that rows a grid line or plane apart share are fetched
 // into ONE L2 rather than into all eight (profiles/microbench/sell_spmv.txt: 3-D Laplace 0.400 -> 0.347 ms).
-constexpr int SELL_U = 4;
+#ifndef AKS_SELL_U
+#define AKS_SELL_U 4            // entries of a row in flight per lane (A/B: profiles/r05_sell_in_solve.txt)
+#endif
+constexpr int SELL_U = AKS_SELL_U;
 #ifndef AKS_NT_SELL
 #define AKS_NT_SELL 1            // non-temporal loads of the value / column streams (read once): 1-8 % (sell_spmv.txt)
 #endif
@@ -1464,11 +1468,78 @@ struct Probe {
     }
 };
 
+// ---- one-shot small all-reduce (opt-in: AKS_ALLREDUCE=oneshot) -------------------------------------------------------
+// The reductions between the Gram-Schmidt stages are <= 2 (max_dim + 1) doubles: latency, not bandwidth (SURVEY 5, 8(e):
+// "one-shot over all 7 xGMI links, not a ring").  Every rank owns a MAILBOX in fine-grained device memory that all its
+// peers have mapped (hipIpc* across processes, the plain pointer inside one process): two parities x `size` rows of
+// ONESHOT_CAP doubles and one arrival counter per parity.  An all-reduce of call number q (parity q & 1) is, in stream
+// order on every rank:
+//   k_oneshot_post   one workgroup: writes this rank's values into ITS row of EVERY peer's mailbox (its own included) with
+//                    system-scope stores, __threadfence_system(), workgroup barrier, then one system-scope release add per
+//                    peer on that peer's arrival counter;
+//   hipStreamWaitValue64 on the LOCAL counter >= size * (calls made on this parity): the queue's command processor polls,
+//                    no compute unit spins -- ranks that share one GPU (the rehearsal) cannot starve the producer they
+//                    wait for;
+//   k_oneshot_sum    one workgroup: sums the `size` rows IN RANK ORDER starting from +0.0 (system-scope loads) into the
+//                    caller's buffer -- the same bits on every rank, and the bits tests/mock_rccl's all-reduce produces.
+// Two parities suffice: a peer can post call q + 1 while this rank still sums call q (other parity), but call q + 2 only
+// after its own wait of q + 1 has seen THIS rank's post of q + 1, which is behind this rank's sum of q in stream order.
+// aks_comm_create sets it up when asked to, proves it with one reduction, lets the ranks vote (over ncclAllReduce), and
+// falls back to ncclAllReduce on every rank if any rank could not (aks_comm_allreduce_path tells which one runs).
+// What only multi-GPU hardware can confirm: system-scope visibility of the posts over xGMI and the cost of the remote
+// adds; on one GPU the peers' mailboxes are local memory.
+// CONSTRAINT: the stream that waits must not share a HARDWARE queue with a stream whose post it waits for -- the wait
+// blocks its queue, a post queued behind it never runs.  Rank processes (one per GPU: the product's mode) have queues
+// of their own and cannot collide; thread ranks inside one process collide as soon as the runtime multiplexes their
+// streams (GPU_MAX_HW_QUEUES, default 4): measured as a hang from the second solve of a process on, gone with more
+// queues than streams (profiles/r05_small_trace.txt).
+constexpr int ONESHOT_CAP = 2 * (AKS_MAX_DIM + 2);      // doubles per row: the widest stage reduction, [h ; ||w||^2]
+constexpr int ONESHOT_MAX_RANKS = 16;
+constexpr int ONESHOT_FLAG_STRIDE = 16;                 // counters 128 bytes apart
+struct OneShotPeers {
+    double *box[ONESHOT_MAX_RANKS];
+    unsigned long long *flag[ONESHOT_MAX_RANKS];
+};
+struct OneShot {
+    bool active = false;
+    void *local = nullptr;                              // this rank's mailbox allocation (counters, then rows)
+    void *opened[ONESHOT_MAX_RANKS] = {};               // hipIpcOpenMemHandle results to close again
+    OneShotPeers peers = {};
+    unsigned long long calls = 0;
+    std::string why_not;                                // set when the set-up was asked for and did not succeed
+};
+constexpr size_t ONESHOT_FLAG_BYTES = 2 * ONESHOT_FLAG_STRIDE * sizeof(unsigned long long);
+inline size_t oneshot_bytes(int size) { return ONESHOT_FLAG_BYTES + (size_t)2 * size * ONESHOT_CAP * sizeof(double); }
+
+__global__ __launch_bounds__(BLOCK) void k_oneshot_post(const double *__restrict__ buf, int count, OneShotPeers P, int size,
+                                                       int rank, int parity) {
+    for (int idx = threadIdx.x; idx < count * size; idx += BLOCK) {
+        const int peer = idx / count, e = idx - peer * count;
+        __hip_atomic_store(&P.box[peer][((size_t)parity * size + rank) * ONESHOT_CAP + e], buf[e], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();                              // every storing thread: its rows are performed at system scope
+    __syncthreads();
+    if ((int)threadIdx.x < size)
+        __hip_atomic_fetch_add(&P.flag[threadIdx.x][parity * ONESHOT_FLAG_STRIDE], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_oneshot_sum(double *__restrict__ buf, int count, const double *box, int size, int parity) {
+    for (int e = threadIdx.x; e < count; e += BLOCK) {
+        double s = 0.0;
+        for (int src = 0; src < size; ++src)             // rank order: the same bits on every rank
+            s += __hip_atomic_load(const_cast<double *>(&box[((size_t)parity * size + src) * ONESHOT_CAP + e]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        buf[e] = s;
+    }
+}
+
 struct Comm {
     ncclComm_t nccl = nullptr;
     hipStream_t side = nullptr;          // carries the ghost exchange next to the diagonal-block SpMV
     hipEvent_t packed = nullptr, arrived = nullptr;
     int rank = 0, size = 1;
+    OneShot one;
 };
 
 // RCCL is loaded when the first communicator is asked for, not with the library: librccl.so is hundreds of megabytes of
@@ -2389,6 +2460,155 @@ int aks_sell_spmv_real(const aks_sell_matrix *A, const double *d_x, double *d_y,
     return sell_spmv_any(A, d_x, d_y, accumulate, d_ws, stream, true, nullptr, EvPair());
 }
 
+// ---- one-shot all-reduce: set-up, vote, tear-down ----------------------------------------------------------------------
+struct OneShotCard {                     // what a rank tells its peers about its mailbox
+    hipIpcMemHandle_t handle;
+    unsigned long long address;          // the pointer itself: valid for peers inside the same process
+    long long pid;
+    int device, ok;
+};
+
+static void oneshot_release(Comm *c) {
+    for (int p = 0; p < ONESHOT_MAX_RANKS; ++p)
+        if (c->one.opened[p] != nullptr) { (void)hipIpcCloseMemHandle(c->one.opened[p]); c->one.opened[p] = nullptr; }
+    if (c->one.local != nullptr) { (void)hipFree(c->one.local); c->one.local = nullptr; }
+    c->one.active = false;
+}
+
+// min over the ranks of `mine` (0 / 1) through the library communicator: the ranks decide TOGETHER
+static int oneshot_vote(Comm *c, double *d_flag, int mine, int *all) {
+    const double v = mine ? 1.0 : 0.0;
+    double got = 0.0;
+    hipError_t e = hipMemcpyAsync(d_flag, &v, sizeof v, hipMemcpyHostToDevice, c->side);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->side);
+    if (e != hipSuccess) return hip_fail(e, "oneshot vote");
+    // sum of the yes-votes == size  <=>  everybody said yes
+    ncclResult_t r = NCCL_CALL(AllReduce)(d_flag, d_flag, 1, ncclDouble, ncclSum, c->nccl, c->side);
+    if (r != ncclSuccess) return nccl_fail(r, "ncclAllReduce(oneshot vote)");
+    e = hipStreamSynchronize(c->side);
+    if (e == hipSuccess) e = hipMemcpy(&got, d_flag, sizeof got, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "oneshot vote");
+    *all = got > c->size - 0.5;
+    return AKS_OK;
+}
+
+static int oneshot_reduce(Comm *c, double *d_buf, int count, hipStream_t s);
+
+static int oneshot_setup(Comm *c) {
+    OneShot &o = c->one;
+    int ok = 1, dev = 0, can_wait = 0;
+    if (c->size > ONESHOT_MAX_RANKS) { ok = 0; o.why_not = "more ranks than ONESHOT_MAX_RANKS"; }
+    if (ok && (hipGetDevice(&dev) != hipSuccess ||
+               hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess || !can_wait)) {
+        ok = 0;
+        o.why_not = "the device does not support hipStreamWaitValue64";
+    }
+    if (ok) {
+        hipError_t e = hipExtMallocWithFlags(&o.local, oneshot_bytes(c->size), hipDeviceMallocFinegrained);
+        if (e == hipSuccess) e = hipMemset(o.local, 0, oneshot_bytes(c->size));
+        if (e != hipSuccess) { ok = 0; o.why_not = std::string("fine-grained mailbox: ") + hipGetErrorString(e); (void)hipGetLastError(); }
+    }
+    // every rank's card to every rank (grouped send / recv on the side stream: the one collective form the library uses)
+    OneShotCard mine = {};
+    std::vector<OneShotCard> cards(c->size);
+    mine.ok = ok;
+    mine.pid = (long long)getpid();
+    mine.device = dev;
+    mine.address = (unsigned long long)reinterpret_cast<uintptr_t>(o.local);
+    if (ok && hipIpcGetMemHandle(&mine.handle, o.local) != hipSuccess) {
+        (void)hipGetLastError();                          // (only peers in OTHER processes need the handle: decided per peer below)
+        memset(&mine.handle, 0, sizeof mine.handle);
+        mine.ok = 2;                                      // usable inside this process only
+    }
+    static_assert(sizeof(OneShotCard) % 8 == 0, "cards travel as doubles");
+    constexpr size_t CARD_D = sizeof(OneShotCard) / 8;
+    double *d_cards = nullptr;
+    hipError_t e = hipMalloc(&d_cards, (size_t)(c->size + 1) * sizeof(OneShotCard) + 8);
+    if (e != hipSuccess) return hip_fail(e, "oneshot set-up");
+    double *d_mine = d_cards + (size_t)c->size * CARD_D, *d_flag = d_mine + CARD_D;
+    int rc = AKS_OK;
+    e = hipMemcpy(d_mine, &mine, sizeof mine, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cards + (size_t)c->rank * CARD_D, &mine, sizeof mine, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "oneshot set-up");
+    if (rc == AKS_OK && c->size > 1) {
+        ncclResult_t r = NCCL_CALL(GroupStart)();
+        for (int peer = 0; peer < c->size && r == ncclSuccess; ++peer) {
+            if (peer == c->rank) continue;
+            r = NCCL_CALL(Send)(d_mine, CARD_D, ncclDouble, peer, c->nccl, c->side);
+            if (r == ncclSuccess) r = NCCL_CALL(Recv)(d_cards + (size_t)peer * CARD_D, CARD_D, ncclDouble, peer, c->nccl, c->side);
+        }
+        const ncclResult_t r2 = NCCL_CALL(GroupEnd)();
+        if (r != ncclSuccess) rc = nccl_fail(r, "ncclSend/ncclRecv(oneshot cards)");
+        else if (r2 != ncclSuccess) rc = nccl_fail(r2, "ncclGroupEnd(oneshot cards)");
+    }
+    if (rc == AKS_OK) {
+        e = hipStreamSynchronize(c->side);
+        if (e == hipSuccess) e = hipMemcpy(cards.data(), d_cards, (size_t)c->size * sizeof(OneShotCard), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "oneshot set-up");
+    }
+    if (rc != AKS_OK) { (void)hipFree(d_cards); oneshot_release(c); return rc; }
+    for (int peer = 0; peer < c->size && ok; ++peer) {
+        const OneShotCard &k = cards[peer];
+        void *base = nullptr;
+        if (!k.ok) { ok = 0; o.why_not = "rank " + std::to_string(peer) + " has no mailbox"; break; }
+        if (peer == c->rank) base = o.local;
+        else if (k.pid == mine.pid) {                     // thread ranks of one process: the pointer is the mapping
+            base = reinterpret_cast<void *>((uintptr_t)k.address);
+            if (k.device != dev) (void)hipDeviceEnablePeerAccess(k.device, 0), (void)hipGetLastError();
+        } else if (k.ok == 2 || mine.ok == 2) { ok = 0; o.why_not = "hipIpcGetMemHandle failed on a mailbox"; }
+        else if (hipIpcOpenMemHandle(&base, k.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            ok = 0;
+            o.why_not = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(hipGetLastError());
+        } else o.opened[peer] = base;
+        if (ok) {
+            o.peers.flag[peer] = static_cast<unsigned long long *>(base);
+            o.peers.box[peer] = reinterpret_cast<double *>(static_cast<char *>(base) + ONESHOT_FLAG_BYTES);
+        }
+    }
+    int all = 0;
+    rc = oneshot_vote(c, d_flag, ok, &all);
+    if (rc == AKS_OK && all) {                            // prove it: sum of (rank + 1), twice (both parities)
+        o.active = true;
+        double got[2] = {0.0, 0.0};
+        for (int rep = 0; rep < 2; ++rep) {           // (BOTH, whatever the first gave: every rank must post the same number of times)
+            const double v = c->rank + 1.0;
+            e = hipMemcpy(d_flag, &v, sizeof v, hipMemcpyHostToDevice);
+            if (e == hipSuccess && oneshot_reduce(c, d_flag, 1, c->side) != AKS_OK) e = hipErrorUnknown;
+            if (e == hipSuccess) e = hipStreamSynchronize(c->side);
+            if (e == hipSuccess) e = hipMemcpy(&got[rep], d_flag, sizeof(double), hipMemcpyDeviceToHost);
+            if (e != hipSuccess || got[rep] != c->size * (c->size + 1) / 2.0) {
+                ok = 0;
+                o.why_not = e != hipSuccess ? std::string("self-test: ") + g_err : "self-test gave " + std::to_string(got[rep]);
+                (void)hipGetLastError();
+            }
+        }
+        rc = oneshot_vote(c, d_flag, ok, &all);
+    }
+    (void)hipFree(d_cards);
+    if (rc != AKS_OK || !all) {
+        if (o.why_not.empty()) o.why_not = "another rank could not set the one-shot all-reduce up";
+        oneshot_release(c);
+    }
+    return rc;
+}
+
+static int oneshot_reduce(Comm *c, double *d_buf, int count, hipStream_t s) {
+    OneShot &o = c->one;
+    const unsigned long long q = ++o.calls;
+    const int parity = (int)(q & 1ull);
+    hipLaunchKernelGGL(k_oneshot_post, dim3(1), dim3(BLOCK), 0, s, d_buf, count, o.peers, c->size, c->rank, parity);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_oneshot_post");
+    const unsigned long long on_parity = (q + (unsigned long long)parity) / 2ull;   // calls made on this parity so far (q = 1, 3, .. odd)
+    e = hipStreamWaitValue64(s, o.peers.flag[c->rank] + parity * ONESHOT_FLAG_STRIDE, (uint64_t)c->size * on_parity,
+                             hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamWaitValue64");
+    hipLaunchKernelGGL(k_oneshot_sum, dim3(1), dim3(BLOCK), 0, s, d_buf, count, o.peers.box[c->rank], c->size, parity);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_oneshot_sum");
+    return AKS_OK;
+}
+
 // ---- communicator: RCCL + a side stream for the ghost exchange ------------------------------
 int aks_comm_unique_id(void *id_out) {
     static_assert(sizeof(ncclUniqueId) <= AKS_COMM_ID_BYTES, "AKS_COMM_ID_BYTES too small");
@@ -2418,6 +2638,11 @@ int aks_comm_create(const void *id, int32_t rank, int32_t size, void **comm_out)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->packed, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->arrived, hipEventDisableTiming);
     if (e != hipSuccess) { (void)aks_comm_destroy(c); return hip_fail(e, "aks_comm_create"); }
+    const char *want = getenv("AKS_ALLREDUCE");
+    if (want != nullptr && strcmp(want, "oneshot") == 0) {
+        const int rc = oneshot_setup(c);                 // AKS_OK also when the ranks agreed to stay with ncclAllReduce
+        if (rc != AKS_OK) { (void)aks_comm_destroy(c); return rc; }
+    }
     *comm_out = c;
     return AKS_OK;
 }
@@ -2425,6 +2650,7 @@ int aks_comm_create(const void *id, int32_t rank, int32_t size, void **comm_out)
 int aks_comm_destroy(void *comm) {
     Comm *c = static_cast<Comm *>(comm);
     if (c == nullptr) return AKS_OK;
+    oneshot_release(c);
     if (c->packed) (void)hipEventDestroy(c->packed);
     if (c->arrived) (void)hipEventDestroy(c->arrived);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -2436,9 +2662,17 @@ int aks_comm_destroy(void *comm) {
 int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *stream) {
     Comm *c = static_cast<Comm *>(comm);
     if (c == nullptr || d_buf == nullptr || count < 1) return fail(AKS_ERR_ARG, "bad argument");
+    if (c->one.active && count <= ONESHOT_CAP) return oneshot_reduce(c, d_buf, (int)count, static_cast<hipStream_t>(stream));
     ncclResult_t r = NCCL_CALL(AllReduce)(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->nccl, static_cast<hipStream_t>(stream));
     if (r != ncclSuccess) return nccl_fail(r, "ncclAllReduce");
     return AKS_OK;
+}
+
+int aks_comm_allreduce_path(void *comm, char *why_not, int64_t why_bytes) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (c == nullptr) return fail(AKS_ERR_ARG, "null communicator");
+    if (why_not != nullptr && why_bytes > 0) snprintf(why_not, (size_t)why_bytes, "%s", c->one.why_not.c_str());
+    return c->one.active ? 1 : 0;
 }
 
 int aks_comm_alltoallv(void *comm, const void *d_send, const int64_t *send_offsets, const int64_t *send_bytes,
@@ -2608,10 +2842,17 @@ int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 
             rc = dgks_gs_(n_panel, J, d_V, ldv, w, d_H + j, ldh, tol, eta, norm_mode, d_ws, ws_bytes, max_dim, stream, raw0, eo);
         } else {
             // the stage kernels with the reductions summed over the ranks in between
+            // (with a probe: every reduction over the ranks between its own pair of recorded events, AKS_PROBE_ALLREDUCE)
+            auto reduce_ranks = [&](c128 *slot, int64_t count) {
+                hipEvent_t done = pr ? pr->begin(AKS_PROBE_ALLREDUCE, static_cast<hipStream_t>(stream)) : nullptr;
+                const int r = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(slot), count, stream);
+                if (done) (void)hipEventRecord(done, static_cast<hipStream_t>(stream));
+                return r;
+            };
             rc = gs_project_(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream, raw0, eo.start);
-            if (rc == AKS_OK) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red1), 2 * (J + 1), stream);
+            if (rc == AKS_OK) rc = reduce_ranks(ws.red1, 2 * (J + 1));
             if (rc == AKS_OK) rc = gs_update_project_(n_panel, J, d_V, ldv, w, d_ws, ws_bytes, max_dim, stream, raw0);
-            if (rc == AKS_OK) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red2), 2 * (J + 1), stream);
+            if (rc == AKS_OK) rc = reduce_ranks(ws.red2, 2 * (J + 1));
             // the step's book-keeping rides on the second-pass kernel when no n-sized normalisation follows: always with
             // the lazy third all-reduce (a step that does take the second pass makes the caller repeat the expansion
             // anyway), otherwise only for the steps that need no second pass -- after one, the norm is summed over the
@@ -2621,7 +2862,7 @@ int aks_arnoldi_expand(const aks_shard *A, aks_c128 *d_V, int64_t ldv, aks_c128 
             const bool last = fin_mode == FIN_ALWAYS;
             if (rc == AKS_OK) rc = gs_update_norm_(n_panel, J, d_V, ldv, w, eta, d_ws, ws_bytes, max_dim, stream, raw0, fin_mode,
                                                    d_H + j, ldh, tol, norm_mode, last ? eo.stop : nullptr);
-            if (rc == AKS_OK && !lazy_third) rc = aks_comm_allreduce_sum(c, reinterpret_cast<double *>(ws.red3), 2, stream);
+            if (rc == AKS_OK && !lazy_third) rc = reduce_ranks(ws.red3, 2);
             if (rc == AKS_OK && !last)
                 rc = gs_finish_(n_panel, J, w, d_H + j, ldh, tol, eta, norm_mode, d_ws, ws_bytes, max_dim, stream, eo.stop,
                                 fin_mode == FIN_IF_ONCE ? 1 : 0);

@@ -193,9 +193,17 @@ def transfer(ins, i, roots, defs):
             defs.pop(("k", d), None)
         return
     if k in ("vload", "vatomic"):
+        # a VECTOR load from the kernarg segment (a by-value struct of pointers indexed per lane: k_oneshot_post's
+        # P.box[peer]) yields some argument; any other load yields data that derives from no argument
+        src = EMPTY
+        for operand in a[1:]:
+            for r in regs(operand):
+                src |= roots.get(r, EMPTY)
+        loaded = frozenset([ANYARG]) if (k == "vload" and KARG in src and ins.op.startswith(("global_load", "flat_load"))) else EMPTY
         for d in dst:
-            roots[d] = EMPTY
+            roots[d] = loaded
             defs[d] = i
+            defs.pop(("k", d), None)
         return
     # the kernarg pointer plus a constant (hidden arguments are read through such a copy): remember the constant
     kd = {}

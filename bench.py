@@ -397,7 +397,7 @@ def _measure(args, comm, world, rank):
 
     probe = None
     if native and GPU:
-        probe = _hip.Probe(capacity=8 * m * args.steps + 8)
+        probe = _hip.Probe(capacity=12 * m * args.steps + 8)
         ctx.probe = probe
     elif GPU:
         ctx.spmv_events = []
@@ -493,6 +493,18 @@ def _measure(args, comm, world, rank):
                 k, ms = probe.read(tag)
                 split[key] = round(ms / k, 4) if k else None
             exchange["spmv_device_ms_rank0"] = split
+            # the reductions over the ranks between the Gram-Schmidt stages (an event pair around each one, rank 0)
+            k, ms = probe.read(_hip.PROBE_ALLREDUCE)
+            probed_steps = max(n_ortho, 1)
+            exchange["allreduce_device_ms_per_step_rank0"] = round(ms / probed_steps, 4) if k else None
+            exchange["allreduce_calls_per_step_probed"] = round(k / probed_steps, 2) if k else None
+            exchange["allreduce_device_us_per_call_rank0"] = round(1e3 * ms / k, 2) if k else None
+        if native and comm is not None and comm.active and GPU:
+            import ctypes
+
+            why = ctypes.create_string_buffer(256)
+            path = _hip.load().aks_comm_allreduce_path(comm.native(), why, 256)
+            exchange["allreduce_path"] = "one-shot mailbox exchange" if path == 1 else ("ncclAllReduce" + (f" ({why.value.decode()})" if why.value else ""))
     res = {
         "value": round(args.steps / elapsed, 4),
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -510,6 +522,29 @@ def _measure(args, comm, world, rank):
         "graph_rate": graph_rate,
     }
     return res
+
+
+# The scaling model of DESIGN section 4 for the headline matrix, so that ONE record of the driver's 1/2/4/8 sweep shows
+# which term misses it: kernel times of the one-GPU run divided by N, the ghost exchange at the per-direction link rate
+# over the N - 1 point-to-point links of a rank, the small reductions at a latency each.
+MODEL_ONE_GPU = {"spmv_ms": 0.481, "gram_schmidt_ms_per_step": 0.864, "compression_ms": 0.965, "host_ms_per_restart": 0.16,
+                 "source": "BENCH_r04.json, one MI355X, random CSR n=10M k=5 m=20"}
+MODEL_LINK_GBS = 50.0          # per direction per xGMI link, as DESIGN 4 assumes
+MODEL_ALLREDUCE_US = 25.0      # one <= 656-byte all-reduce over 8 GPUs
+
+
+def predicted_restarts_per_s(world, m, p, ghost_bytes_per_spmv, collectives_per_step):
+    """restarts/s of the headline workload on ``world`` GPUs by DESIGN section 4's model (see MODEL_* above)."""
+    steps = m - p
+    exch_ms = ghost_bytes_per_spmv / (MODEL_LINK_GBS * 1e9 * max(world - 1, 1)) * 1e3 if world > 1 else 0.0
+    reductions = max(int(collectives_per_step) - 1, 0) if world > 1 else 0
+    step_ms = exch_ms + (MODEL_ONE_GPU["spmv_ms"] + MODEL_ONE_GPU["gram_schmidt_ms_per_step"]) / world \
+        + reductions * MODEL_ALLREDUCE_US * 1e-3
+    restart_ms = steps * step_ms + MODEL_ONE_GPU["compression_ms"] / world + MODEL_ONE_GPU["host_ms_per_restart"]
+    return 1e3 / restart_ms, {"exchange_ms_per_spmv": round(exch_ms, 4), "kernels_ms_per_step": round(step_ms - exch_ms, 4),
+                              "reductions_per_step": reductions, "restart_ms": round(restart_ms, 3),
+                              "link_GBs_per_direction": MODEL_LINK_GBS, "allreduce_us": MODEL_ALLREDUCE_US,
+                              "one_gpu": MODEL_ONE_GPU}
 
 
 def spmv_kernel_name(res, world):
@@ -746,6 +781,18 @@ def emit(line):
 _REAL_STDOUT = 1
 
 
+def model_fields(res, args, world):
+    """``predicted_restarts_per_s`` next to the measured ``value`` (N > 1, headline workload at its BASELINE size only:
+    the model's one-GPU terms are that workload's)."""
+    ex = res.get("exchange")
+    if world <= 1 or not ex or args.workload != "random" or args.matrix is not None or res["n"] != 10_000_000 \
+            or (res["nev"], res["m"]) != (5, 20) or args.arithmetic != "complex":
+        return {}
+    rate, parts = predicted_restarts_per_s(world, res["m"], res["p"], ex["ghost_bytes_received_per_spmv_rank0"],
+                                           ex["collectives_per_arnoldi_step"])
+    return {"predicted_restarts_per_s": round(rate, 2), "prediction_model": parts}
+
+
 def headline(res, args, world, comm_forced=False, preflight=None):
     """The JSON object of the headline measurement (what rank 0 prints), from ``measure``'s result."""
     n, m, p, nev = res["n"], res["m"], res["p"], res["nev"]
@@ -781,6 +828,7 @@ def headline(res, args, world, comm_forced=False, preflight=None):
         "initial_expand_ms": round(res["initial_ms"], 2),
         "setup_s": round(res["setup_s"], 2),
         "arnoldi_steps_timed": res["steps_done"],
+        **model_fields(res, args, world),
         "roofline": {
             "kernel": spmv_kernel_name(res, world),
             "spmv_form": res["spmv_form"],

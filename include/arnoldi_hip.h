@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define AKS_ABI_VERSION 4
+#define AKS_ABI_VERSION 5
 
 #define AKS_OK 0
 #define AKS_ERR_ARG (-1)         /* bad argument (null pointer, size, alignment) */
@@ -325,6 +325,13 @@ int aks_comm_create(const void *id, int32_t rank, int32_t size, void **comm_out)
 int aks_comm_destroy(void *comm);
 /* In-place sum over the ranks of `count` doubles on `stream` (the Gram-Schmidt reductions). */
 int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *stream);
+/* Which all-reduce the communicator runs: 0 = ncclAllReduce (the default), 1 = the one-shot mailbox exchange
+ * (AKS_ALLREDUCE=oneshot in the environment of EVERY rank at aks_comm_create: each rank's [h ; ||w||^2] is written
+ * into a row of every peer's fine-grained mailbox, arrival is a counter the stream waits on -- hipStreamWaitValue64, no
+ * spinning kernel --, and every rank sums the rows in rank order: identical bits on all ranks).
+ * aks_comm_create proves the exchange and lets the ranks vote; if any rank cannot, ALL stay with ncclAllReduce and
+ * `why_not` (optional, NUL-terminated, at most why_bytes) says why.  Negative: error. */
+int aks_comm_allreduce_path(void *comm, char *why_not, int64_t why_bytes);
 /* Personalised exchange of BYTES between all ranks on `stream`, one group of sends / receives: rank r receives
  * send_bytes[r] bytes starting at d_send + send_offsets[r] of every peer into d_recv + recv_offsets[peer]
  * (recv_bytes[peer] must equal what that peer sends here; this rank's own slice is a device copy).  The arrays are
@@ -459,6 +466,9 @@ int aks_scale(int64_t n_rows, aks_c128 *d_w, double alpha_re, double alpha_im, v
 #define AKS_PROBE_EXCHANGE 3
 #define AKS_PROBE_DIAG 4
 #define AKS_PROBE_OFFDIAG 5
+/* every reduction over the ranks between the Gram-Schmidt stages (aks_comm_allreduce_sum: ncclAllReduce or the
+ * one-shot exchange), bracketed by recorded events on the compute stream: 2 - 3 pairs per Arnoldi step */
+#define AKS_PROBE_ALLREDUCE 6
 int aks_probe_create(int32_t capacity, void **probe_out);
 int aks_probe_destroy(void *probe);
 int aks_probe_reset(void *probe);

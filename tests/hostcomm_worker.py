@@ -92,6 +92,12 @@ def main():
         from dist_cases import run_cases
 
         verdict = run_cases(comm, comm.rank, comm.size)
+        import ctypes
+
+        from arnoldi_amd import _hip
+
+        why = ctypes.create_string_buffer(256)
+        verdict["allreduce_path"] = [int(_hip.load().aks_comm_allreduce_path(comm.native(), why, 256)), why.value.decode()]
     verdict["torch_imported"] = "torch" in sys.modules
     with open(os.path.join(args.out, f"rank{comm.rank}.json"), "w") as f:
         json.dump(verdict, f)

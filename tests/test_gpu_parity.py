@@ -999,6 +999,28 @@ def test_row_sharded_torch_free_process_ranks(amd, tmp_path, ranks):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     verdicts = run_hostcomm_worker(tmp_path, ranks, "solve")
     assert not any(v.pop("torch_imported") for v in verdicts)
+    assert all(v.pop("allreduce_path") == [0, ""] for v in verdicts)                 # the library collective (default)
+    check_dist_verdicts(verdicts, native=True)
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_one_shot_allreduce_across_process_ranks(amd, tmp_path, ranks):
+    """``AKS_ALLREDUCE=oneshot`` between PROCESSES (mailboxes mapped with hipIpc*, arrival counters waited on by the
+    stream): the same cases, the same verdicts, and every rank reports that the one-shot path is the one that ran."""
+    import subprocess
+
+    from test_host_logic import ROOT, check_dist_verdicts, run_hostcomm_worker
+
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    os.environ["AKS_ALLREDUCE"] = "oneshot"
+    try:
+        verdicts = run_hostcomm_worker(tmp_path, ranks, "solve")
+    finally:
+        del os.environ["AKS_ALLREDUCE"]
+    assert not any(v.pop("torch_imported") for v in verdicts)
+    paths = [v.pop("allreduce_path") for v in verdicts]
+    assert all(p_ == [1, ""] for p_ in paths), paths
     check_dist_verdicts(verdicts, native=True)
 
 

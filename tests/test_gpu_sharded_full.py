@@ -22,13 +22,14 @@ from conftest import ROOT
 MOCK_LIB = os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so")
 
 
-def _worker(tmp_path, case, extra=(), timeout=840):
+def _worker(tmp_path, case, extra=(), timeout=840, env_extra=None):
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = os.path.join(tmp_path, f"{case}.json")
     env = dict(os.environ, AKS_LIB_PATH=MOCK_LIB, AKS_GRAPH="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AKS_SPMV_FORM"):
         env.pop(k, None)
+    env.update(env_extra or {})
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "thread_ranks_worker.py"), "--case", case, "--out", out,
                           *extra], capture_output=True, text=True, timeout=timeout, env=env)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-4000:]
@@ -107,6 +108,12 @@ def test_bench_eight_ranks_full_size_line(tmp_path):
     split = ex["spmv_device_ms_rank0"]
     assert all(split[k] is not None and split[k] > 0 for k in ("pack", "exchange", "diag_block", "ghost_wait_plus_offdiag_block"))
     assert out["data"].startswith("rehearsal")
+    # what makes the first hardware run cheap to read: the reductions' device time per step on rank 0
+    # (an event pair around each aks_comm_allreduce_sum) and the model's prediction next to the measured value
+    assert ex["allreduce_device_ms_per_step_rank0"] > 0 and ex["allreduce_calls_per_step_probed"] in (2.0, 3.0), ex
+    assert ex["allreduce_path"].startswith("ncclAllReduce"), ex
+    assert 150 < out["predicted_restarts_per_s"] < 300 and out["prediction_model"]["reductions_per_step"] == 2, out.get("prediction_model")
+    assert abs(out["prediction_model"]["exchange_ms_per_spmv"] - ex["ghost_bytes_received_per_spmv_rank0"] / (50e9 * 7) * 1e3) < 1e-3
     assert out["roofline"]["launches"] == 3 * 9 and out["roofline_ortho"]["launch_groups"] == 3 * 10     # (a restart's first product is the look-ahead one)
     # ... and the sharded legs of N > 1 at THEIR full sizes: Markov n = 10M (ghosts: a few grid lines), the 3-D Laplacian of
     # config 4 in z-slabs (one 252 x 253 plane per neighbour), the headline matrix real-packed (8 instead of 16 bytes per entry)
@@ -153,6 +160,28 @@ def test_full_size_drivers_are_bitwise_repeatable(tmp_path, name, args, forms, d
     assert len(set(r["sha"])) == 1, (r["sha"], r["report"])
     assert all(x["first_differing_snapshot"] is None and x["snapshots"] >= 8 for x in r["report"]), r["report"]
     print(name, r["n"], r["forms"], r["info"][-1], r["sha"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,args", [(2, []), (3, []), (4, ["--workload", "laplace3d", "--rows", "16000000"])])
+def test_one_shot_allreduce_gives_the_collectives_bits(tmp_path, ranks, args):
+    """``AKS_ALLREDUCE=oneshot``: every rank writes its [h ; ||w||^2] into a row of
+    every peer's mailbox, waits for the arrivals with a stream memory operation and sums the rows in rank order.  Full-size
+    sharded solves (config 5 at 2 and 3 ranks, config 4 at 4: every step with the third reduction) must give H -- after
+    every expansion and contraction -- bit for bit what the library collective (here: its order-checking stand-in, which
+    also sums in rank order) gives, and must say that the one-shot path is the one that ran.
+
+    Thread ranks live in ONE process, and a stream that waits for a peer's post must not share a hardware queue with the
+    stream that posts (the wait would block the queue in front of the post: observed as a hang from the second solve of
+    a process on, profiles/r05_small_trace.txt).  Rank PROCESSES -- the product's mode -- cannot collide
+    (tests/test_gpu_parity.py::test_one_shot_allreduce_across_process_ranks); here each run is a fresh process with one
+    solve and GPU_MAX_HW_QUEUES raised above its stream count, and the 8-rank case (16 streams) is run by hand only."""
+    base = _worker(tmp_path, "repro", ["--ranks", str(ranks), "--repeats", "1"] + args, timeout=300)
+    one = _worker(tmp_path, "repro", ["--ranks", str(ranks), "--repeats", "1"] + args, timeout=300,
+                  env_extra={"AKS_ALLREDUCE": "oneshot", "GPU_MAX_HW_QUEUES": "32"})
+    assert base["allreduce_path"] == [0, ""] and one["allreduce_path"] == [1, ""], (base["allreduce_path"], one["allreduce_path"])
+    assert one["info"] == base["info"] and one["sha"] == base["sha"], (base["sha"], one["sha"])
+    print(f"one-shot x{ranks}:", one["n"], one["forms"], one["info"][-1], one["sha"])
 
 
 @pytest.mark.gpu

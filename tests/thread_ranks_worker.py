@@ -298,7 +298,13 @@ def case_repro(ranks, n, repeats=3, workload="random", real=False, sweep=False):
                 Hs.append(s.H.copy())
                 c = s.ctx.last_ctrl
                 info.append((int(c.second_passes), int(c.steps_done), s.ctx.lazy_redos, s.ctx.deferred_expansions))
-            return Hs, info, [op.spmv_form, getattr(op.off, "form", None)]
+            import ctypes
+
+            from arnoldi_amd import _hip
+
+            why = ctypes.create_string_buffer(256)
+            path = _hip.load().aks_comm_allreduce_path(comm.native(), why, 256) if (comm.size > 1 and comm.native() is not None) else -1
+            return Hs, info, [op.spmv_form, getattr(op.off, "form", None)], (int(path), why.value.decode())
 
         out = run_ranks(ranks, rank_fn)
         runs.append(out[0])
@@ -320,7 +326,7 @@ def case_repro(ranks, n, repeats=3, workload="random", real=False, sweep=False):
             cols = [float(np.abs(a[:, j] - b[:, j]).max() / max(np.abs(a[:, j]).max(), 1e-300)) for j in range(a.shape[1])]
         report.append({"run": rep, "first_differing_snapshot": first, "max_rel_diff": worst, "snapshots": len(base),
                        "spectrum_rel_diff_per_snapshot": spec, "column_rel_diff_in_first_bad_snapshot": cols})
-    return {"ranks": ranks, "n": n, "forms": runs[0][2], "info": runs[0][1], "report": report,
+    return {"ranks": ranks, "n": n, "forms": runs[0][2], "info": runs[0][1], "report": report, "allreduce_path": runs[0][3],
             "sha": [hashlib.sha256(np.ascontiguousarray(r[0][-1]).tobytes()).hexdigest()[:12] for r in runs]}
 
 
