@@ -324,8 +324,7 @@ def measure(args, comm, world, rank):
 
 def _measure(args, comm, world, rank):
     """Build the operator for args.workload, run warmup + steps restarts, return (dict, context for extras)."""
-    import torch
-    from arnoldi_amd import _hip
+    from arnoldi_amd import _hip, mem                      # (mem: torch's or the HIP runtime's synchronize, by backend)
     from arnoldi_amd.dist import row_offsets, slab_offsets
     from arnoldi_amd.engine import CsrOperator
     from arnoldi_amd.krylov_schur import KrylovSchurSolver
@@ -379,7 +378,7 @@ def _measure(args, comm, world, rank):
 
     def sync():
         if GPU:
-            torch.cuda.synchronize()
+            mem.synchronize()
         if comm is not None:
             comm.barrier()
 
@@ -387,7 +386,7 @@ def _measure(args, comm, world, rank):
     t0 = time.perf_counter()
     assert solver.start() == m
     if GPU:
-        torch.cuda.synchronize()
+        mem.synchronize()
     initial_ms = (time.perf_counter() - t0) * 1e3
     deferred_initial = ctx.deferred_expansions > 0          # did the m-step expansion leave its columns raw?
 
@@ -467,12 +466,12 @@ def _measure(args, comm, world, rank):
         for i in range(2):
             solver.contract(args.warmup + args.steps + i)
             solver.expand()
-        torch.cuda.synchronize()
+        mem.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
             solver.contract(args.warmup + args.steps + 2 + i)
             solver.expand()
-        torch.cuda.synchronize()
+        mem.synchronize()
         graph_rate = args.steps / (time.perf_counter() - t0)
         ctx.use_graph = was_graph
 
@@ -876,8 +875,6 @@ def sharded_legs(args, comm, world, rank, log=None):
     import copy
     import gc
 
-    import torch
-
     legs = []
     small = args.leg_rows
     specs = (("markov", dict(workload="markov", n=small or 10_000_000, nev=5, max_dim=20, arithmetic="complex")),
@@ -890,8 +887,8 @@ def sharded_legs(args, comm, world, rank, log=None):
             setattr(a, k, v)
         a.steps, a.warmup = min(args.steps, 5), 2
         gc.collect()
-        if GPU:
-            torch.cuda.empty_cache()
+        if GPU and "torch" in sys.modules:                # (the torch-free ranks free their HIP allocations with the objects)
+            sys.modules["torch"].cuda.empty_cache()
         t0 = time.perf_counter()
         res = measure(a, comm, world, rank)
         leg = leg_summary(res, a, world)
@@ -905,11 +902,52 @@ def sharded_legs(args, comm, world, rank, log=None):
     return legs
 
 
+def run_rank_torch_free(args):
+    """``AKS_COMM=host``: the ranks of ``--gpus N`` without torch in the process -- ``dist.HostComm`` (TCP rendezvous + the
+    library's own communicator) and the HIP runtime's allocator; rank r takes GPU ``LOCAL_RANK`` (modulo the GPUs that
+    exist: a one-GPU rehearsal shares it).  The same ``measure`` / ``headline`` / sharded legs as the torch ranks; no
+    preflight (that compares the C-driven path with the torch.distributed one) and no child-process legs."""
+    global GPU
+    os.environ.setdefault("AKS_HOST_ALLOC", "hip")
+    from arnoldi_amd import mem
+    from arnoldi_amd.dist import HostComm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    GPU = mem.gpu_available()
+    if GPU and mem.BACKEND == "hip":
+        import ctypes
+
+        count = ctypes.c_int(0)
+        mem._rt().hipGetDeviceCount(ctypes.byref(count))
+        mem._ck(mem._rt().hipSetDevice(int(os.environ.get("LOCAL_RANK", "0")) % max(count.value, 1)), "hipSetDevice")
+    comm = HostComm() if world > 1 else None
+    res = measure(args, comm, world, rank)
+    out = headline(res, args, world, False, None) if rank == 0 else None
+    if rank == 0:
+        out["config"]["rank_layer"] = "dist.HostComm (TCP rendezvous + aks_comm_alltoallv), AKS_HOST_ALLOC=" + mem.BACKEND
+    if world > 1 and args.workload == "random" and args.arithmetic == "complex" and not args.no_workloads:
+        legs = sharded_legs(args, comm, world, rank)
+        if rank == 0:
+            out["workloads"] = legs
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+    if rank == 0:
+        out["torch_in_process"] = "torch" in sys.modules
+        emit(json.dumps(out))
+    return 0
+
+
 def run_rank(args, argv):
     global _REAL_STDOUT
     sys.stdout.flush()
     _REAL_STDOUT = os.dup(1)
     os.dup2(2, 1)
+    if os.environ.get("AKS_COMM") == "host" and args.leg is None:
+        return run_rank_torch_free(args)
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

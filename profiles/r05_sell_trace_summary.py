@@ -16,7 +16,7 @@ def main(trace_dir, phases_json, label):
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    short = lambda k: k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")      # noqa: E731
+    short = lambda k: k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]      # noqa: E731
     sell = [(i, (e - s) / 1e3) for i, (s, e, k) in enumerate(rows) if "k_sell" in k]
     bytes_ = meta["algorithmic_bytes"]
     print(f"# {label}: {len(rows)} dispatches, {len(sell)} k_sell launches; shell CSR n = {meta['n']}, nnz = {meta['nnz']}, "
@@ -30,7 +30,7 @@ def main(trace_dir, phases_json, label):
         d = [t for _, t in chunk]
         med = statistics.median(d)
         print(f"{label:8s} {name:14s} n={len(d):3d}  median {med:7.2f} us  mean {statistics.mean(d):7.2f}  min {min(d):7.2f}  max {max(d):7.2f}"
-              f"   = {bytes_ / med / 1e6 / 8000:.3f} of 8 TB/s")
+              f"   = {bytes_ / (med * 1e-6) / 8e12:.3f} of 8 TB/s")
         if name == "in_solve":
             by_prev = {}
             for i, t in chunk:

@@ -1083,6 +1083,38 @@ def test_bench_multi_rank_line_on_the_c_driven_path(amd):
     assert legs["laplace3d"]["exchange"]["ghost_bytes_received_per_spmv_rank0"] == 16 * nx * (nx + 1)
 
 
+def test_bench_multi_rank_line_without_torch(amd):
+    """``AKS_COMM=host python bench.py --gpus 2``: the ranks bootstrap over ``dist.HostComm``, allocate
+    through the HIP runtime and never import torch; same line -- C-driven path, exchange block, sharded legs."""
+    import json
+    import subprocess
+    import sys
+
+    from test_host_logic import ROOT
+
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    env = dict(os.environ, AKS_LIB_PATH=os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"), AKS_COMM="host",
+               AKS_GRAPH="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AKS_HOST_ALLOC"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "400000", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline", "--leg-rows", "300000"], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["torch_in_process"] is False and out["config"]["rank_layer"].startswith("dist.HostComm")
+    assert out["n_gpus"] == 2 and "issued from C" in out["config"]["path"] and out["value"] > 0
+    ex = out["config"]["exchange"]
+    assert ex["ghost_bytes_received_per_spmv_rank0"] > 0 and ex["collectives_per_arnoldi_step"] == 3
+    assert ex["allreduce_path"].startswith("ncclAllReduce") and ex["allreduce_device_ms_per_step_rank0"] > 0
+    legs = {leg["name"]: leg for leg in out["workloads"]}
+    assert set(legs) == {"markov", "laplace3d", "random_real_packed"}
+    assert all("error" not in leg and leg["restarts_per_s"] > 0 and leg["path"].startswith("C-driven") for leg in legs.values())
+
+
 def test_rccl_collectives_one_rank(amd, tmp_path):
     """The collectives of the multi-rank path issued through RCCL (torch 'nccl') on a one-rank
     group, real kernels: workspace-slot all-reduces, uneven all-to-all incl. empty messages, the
