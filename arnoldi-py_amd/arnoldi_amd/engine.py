@@ -418,11 +418,13 @@ class ArnoldiContext:
         # relative to the kernels).  Not used while a probe records per-kernel events.  With a communicator the
         # sequence contains RCCL calls.  The stage all-reduces can be captured with it (AKS_GRAPH_COMM=1, opt-in:
         # checked on a one-rank communicator only -- tests/nccl_single_worker.py -- where replay is bit-identical
-        # to eager); a ghost exchange is never captured: in round 3 a capture that contained the grouped ncclSend /
-        # ncclRecv forked onto the communicator's side stream (a send + recv to self on a one-rank communicator) ended in
-        # a SIGSEGV whose cause cannot be decided without RCCL's sources, so sequences with an exchange
-        # stay eager (pinned by test_sequences_with_a_ghost_exchange_are_never_captured).  At the shard sizes of the BASELINE configs on 8 GPUs (1.25M - 2M rows) a kernel
-        # lasts 20-60 us against ~4 us to launch it, so the eager sequence is not host-bound there.
+        # to eager); a ghost exchange is never captured: a grouped ncclSend / ncclRecv captured on a stream that JOINED the
+        # capture through an event (the communicator's side stream) sends the HIP runtime's end-of-capture walk into an
+        # unbounded recursion -- 174 573 nested frames of hip::Stream::EndCapture(), a stack overflow, with HIP 7.0.51831 +
+        # RCCL 2.26.6 (profiles/r05_capture_crash.txt: backtrace, and the variants that do capture: the same group on the
+        # capturing stream, an all-reduce or a kernel on the forked stream).  So sequences with an exchange stay eager
+        # (pinned by test_sequences_with_a_ghost_exchange_are_never_captured).  At the shard sizes of the BASELINE configs on
+        # 8 GPUs (1.25M - 2M rows) a kernel lasts 20-60 us against ~4 us to launch it: the eager sequence is not host-bound.
         key = (start, end, float(tol), float(eta), w_ready, lazy, defer)
         graph_ok = not op.native_comm or (os.environ.get("AKS_GRAPH_COMM", "0") == "1" and not op.any_exchange)
         if self.use_graph and self.probe is None and start > 0 and graph_ok and b.V.is_cuda:

@@ -108,10 +108,13 @@ def launch_ranks(args, argv):
     rank 0's JSON line.  This parent never touches the GPU.  A failed rank => the others are stopped
     (by PID) and the exit status is non-zero."""
     port = free_port()
+    rendezvous = {}
+    if os.environ.get("AKS_COMM") == "host" and "AKS_RENDEZVOUS" not in os.environ:
+        rendezvous["AKS_RENDEZVOUS"] = f"127.0.0.1:{free_port()}"      # the torch-free ranks' own port (dist.HostComm)
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **rendezvous)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))

@@ -25,11 +25,15 @@ def main(variant):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     rccl = C.CDLL("librccl.so")
-    uid = (C.c_char * 128)()
+    class UniqueId(C.Structure):                      # ncclUniqueId: 128 bytes, passed BY VALUE to ncclCommInitRank
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
     comm = C.c_void_p()
-    assert rccl.ncclGetUniqueId(uid) == 0
-    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char * 128, C.c_int]
-    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rc = rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0)
+    assert rc == 0, rc
     for f in (rccl.ncclSend, rccl.ncclRecv):
         f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     rccl.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

@@ -997,7 +997,7 @@ def test_row_sharded_torch_free_process_ranks(amd, tmp_path, ranks):
 
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    verdicts = run_hostcomm_worker(tmp_path, ranks, "solve")
+    verdicts = run_hostcomm_worker(tmp_path, ranks, "solve", timeout=300)
     assert not any(v.pop("torch_imported") for v in verdicts)
     assert all(v.pop("allreduce_path") == [0, ""] for v in verdicts)                 # the library collective (default)
     check_dist_verdicts(verdicts, native=True)
@@ -1015,7 +1015,7 @@ def test_one_shot_allreduce_across_process_ranks(amd, tmp_path, ranks):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     os.environ["AKS_ALLREDUCE"] = "oneshot"
     try:
-        verdicts = run_hostcomm_worker(tmp_path, ranks, "solve")
+        verdicts = run_hostcomm_worker(tmp_path, ranks, "solve", timeout=300)
     finally:
         del os.environ["AKS_ALLREDUCE"]
     assert not any(v.pop("torch_imported") for v in verdicts)

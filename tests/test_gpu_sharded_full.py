@@ -176,8 +176,8 @@ def test_one_shot_allreduce_gives_the_collectives_bits(tmp_path, ranks, args):
     a process on, profiles/r05_small_trace.txt).  Rank PROCESSES -- the product's mode -- cannot collide
     (tests/test_gpu_parity.py::test_one_shot_allreduce_across_process_ranks); here each run is a fresh process with one
     solve and GPU_MAX_HW_QUEUES raised above its stream count, and the 8-rank case (16 streams) is run by hand only."""
-    base = _worker(tmp_path, "repro", ["--ranks", str(ranks), "--repeats", "1"] + args, timeout=300)
-    one = _worker(tmp_path, "repro", ["--ranks", str(ranks), "--repeats", "1"] + args, timeout=300,
+    base = _worker(tmp_path, "repro", ["--ranks", str(ranks), "--repeats", "1"] + args, timeout=240)
+    one = _worker(tmp_path, "repro", ["--ranks", str(ranks), "--repeats", "1"] + args, timeout=240,     # (a hang must fail HERE, fast)
                   env_extra={"AKS_ALLREDUCE": "oneshot", "GPU_MAX_HW_QUEUES": "32"})
     assert base["allreduce_path"] == [0, ""] and one["allreduce_path"] == [1, ""], (base["allreduce_path"], one["allreduce_path"])
     assert one["info"] == base["info"] and one["sha"] == base["sha"], (base["sha"], one["sha"])
