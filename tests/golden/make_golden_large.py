@@ -83,9 +83,44 @@ def augment():
         print(os.path.basename(path), draws_sha[:16], repr(norm))
 
 
+STRESS_GRID = [(3, 20, 10), (6, 20, 12), (10, 20, 16), (12, 30, 21), (20, 40, 30), (30, 50, 40), (50, 80, 65),
+               (50, 100, 75), (75, 100, 85)]                      # scripts/stress-test.py:29-41, x {LM, LR}, TOL = 1e-8
+GRID_N, GRID_PER_ROW, GRID_PLANTED = 300_000, 11, tuple(120.0 - 1.0 * i for i in range(100))
+
+
+def stress_grid():
+    """The reference's stress grid (nev, ncv, p) x {LM, LR} at n = 300 000 -- panels up to 100 columns wide, restart sizes up
+    to 85 -- on a banded matrix with 100 planted dominant eigenvalues (all positive: the two sort keys then pick the same
+    pairs through different code).  One fixture, a record per case: restarts, History, diag(T), max residual, wall time."""
+    from arnoldi.utils import arg_largest_real
+
+    A = matrices.banded_csr(GRID_N, GRID_PER_ROW, 1234, planted=GRID_PLANTED)
+    Ac = A.astype(np.complex128)
+    out = dict(n=np.int64(GRID_N), per_row=np.int64(GRID_PER_ROW), planted=np.array(GRID_PLANTED), nnz=np.int64(A.nnz),
+               tol=np.float64(1e-8))
+    for which, sort in (("LM", arg_largest_magnitude), ("LR", arg_largest_real)):
+        for nev, ncv, p in STRESS_GRID:
+            key = f"{which}_{nev}_{ncv}_{p}"
+            np.random.seed(nev + ncv)
+            t0 = time.time()
+            Q, T, hist = partial_schur(Ac, nev, max_dim=ncv, p=p, stopping_criterion=1e-8, max_restarts=100_000, sort_function=sort)
+            wall = time.time() - t0
+            T = np.array(T)
+            vals, S = np.linalg.eig(T)
+            vecs = np.array(Q) @ S
+            rel = np.linalg.norm(Ac @ vecs - vecs * vals, axis=0) / np.abs(vals)
+            out.update({f"{key}_restarts": np.int64(hist.restarts.max()), f"{key}_hist_matvecs": hist.matvecs,
+                        f"{key}_hist_restarts": hist.restarts, f"{key}_diagT": np.diag(T).copy(),
+                        f"{key}_rel_max": np.float64(rel.max()), f"{key}_wall_s": np.float64(wall)})
+            print(f"{key}: restarts={int(hist.restarts.max())} wall={wall:.1f}s max_rel={rel.max():.3e}", flush=True)
+            np.savez_compressed(os.path.join(HERE, "g12_stress_grid_300k.npz"), **out)
+
+
 def main():
     if sys.argv[1] == "augment":
         return augment()
+    if sys.argv[1] == "grid":
+        return stress_grid()
     name = sys.argv[1]
     build, kw, seed = CASES[name]
     kw = dict(kw)

@@ -162,3 +162,58 @@ def test_start_vector_of_the_c5_fixture_on_the_cpu():
     v0 = rand_normalized_vector(int(g["n"]), C128)
     assert _sha(v0) == str(g["v0_sha256"])
     np.testing.assert_array_equal(v0[:4], g["v0_head"])
+
+
+# ---------------------------------------------------------------------------- the reference's stress grid, run BY the reference
+STRESS_GRID = [(3, 20, 10), (6, 20, 12), (10, 20, 16), (12, 30, 21), (20, 40, 30), (30, 50, 40), (50, 80, 65),
+               (50, 100, 75), (75, 100, 85)]                      # scripts/stress-test.py:29-41
+_grid_matrix = {}
+
+
+def _grid_fixture():
+    path = os.path.join(GOLDEN, "g12_stress_grid_300k.npz")
+    if not os.path.exists(path):
+        pytest.skip("g12_stress_grid_300k.npz has not been generated (tests/golden/make_golden_large.py grid)")
+    return np.load(path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["LM", "LR"])
+@pytest.mark.parametrize("nev,ncv,p", STRESS_GRID)
+def test_stress_grid_matches_the_reference_run(nev, ncv, p, which):
+    """Every (nev, ncv, p) x {LM, LR} of the reference's stress test (TOL = 1e-8) at n = 300 000 against what the REFERENCE
+    itself produced on the same matrix and seed (tests/golden/make_golden_large.py grid): panels up to 100 columns and
+    restart sizes up to 85 -- the grouped projections, the column-split fused update and the widest compression buckets --
+    with the same restart count, History, diag(T) and residual bar as the fixtures above."""
+    import arnoldi_amd
+    from arnoldi_amd import matrices
+    from arnoldi_amd.utils import arg_largest_magnitude, arg_largest_real
+
+    g = _grid_fixture()
+    if "A" not in _grid_matrix:
+        _grid_matrix["A"] = matrices.banded_csr(int(g["n"]), int(g["per_row"]), 1234, planted=tuple(g["planted"]))
+    A = _grid_matrix["A"]
+    assert A.nnz == int(g["nnz"])
+    key = f"{which}_{nev}_{ncv}_{p}"
+    np.random.seed(nev + ncv)
+    st = {}
+    Q, T, hist = arnoldi_amd.partial_schur(A, nev, max_dim=ncv, p=p, stopping_criterion=float(g["tol"]), max_restarts=100_000,
+                                           sort_function=arg_largest_magnitude if which == "LM" else arg_largest_real, stats=st)
+    assert st["restarts"] == int(g[f"{key}_restarts"]), (st["restarts"], int(g[f"{key}_restarts"]))
+    np.testing.assert_array_equal(hist.restarts, g[f"{key}_hist_restarts"])
+    np.testing.assert_array_equal(hist.matvecs, g[f"{key}_hist_matvecs"])
+    np.testing.assert_allclose(np.diag(T), g[f"{key}_diagT"], rtol=1e-9, atol=1e-12)
+    _, _, drel = st["solver"].true_residuals()
+    assert drel.max() <= max(1.05 * float(g[f"{key}_rel_max"]), 1e-13), (drel.max(), float(g[f"{key}_rel_max"]))
+    np.testing.assert_allclose(Q.conj().T @ Q, np.eye(nev), atol=1e-11)
+
+
+def test_stress_grid_fixture_is_complete():
+    """(CPU) all 18 cases are in the fixture and every one converged below 5 tol (scripts/benchmark-partial-schur.py:97-100)."""
+    g = _grid_fixture()
+    for which in ("LM", "LR"):
+        for nev, ncv, p in STRESS_GRID:
+            key = f"{which}_{nev}_{ncv}_{p}"
+            assert int(g[f"{key}_restarts"]) >= 1 and g[f"{key}_diagT"].shape == (nev,)
+            assert float(g[f"{key}_rel_max"]) < 5 * float(g["tol"])
+            assert np.all(g[f"{key}_hist_restarts"] == int(g[f"{key}_restarts"]))
