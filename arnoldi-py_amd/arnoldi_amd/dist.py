@@ -696,5 +696,9 @@ def host_comm_from_env():
     """One ``HostComm`` per process for the ranks an environment describes (RANK / WORLD_SIZE / MASTER_*)."""
     global _host_comm
     if _host_comm is None:
+        from . import mem
+
+        if mem.gpu_available() and "LOCAL_RANK" in os.environ:      # one process per GPU: rank r of a node drives GPU LOCAL_RANK
+            mem.set_device(int(os.environ["LOCAL_RANK"]) % max(mem.device_count(), 1))
         _host_comm = HostComm()
     return _host_comm

@@ -50,6 +50,12 @@ if BACKEND == "torch":
     def current_device():
         return torch.cuda.current_device()
 
+    def device_count():
+        return torch.cuda.device_count()
+
+    def set_device(index):
+        torch.cuda.set_device(int(index))
+
     def as_device(device):
         return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
@@ -142,6 +148,14 @@ else:
         d = C.c_int(0)
         _ck(_rt().hipGetDevice(C.byref(d)), "hipGetDevice")
         return d.value
+
+    def device_count():
+        n = C.c_int(0)
+        _ck(_rt().hipGetDeviceCount(C.byref(n)), "hipGetDeviceCount")
+        return n.value
+
+    def set_device(index):
+        _ck(_rt().hipSetDevice(int(index)), "hipSetDevice")
 
     def as_device(device):
         if device is None:

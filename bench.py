@@ -91,7 +91,7 @@ def parse_args(argv=None):
     ap.add_argument("--probe-every", type=int, default=1,
                     help="record the HIP-event pairs around the SpMV / Gram-Schmidt launches in every K-th restart of "
                          "the timed region (1 = every restart)")
-    ap.add_argument("--leg", choices=["measure", "cpu", "preflight"], default=None,
+    ap.add_argument("--leg", choices=["measure", "cpu", "preflight", "allreduce_probe"], default=None,
                     help="(internal) run one extra leg and print its JSON object")
     return ap.parse_args(argv)
 
@@ -725,6 +725,77 @@ def preflight_child(args):
     return 0
 
 
+def allreduce_probe_child(args):
+    """``--leg allreduce_probe`` (one process per rank, started by ``native_preflight`` AFTER the path check, with its own
+    time-out): what the small reductions between the Gram-Schmidt stages cost on THIS machine through each of the two
+    implementations -- ``ncclAllReduce`` and the one-shot mailbox exchange (AKS_ALLREDUCE=oneshot) -- 42 doubles, a batch of
+    200 back-to-back calls between two events, every rank.  On a multi-GPU node this is the number round 5 could not
+    measure; a failure, a hang or a crash here costs the probe, nothing else."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    from arnoldi_amd import _hip
+    from arnoldi_amd.dist import Comm
+
+    world, rank, local_rank = (int(os.environ[k]) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    lib, out = _hip.load(), {"world": world}
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for name, env in (("nccl", None), ("oneshot", "oneshot")):
+        if env is None:
+            os.environ.pop("AKS_ALLREDUCE", None)
+        else:
+            os.environ["AKS_ALLREDUCE"] = env
+        comm = Comm(force=(world == 1))
+        handle = comm.native()
+        why = C.create_string_buffer(256)
+        path = lib.aks_comm_allreduce_path(handle, why, 256)
+        buf = torch.full((42,), float(rank + 1), dtype=torch.float64, device="cuda")
+        _hip.check(lib.aks_comm_allreduce_sum(handle, C.c_void_p(buf.data_ptr()), 42, stream), "allreduce")
+        torch.cuda.synchronize()
+        ok = bool(abs(float(buf[0].item()) - world * (world + 1) / 2) < 1e-9)
+        best = None
+        for _ in range(3):
+            buf.fill_(1e-300)                                    # (200 sums of N equal terms stay finite)
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                lib.aks_comm_allreduce_sum(handle, C.c_void_p(buf.data_ptr()), 42, stream)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 200
+            best = us if best is None else min(best, us)
+        out[name] = {"path": "one-shot mailbox exchange" if path == 1 else "ncclAllReduce", "why_not_oneshot": why.value.decode() or None,
+                     "sum_ok": ok, "device_us_per_call": round(best, 2)}
+        comm.close()
+    t = torch.tensor([out["nccl"]["device_us_per_call"], out["oneshot"]["device_us_per_call"]], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out["slowest_rank_us_per_call"] = {"nccl": round(float(t[0]), 2), "oneshot": round(float(t[1]), 2)}
+    dist.barrier()
+    dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def run_probe_child(leg, env, timeout_s):
+    """One child process of this rank; its last JSON line, or {"error": ...}."""
+    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--leg", leg], env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        so, se = proc.communicate(timeout=timeout_s)
+        for ln in reversed(so.splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": f"exit status {proc.returncode}: " + " | ".join((se or so).strip().splitlines()[-3:])}
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return {"error": f"timed out after {timeout_s} s"}
+
+
 def native_preflight(world, rank, local_rank, timeout_s=300):
     """The C-driven RCCL path has only ever met one GPU per developer box; the first time several GPUs see it is the
     driver's scaling run.  So before THIS process touches its GPU, every rank starts a child (``--leg preflight``,
@@ -765,6 +836,13 @@ def native_preflight(world, rank, local_rank, timeout_s=300):
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     verdict["all_ranks_ok"] = bool(flag.item())
     verdict["seconds"] = round(time.perf_counter() - t0, 1)
+    if verdict["all_ranks_ok"] and os.environ.get("AKS_BENCH_ALLREDUCE_PROBE", "1") != "0":
+        # the two all-reduce implementations, timed side by side in children of their own (they cannot hurt this process)
+        port = [free_port() if rank == 0 else None]
+        dist.broadcast_object_list(port, src=0)
+        probe = run_probe_child("allreduce_probe", dict(env, MASTER_PORT=str(port[0])), 120)
+        if rank == 0:
+            verdict["allreduce_probe"] = probe
     dist.barrier()
     dist.destroy_process_group()
     if not verdict["all_ranks_ok"]:
@@ -920,12 +998,8 @@ def run_rank_torch_free(args):
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     GPU = mem.gpu_available()
-    if GPU and mem.BACKEND == "hip":
-        import ctypes
-
-        count = ctypes.c_int(0)
-        mem._rt().hipGetDeviceCount(ctypes.byref(count))
-        mem._ck(mem._rt().hipSetDevice(int(os.environ.get("LOCAL_RANK", "0")) % max(count.value, 1)), "hipSetDevice")
+    if GPU:
+        mem.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(mem.device_count(), 1))
     comm = HostComm() if world > 1 else None
     res = measure(args, comm, world, rank)
     out = headline(res, args, world, False, None) if rank == 0 else None
@@ -1072,6 +1146,8 @@ def main():
         return 0
     if args.leg == "preflight":
         return preflight_child(args)
+    if args.leg == "allreduce_probe":
+        return allreduce_probe_child(args)
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, argv)
     return run_rank(args, argv)

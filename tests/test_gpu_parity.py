@@ -1115,6 +1115,34 @@ def test_bench_multi_rank_line_without_torch(amd):
     assert all("error" not in leg and leg["restarts_per_s"] > 0 and leg["path"].startswith("C-driven") for leg in legs.values())
 
 
+def test_bench_preflight_probes_both_allreduce_paths(amd):
+    """``bench.py`` with a communicator (here: a forced one-rank RCCL group, the only kind a one-GPU box can make) runs its
+    preflight children before it touches the GPU: the C-driven path against the chained one, then -- in a child of its own
+    -- the two all-reduce implementations timed side by side (``ncclAllReduce`` / one-shot mailbox exchange).  On the
+    driver's multi-GPU run that block of the line is the measurement round 5 could not make."""
+    import json
+    import subprocess
+    import sys
+
+    from test_host_logic import ROOT
+
+    env = dict(os.environ, AKS_FORCE_COMM="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AKS_LIB_PATH", "AKS_ALLREDUCE", "AKS_DIST_PATH"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "300000", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-real-leg", "--no-workloads"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    pre = out["config"]["native_preflight"]
+    assert pre["all_ranks_ok"] and "issued from C" in out["config"]["path"], pre
+    probe = pre["allreduce_probe"]
+    assert "error" not in probe, probe
+    assert probe["nccl"]["path"] == "ncclAllReduce" and probe["nccl"]["sum_ok"] and probe["nccl"]["device_us_per_call"] > 0
+    assert probe["oneshot"]["path"] == "one-shot mailbox exchange" and probe["oneshot"]["sum_ok"], probe
+    assert probe["oneshot"]["device_us_per_call"] > 0 and set(probe["slowest_rank_us_per_call"]) == {"nccl", "oneshot"}
+    print("all-reduce probe, one rank:", probe["slowest_rank_us_per_call"])
+
+
 def test_rccl_collectives_one_rank(amd, tmp_path):
     """The collectives of the multi-rank path issued through RCCL (torch 'nccl') on a one-rank
     group, real kernels: workspace-slot all-reduces, uneven all-to-all incl. empty messages, the
