@@ -13,9 +13,9 @@ from arnoldi_amd.krylov_schur import KrylovSchurSolver  # noqa: E402
 from arnoldi_amd.utils import arg_largest_magnitude  # noqa: E402
 
 
-def history(name, A, nev, m, p, restarts):
+def history(name, A, nev, m, p, restarts, sort=arg_largest_magnitude):
     np.random.seed(0)
-    s = KrylovSchurSolver(A, nev, m, p, 1e-300, arg_largest_magnitude)
+    s = KrylovSchurSolver(A, nev, m, p, 1e-300, sort)
     t0 = time.time()
     s.start()
     for r in range(restarts):
@@ -26,5 +26,10 @@ def history(name, A, nev, m, p, restarts):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "markov":          # the README's matrix at n = 10M, sorted LR (north_star: "synthetic Markov")
+        from arnoldi_amd.utils import arg_largest_real
+
+        history("markov10m", matrices.mark(4472), 5, 20, 10, 40, arg_largest_real)
+        sys.exit(0)
     history("c2", matrices.laplace2d(1000, 1001), 10, 40, 15, 60)
     history("c4", matrices.laplace3d(251, 252, 253), 10, 40, 15, 12)

@@ -20,7 +20,9 @@ and asserts
   * max ||A v - l v|| / |l|  <=  1.05 x the reference's own (north_star's bar; 1e-13 floor).
 
 c2 / c4 use the loose ``stopping_criterion`` the fixture records (the reference needs hours to days at the default one;
-the iteration is the same until it stops); ``c2full`` is config 2 at the default tolerance, all the way.
+the iteration is the same until it stops); ``c2full`` is config 2 at the default tolerance, all the way; ``c1big`` is
+config 1's matrix -- the README's Markov chain, sorted by real part -- at n = 10M (north_star: "synthetic Markov"), whose
+spectral gap of ~1e-7 only allows an early stop.
 """
 import hashlib
 import os
@@ -46,6 +48,7 @@ def _matrix(name):
         "c2": lambda: matrices.laplace2d(1000, 1001),
         "c2full": lambda: matrices.laplace2d(1000, 1001),
         "c4": lambda: matrices.laplace3d(251, 252, 253),
+        "c1big": lambda: matrices.mark(4472),                   # the README's Markov chain at n = 10M (sorted LR)
     }[name]()
 
 
@@ -56,12 +59,29 @@ def _fixture(name):
     return np.load(path)
 
 
+def _assert_equal_up_to_conjugation(got, want, real_matrix):
+    """diag(T) to 1e-9 -- or, for a REAL matrix, its complex conjugate: the reference's sort keys (-|l|, -Re l) tie on a
+    conjugate pair of Ritz values, the tie is broken by the last bits ``zgees`` leaves in them, and when the cut at p or at
+    nev falls inside a pair the reference keeps one member or the other depending on the host's BLAS kernels -- the whole
+    trajectory then comes out mirrored (same restart count, same residuals).  Observed: the reference's own algorithm
+    returns the conjugate on the MI355X boxes' CPUs of what it returns in the build container
+    (profiles/r05_conjugate_probe.txt); only early-stopped solves on real matrices show it (converged dominant pairs of
+    the BASELINE matrices are real)."""
+    try:
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+    except AssertionError:
+        if not real_matrix:
+            raise
+        np.testing.assert_allclose(got, np.conj(want), rtol=1e-9, atol=1e-12)
+        print("   (diag(T) is the complex conjugate of the fixture's: the mirrored trajectory of a real matrix)")
+
+
 def _sha(v):
     return hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["c5", "c3b", "c3s", "c2", "c4", "c2full"])
+@pytest.mark.parametrize("name", ["c5", "c3b", "c3s", "c2", "c4", "c2full", "c1big"])
 def test_full_size_solve_matches_the_reference_run(name):
     import torch
 
@@ -95,6 +115,10 @@ def test_full_size_solve_matches_the_reference_run(name):
 
     tol_default = float(np.sqrt(np.finfo(np.float64).eps))
     kw = {} if float(g["tol"]) == tol_default else {"stopping_criterion": float(g["tol"])}
+    if "sort" in g.files and str(g["sort"]) == "LR":
+        from arnoldi_amd.utils import arg_largest_real
+
+        kw["sort_function"] = arg_largest_real
     np.random.seed(seed)
     st = {}
     Q, T, hist = arnoldi_amd.partial_schur(A, nev, max_dim=int(g["max_dim"]), max_restarts=int(g["restarts"]) + 50,
@@ -102,7 +126,7 @@ def test_full_size_solve_matches_the_reference_run(name):
     assert st["restarts"] == int(g["restarts"]), (st["restarts"], int(g["restarts"]))
     np.testing.assert_array_equal(hist.restarts, g["hist_restarts"])
     np.testing.assert_array_equal(hist.matvecs, g["hist_matvecs"])
-    np.testing.assert_allclose(np.diag(T), g["diagT"], rtol=1e-9, atol=1e-12)
+    _assert_equal_up_to_conjugation(np.diag(T), g["diagT"], real_matrix=not np.iscomplexobj(A.data))
 
     dvals, _, drel = st["solver"].true_residuals()            # on the device: no n-vector leaves the GPU
     bound = max(1.05 * float(g["rel_residuals"].max()), 1e-13)
@@ -137,7 +161,7 @@ def test_start_vector_bytes_equal_numpy_on_this_box(n):
         np.testing.assert_array_equal(after_got, after_want)
 
 
-@pytest.mark.parametrize("name", ["c5", "c3b", "c3s", "c2", "c4", "c2full"])
+@pytest.mark.parametrize("name", ["c5", "c3b", "c3s", "c2", "c4", "c2full", "c1big"])
 def test_large_fixture_is_self_consistent(name):
     """(CPU) what a fixture must hold for the GPU test to mean something: the reference converged, its History carries the
     last restart for every eigenvalue (krylov_schur.py:94-97), T is upper triangular with the eigenvalues on its diagonal."""
