@@ -1506,6 +1506,7 @@ struct OneShot {
     void *opened[ONESHOT_MAX_RANKS] = {};               // hipIpcOpenMemHandle results to close again
     OneShotPeers peers = {};
     unsigned long long calls = 0;
+    bool mute = false;                                  // fault injection (AKS_ONESHOT_FAULT_RANK=<rank>): this rank's posts are lost
     std::string why_not;                                // set when the set-up was asked for and did not succeed
 };
 constexpr size_t ONESHOT_FLAG_BYTES = 2 * ONESHOT_FLAG_STRIDE * sizeof(unsigned long long);
@@ -2494,6 +2495,33 @@ static int oneshot_vote(Comm *c, double *d_flag, int mine, int *all) {
 
 static int oneshot_reduce(Comm *c, double *d_buf, int count, hipStream_t s);
 
+// The self-test must not hang a process whose peers' posts do not become visible (the one thing only multi-GPU hardware can
+// show): wait for the side stream with a deadline; past it, RELEASE the stream's pending wait by raising this rank's own
+// arrival counters from the host side (a second stream), let the stream drain, and report failure -- the ranks then vote
+// the path down together and the mailboxes are freed.
+constexpr int ONESHOT_SELFTEST_MS = 5000;
+static bool oneshot_drain(Comm *c, int rep) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipStreamQuery(c->side) == hipErrorNotReady) {
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > ONESHOT_SELFTEST_MS) {
+            hipStream_t rescue = nullptr;
+            if (hipStreamCreateWithFlags(&rescue, hipStreamNonBlocking) == hipSuccess) {
+                for (int parity = 0; parity < 2; ++parity)
+                    (void)hipStreamWriteValue64(rescue, c->one.peers.flag[c->rank] + parity * ONESHOT_FLAG_STRIDE, ~0ull >> 1, 0);
+                (void)hipStreamSynchronize(rescue);
+                (void)hipStreamSynchronize(c->side);
+                (void)hipStreamDestroy(rescue);
+            }
+            (void)hipGetLastError();
+            (void)rep;
+            return false;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    (void)hipGetLastError();
+    return true;
+}
+
 static int oneshot_setup(Comm *c) {
     OneShot &o = c->one;
     int ok = 1, dev = 0, can_wait = 0;
@@ -2569,16 +2597,24 @@ static int oneshot_setup(Comm *c) {
     rc = oneshot_vote(c, d_flag, ok, &all);
     if (rc == AKS_OK && all) {                            // prove it: sum of (rank + 1), twice (both parities)
         o.active = true;
+        const char *fault = getenv("AKS_ONESHOT_FAULT_RANK");       // tests: what the peers of a rank whose posts never arrive do
+        o.mute = fault != nullptr && *fault != 0 && atoi(fault) == c->rank;
         double got[2] = {0.0, 0.0};
         for (int rep = 0; rep < 2; ++rep) {           // (BOTH, whatever the first gave: every rank must post the same number of times)
             const double v = c->rank + 1.0;
             e = hipMemcpy(d_flag, &v, sizeof v, hipMemcpyHostToDevice);
             if (e == hipSuccess && oneshot_reduce(c, d_flag, 1, c->side) != AKS_OK) e = hipErrorUnknown;
-            if (e == hipSuccess) e = hipStreamSynchronize(c->side);
+            if (e == hipSuccess && !oneshot_drain(c, rep)) {       // the posts of some peer never arrived: do not hang here
+                ok = 0;
+                o.why_not = "self-test: the arrival counter was not reached within " + std::to_string(ONESHOT_SELFTEST_MS) +
+                            " ms (posts of a peer not visible to this rank's wait)";
+                continue;
+            }
             if (e == hipSuccess) e = hipMemcpy(&got[rep], d_flag, sizeof(double), hipMemcpyDeviceToHost);
             if (e != hipSuccess || got[rep] != c->size * (c->size + 1) / 2.0) {
                 ok = 0;
-                o.why_not = e != hipSuccess ? std::string("self-test: ") + g_err : "self-test gave " + std::to_string(got[rep]);
+                if (o.why_not.empty())                       // (the first reason stands)
+                    o.why_not = e != hipSuccess ? std::string("self-test: ") + g_err : "self-test gave " + std::to_string(got[rep]);
                 (void)hipGetLastError();
             }
         }
@@ -2596,7 +2632,7 @@ static int oneshot_reduce(Comm *c, double *d_buf, int count, hipStream_t s) {
     OneShot &o = c->one;
     const unsigned long long q = ++o.calls;
     const int parity = (int)(q & 1ull);
-    hipLaunchKernelGGL(k_oneshot_post, dim3(1), dim3(BLOCK), 0, s, d_buf, count, o.peers, c->size, c->rank, parity);
+    if (!o.mute) hipLaunchKernelGGL(k_oneshot_post, dim3(1), dim3(BLOCK), 0, s, d_buf, count, o.peers, c->size, c->rank, parity);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k_oneshot_post");
     const unsigned long long on_parity = (q + (unsigned long long)parity) / 2ull;   // calls made on this parity so far (q = 1, 3, .. odd)

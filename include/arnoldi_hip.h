@@ -329,8 +329,10 @@ int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *strea
  * (AKS_ALLREDUCE=oneshot in the environment of EVERY rank at aks_comm_create: each rank's [h ; ||w||^2] is written
  * into a row of every peer's fine-grained mailbox, arrival is a counter the stream waits on -- hipStreamWaitValue64, no
  * spinning kernel --, and every rank sums the rows in rank order: identical bits on all ranks).
- * aks_comm_create proves the exchange and lets the ranks vote; if any rank cannot, ALL stay with ncclAllReduce and
- * `why_not` (optional, NUL-terminated, at most why_bytes) says why.  Negative: error. */
+ * aks_comm_create proves the exchange (with a deadline: posts that never arrive are a failed proof, not a hang) and lets
+ * the ranks vote; if any rank cannot, ALL stay with ncclAllReduce and `why_not` (optional, NUL-terminated, at most
+ * why_bytes) says why.  Negative: error.  (AKS_ONESHOT_FAULT_RANK=<rank> loses that rank's posts: fault injection for
+ * tests.) */
 int aks_comm_allreduce_path(void *comm, char *why_not, int64_t why_bytes);
 /* Personalised exchange of BYTES between all ranks on `stream`, one group of sends / receives: rank r receives
  * send_bytes[r] bytes starting at d_send + send_offsets[r] of every peer into d_recv + recv_offsets[peer]

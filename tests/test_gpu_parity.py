@@ -1024,6 +1024,30 @@ def test_one_shot_allreduce_across_process_ranks(amd, tmp_path, ranks):
     check_dist_verdicts(verdicts, native=True)
 
 
+def test_one_shot_allreduce_whose_posts_never_arrive_falls_back_on_every_rank(amd, tmp_path):
+    """What only multi-GPU hardware can show is whether a peer's posts become visible to this rank's wait.  If they do not,
+    the self-test of ``aks_comm_create`` must neither hang nor pass: fault injection (``AKS_ONESHOT_FAULT_RANK=1``: rank
+    1's posts are lost) -- the other rank's arrival counter is not reached within the deadline, its pending wait is
+    released from the host side, the ranks vote, and BOTH run ``ncclAllReduce`` (here: its stand-in) with the reason on
+    record; the solves come out as always."""
+    import subprocess
+
+    from test_host_logic import ROOT, check_dist_verdicts, run_hostcomm_worker
+
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    os.environ.update(AKS_ALLREDUCE="oneshot", AKS_ONESHOT_FAULT_RANK="1")
+    try:
+        verdicts = run_hostcomm_worker(tmp_path, 2, "solve", timeout=300)
+    finally:
+        del os.environ["AKS_ALLREDUCE"], os.environ["AKS_ONESHOT_FAULT_RANK"]
+    assert not any(v.pop("torch_imported") for v in verdicts)
+    paths = [v.pop("allreduce_path") for v in verdicts]
+    assert [p_[0] for p_ in paths] == [0, 0], paths
+    assert "arrival counter was not reached" in paths[0][1] and paths[1][1], paths       # rank 0 timed out; rank 1 has a reason too
+    check_dist_verdicts(verdicts, native=True)
+
+
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_row_sharded_c_driven_path_over_rccl(amd, tmp_path, ranks):
     """The same cases through RCCL ITSELF, rank r on GPU r: only runs on a box that has the GPUs (the one-GPU boxes of
