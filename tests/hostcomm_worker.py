@@ -4,6 +4,8 @@ AKS_RENDEZVOUS in the environment), ranks talking through ``arnoldi_amd.dist.Hos
 ``--case setup``   (anywhere, no GPU) the set-up exchanges themselves: all-gather, ghost requests against a brute-force
                    answer, row gather, all-reduce and all-to-all of the Python-chained path, max, barrier -- over the TCP
                    rendezvous alone (AKS_DIST_PATH=python: no communicator of the library's is created).
+``--case solve_chained``  (GPU) the same cases with AKS_DIST_PATH=python: the stages chained from Python, all-reduces and the ghost
+                   all-to-all staged through the host and carried by the rendezvous (functional path, no library communicator).
 ``--case solve``   (GPU) the cases of tests/dist_cases.py on the C-driven path with ``AKS_HOST_ALLOC=hip`` and the library
                    built against tests/mock_rccl (the ranks share GPU 0): communicator id over the rendezvous, ghost
                    requests and Schur-vector rows through ``aks_comm_alltoallv``.
@@ -72,10 +74,14 @@ def setup_case(comm):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--case", choices=["setup", "solve"], required=True)
+    ap.add_argument("--case", choices=["setup", "solve", "solve_chained"], required=True)
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
-    if args.case == "solve":           # before arnoldi_amd is imported: _hip / mem read these at import
+    if args.case == "solve_chained":   # the same cases with the stages chained from Python: every collective through the rendezvous
+        os.environ["AKS_DIST_PATH"] = "python"
+        os.environ["AKS_HOST_ALLOC"] = "hip"
+        os.environ["AKS_COMM"] = "host"
+    elif args.case == "solve":         # before arnoldi_amd is imported: _hip / mem read these at import
         os.environ["AKS_LIB_PATH"] = os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so")
         os.environ["AKS_HOST_ALLOC"] = "hip"
         os.environ["AKS_COMM"] = "host"
@@ -92,12 +98,13 @@ def main():
         from dist_cases import run_cases
 
         verdict = run_cases(comm, comm.rank, comm.size)
-        import ctypes
+        if args.case == "solve":
+            import ctypes
 
-        from arnoldi_amd import _hip
+            from arnoldi_amd import _hip
 
-        why = ctypes.create_string_buffer(256)
-        verdict["allreduce_path"] = [int(_hip.load().aks_comm_allreduce_path(comm.native(), why, 256)), why.value.decode()]
+            why = ctypes.create_string_buffer(256)
+            verdict["allreduce_path"] = [int(_hip.load().aks_comm_allreduce_path(comm.native(), why, 256)), why.value.decode()]
     verdict["torch_imported"] = "torch" in sys.modules
     with open(os.path.join(args.out, f"rank{comm.rank}.json"), "w") as f:
         json.dump(verdict, f)

@@ -1003,6 +1003,17 @@ def test_row_sharded_torch_free_process_ranks(amd, tmp_path, ranks):
     check_dist_verdicts(verdicts, native=True)
 
 
+def test_row_sharded_torch_free_chained_path(amd, tmp_path):
+    """``AKS_DIST_PATH=python`` over ``dist.HostComm``: the Python-chained stages with every collective (all-reduces, the ghost
+    all-to-all) staged through the host and carried by the TCP rendezvous -- the functional fall-back of the torch-free
+    ranks, on real device arrays of the HIP allocator; same cases, no library communicator."""
+    from test_host_logic import check_dist_verdicts, run_hostcomm_worker
+
+    verdicts = run_hostcomm_worker(tmp_path, 2, "solve_chained", timeout=300)
+    assert not any(v.pop("torch_imported") for v in verdicts)
+    check_dist_verdicts(verdicts, native=False)
+
+
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_one_shot_allreduce_across_process_ranks(amd, tmp_path, ranks):
     """``AKS_ALLREDUCE=oneshot`` between PROCESSES (mailboxes mapped with hipIpc*, arrival counters waited on by the
