@@ -448,7 +448,11 @@ class _Hub:
 
     def _recv_blobs(self, conn):
         (k,) = struct.unpack("<q", self._recv_exact(conn, 8))
+        if not 0 <= k <= max(self.size, 1):
+            raise RuntimeError(f"rendezvous: malformed message ({k} parts announced)")
         sizes = struct.unpack(f"<{k}q", self._recv_exact(conn, 8 * k)) if k else ()
+        if any(n < 0 for n in sizes):
+            raise RuntimeError("rendezvous: malformed message (negative length)")
         return [self._recv_exact(conn, n) if n else b"" for n in sizes]
 
     def alltoall(self, blobs):
@@ -470,8 +474,21 @@ class _Hub:
         return [table[src][0] for src in range(self.size)]
 
     def gather(self, blob):
-        """Every rank's ``blob`` on every rank, in rank order."""
-        return self.alltoall([blob] * self.size)
+        """Every rank's ``blob`` on every rank, in rank order (each rank sends its blob ONCE)."""
+        if self.size == 1:
+            return [bytes(blob)]
+        if self.rank != 0:
+            self._send_blobs(self.peers[0], [blob])
+            return self._recv_blobs(self.peers[0])
+        parts = [bytes(blob)]
+        for peer in range(1, self.size):
+            got = self._recv_blobs(self.peers[peer])
+            if len(got) != 1:
+                raise RuntimeError("rendezvous: ranks made different calls")
+            parts.append(got[0])
+        for peer in range(1, self.size):
+            self._send_blobs(self.peers[peer], parts)
+        return parts
 
     def close(self):
         for conn in self.peers.values():
