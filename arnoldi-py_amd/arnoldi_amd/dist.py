@@ -397,7 +397,12 @@ class _Hub:
         if rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((host if host not in ("", "localhost") else "127.0.0.1", port))
+            try:
+                srv.bind((host if host not in ("", "localhost") else "127.0.0.1", port))
+            except OSError as e:
+                srv.close()
+                raise RuntimeError(f"rendezvous: rank 0 cannot listen on {host}:{port} ({e}); choose another port with "
+                                   f"AKS_RENDEZVOUS=host:port on every rank") from None
             srv.listen(size)
             srv.settimeout(timeout)
             try:
