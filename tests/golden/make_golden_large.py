@@ -119,11 +119,34 @@ def stress_grid():
             np.savez_compressed(os.path.join(HERE, "g12_stress_grid_300k.npz"), **out)
 
 
+def explicit_deflation():
+    """``explicit_restarts_with_deflation`` (explicit_restarts.py:80-168) run by the reference on the
+    stress-grid matrix (n = 300 000): eigenvalues, eigenvector residuals, History -- for two parameter sets."""
+    from arnoldi.explicit_restarts import explicit_restarts_with_deflation
+
+    A = matrices.banded_csr(GRID_N, GRID_PER_ROW, 1234, planted=GRID_PLANTED)
+    Ac = A.astype(np.complex128)
+    out = dict(n=np.int64(GRID_N), per_row=np.int64(GRID_PER_ROW), planted=np.array(GRID_PLANTED), nnz=np.int64(A.nnz))
+    for key, nev, m, tol in (("a", 4, 20, 1e-8), ("b", 6, 30, None)):
+        np.random.seed(nev)
+        t0 = time.time()
+        vals, vecs, hist = explicit_restarts_with_deflation(Ac, nev, max_dim=m, stopping_criterion=tol, max_restarts=500)
+        wall = time.time() - t0
+        res = np.linalg.norm(Ac @ vecs - vecs * vals, axis=0)
+        out.update({f"{key}_nev": np.int64(nev), f"{key}_max_dim": np.int64(m), f"{key}_tol": np.float64(-1.0 if tol is None else tol),
+                    f"{key}_vals": vals, f"{key}_res": res, f"{key}_hist_matvecs": hist.matvecs, f"{key}_hist_restarts": hist.restarts,
+                    f"{key}_wall_s": np.float64(wall)})
+        print(f"explicit {key}: nev={nev} m={m} restarts={hist.restarts} matvecs={hist.matvecs} res max {res.max():.3e} wall {wall:.1f}s", flush=True)
+    np.savez_compressed(os.path.join(HERE, "g13_explicit_deflation_300k.npz"), **out)
+
+
 def main():
     if sys.argv[1] == "augment":
         return augment()
     if sys.argv[1] == "grid":
         return stress_grid()
+    if sys.argv[1] == "explicit":
+        return explicit_deflation()
     name = sys.argv[1]
     build, kw, seed = CASES[name]
     kw = dict(kw)

@@ -241,3 +241,30 @@ def test_stress_grid_fixture_is_complete():
             assert int(g[f"{key}_restarts"]) >= 1 and g[f"{key}_diagT"].shape == (nev,)
             assert float(g[f"{key}_rel_max"]) < 5 * float(g["tol"])
             assert np.all(g[f"{key}_hist_restarts"] == int(g[f"{key}_restarts"]))
+
+
+# ---------------------------------------------------------------------------- explicit restarts with deflation, run BY the reference
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["a", "b"])
+def test_explicit_restarts_with_deflation_match_the_reference_run(key):
+    """``explicit_restarts_with_deflation`` (explicit_restarts.py:80-168) at n = 300 000 against what
+    the REFERENCE produced on the same matrix and seed (tests/golden/make_golden_large.py explicit): per-eigenvalue restart
+    and matvec History, eigenvalues to 1e-8, eigenvector residuals within 2 x the reference's."""
+    from arnoldi_amd import matrices
+    from arnoldi_amd.explicit_restarts import explicit_restarts_with_deflation
+
+    path = os.path.join(GOLDEN, "g13_explicit_deflation_300k.npz")
+    if not os.path.exists(path):
+        pytest.skip("g13_explicit_deflation_300k.npz has not been generated")
+    g = np.load(path)
+    if "A" not in _grid_matrix:
+        _grid_matrix["A"] = matrices.banded_csr(int(g["n"]), int(g["per_row"]), 1234, planted=tuple(g["planted"]))
+    A = _grid_matrix["A"]
+    nev, m, tol = int(g[f"{key}_nev"]), int(g[f"{key}_max_dim"]), float(g[f"{key}_tol"])
+    np.random.seed(nev)
+    vals, vecs, hist = explicit_restarts_with_deflation(A, nev, max_dim=m, stopping_criterion=None if tol < 0 else tol, max_restarts=500)
+    np.testing.assert_array_equal(hist.restarts, g[f"{key}_hist_restarts"])
+    np.testing.assert_array_equal(hist.matvecs, g[f"{key}_hist_matvecs"])
+    np.testing.assert_allclose(vals, g[f"{key}_vals"], rtol=1e-8, atol=1e-11)
+    res = np.linalg.norm(A @ vecs - vecs * vals, axis=0)
+    assert np.all(res <= np.maximum(2 * g[f"{key}_res"], 1e-11)), (res, g[f"{key}_res"])
