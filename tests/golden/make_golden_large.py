@@ -140,9 +140,39 @@ def explicit_deflation():
     np.savez_compressed(os.path.join(HERE, "g13_explicit_deflation_300k.npz"), **out)
 
 
+def arnoldi_full_size():
+    """One 40-step ``arnoldi_decomposition`` (decomposition.py:13-68) of the reference on config 2's matrix (n = 1 001 000) and
+    on the config-5 matrix (n = 10M, 20 steps): the whole H and 256 sampled rows of V -- the SpMV / dgks_gs / normalise
+    chain step by step at full size, without any restart logic around it."""
+    from arnoldi.decomposition import arnoldi_decomposition
+
+    out = {}
+    for key, build, m, seed in (("c2", lambda: matrices.laplace2d(1000, 1001), 40, 0),
+                                ("c5", lambda: matrices.random_csr(10_000_000, 5, 1234, planted=PLANTED_C5), 20, 0)):
+        A = build()
+        Ac = A.astype(np.complex128)
+        n = A.shape[0]
+        np.random.seed(seed)
+        v0 = rand_normalized_vector(n, np.complex128)
+        V = np.zeros((n, m + 1), np.complex128, order="F")
+        H = np.zeros((m + 1, m), np.complex128)
+        V[:, 0] = v0
+        t0 = time.time()
+        _, _, n_iter = arnoldi_decomposition(Ac, V, H, np.sqrt(np.finfo(np.float64).eps), max_dim=m)
+        rows = np.random.default_rng(99).choice(n, 256, replace=False)
+        rows.sort()
+        out.update({f"{key}_n": np.int64(n), f"{key}_m": np.int64(m), f"{key}_seed": np.int64(seed), f"{key}_n_iter": np.int64(n_iter),
+                    f"{key}_H": H, f"{key}_rows": rows, f"{key}_V_rows": V[rows, :].copy(),
+                    f"{key}_v0_sha256": np.array(hashlib.sha256(v0.tobytes()).hexdigest())})
+        print(f"arnoldi {key}: n={n} m={m} n_iter={n_iter} wall={time.time() - t0:.1f}s |H| max {np.abs(H).max():.3f}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "g14_arnoldi_full.npz"), **out)
+
+
 def main():
     if sys.argv[1] == "augment":
         return augment()
+    if sys.argv[1] == "arnoldi":
+        return arnoldi_full_size()
     if sys.argv[1] == "grid":
         return stress_grid()
     if sys.argv[1] == "explicit":

@@ -268,3 +268,42 @@ def test_explicit_restarts_with_deflation_match_the_reference_run(key):
     np.testing.assert_allclose(vals, g[f"{key}_vals"], rtol=1e-8, atol=1e-11)
     res = np.linalg.norm(A @ vecs - vecs * vals, axis=0)
     assert np.all(res <= np.maximum(2 * g[f"{key}_res"], 1e-11)), (res, g[f"{key}_res"])
+
+
+# ---------------------------------------------------------------------------- one Arnoldi expansion at full size, run BY the reference
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["c2", "c5"])
+def test_arnoldi_expansion_at_full_size_matches_the_reference_run(key):
+    """``arnoldi_decomposition`` (decomposition.py:13-68) without any restart logic around it: the reference's H (all of it)
+    and 256 sampled rows of its V after 40 steps on config 2's matrix / 20 steps on config 5's planted matrix, against
+    ``aks_arnoldi_expand`` on the same start vector -- the SpMV, both Gram-Schmidt passes and the normalisation, step by step,
+    at the BASELINE sizes.  The two computations round differently (summation orders); measured on an MI355X box: H to
+    2.8e-16 (config 2, 40 steps) and 8.1e-15 (config 5, 20 steps) of its largest entry, the sampled rows of V to 3 - 4e-15.
+    The bars leave two orders of magnitude and are nine below what a wrong partial sum or a stale scale leaves (1e-3 and
+    up, round 4)."""
+    import torch
+    from arnoldi_amd.engine import ArnoldiContext, as_operator
+    from arnoldi_amd.utils import rand_normalized_vector
+
+    path = os.path.join(GOLDEN, "g14_arnoldi_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("g14_arnoldi_full.npz has not been generated")
+    g = np.load(path)
+    A = _matrix("c2" if key == "c2" else "c5")
+    n, m = int(g[f"{key}_n"]), int(g[f"{key}_m"])
+    assert A.shape[0] == n
+    np.random.seed(int(g[f"{key}_seed"]))
+    v0 = rand_normalized_vector(n, C128)
+    ctx = ArnoldiContext(as_operator(A), m)
+    ctx.set_start_vector(v0)
+    H = np.zeros((m + 1, m), C128)
+    assert ctx.expand(H, 0, m, float(np.sqrt(np.finfo(np.float64).eps))) == int(g[f"{key}_n_iter"]) == m
+    Href = g[f"{key}_H"]
+    errH = float(np.abs(H - Href).max() / np.abs(Href).max())
+    rows = torch.from_numpy(g[f"{key}_rows"]).cuda()
+    Vrows = ctx.basis.V[: m + 1][:, rows].cpu().numpy().T                      # (256, m + 1)
+    Vref = g[f"{key}_V_rows"]
+    errV = float(np.abs(Vrows - Vref).max() / np.abs(Vref).max())
+    per_col = np.abs(Vrows - Vref).max(axis=0) / np.abs(Vref).max()
+    print(f"{key}: max |H - H_ref| / |H_ref| = {errH:.2e}; sampled V: {errV:.2e} (column 1: {per_col[1]:.1e}, last: {per_col[-1]:.1e})")
+    assert errH < 1e-12 and errV < 1e-12, (errH, errV)
