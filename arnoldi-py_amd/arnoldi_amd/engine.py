@@ -426,7 +426,8 @@ class ArnoldiContext:
         # (pinned by test_sequences_with_a_ghost_exchange_are_never_captured).  At the shard sizes of the BASELINE configs on
         # 8 GPUs (1.25M - 2M rows) a kernel lasts 20-60 us against ~4 us to launch it: the eager sequence is not host-bound.
         key = (start, end, float(tol), float(eta), w_ready, lazy, defer)
-        graph_ok = not op.native_comm or (os.environ.get("AKS_GRAPH_COMM", "0") == "1" and not op.any_exchange)
+        graph_ok = not op.native_comm or (os.environ.get("AKS_GRAPH_COMM", "0") == "1" and not op.any_exchange
+                                          and os.environ.get("AKS_ALLREDUCE") != "oneshot")   # (a stream wait is not capturable)
         if self.use_graph and self.probe is None and start > 0 and graph_ok and b.V.is_cuda:
             g = self._graphs.get(key)
             if g is None:
