@@ -273,6 +273,7 @@ class ArnoldiContext:
         self._raw_from = None       # first raw column of the basis, if an expansion left any
         self._raw_scale = {}        # column -> its scale beta (the host's copy of the workspace's colscale)
         self.deferred_expansions = 0
+        self.graph_capture_failures = 0          # captures that failed and fell back to eager launches
         self.discarded_second_passes = self.discarded_steps = self.discarded_applies = 0   # work of repeated expansions
         self.last_ctrl = None
         self._coef_stage = self._coef_dev = None      # pinned / device buffers of the restart coefficients
@@ -435,6 +436,17 @@ class ArnoldiContext:
                 gc.disable()     # a collection during capture could free device objects (illegal in capture)
                 try:
                     g = mem.Graph(enqueue)       # torch's capture API, or hipStreamBeginCapture / EndCapture (mem.py)
+                except Exception as e:           # noqa: BLE001  a capture that did not come about (another thread's device-wide
+                    # call invalidated it, the runtime refused a node): nothing of the sequence has run -- launch it eagerly,
+                    # now and from here on; a graph is an optimisation, never a reason for a solve to fail
+                    self.use_graph = False
+                    self.graph_capture_failures += 1
+                    import warnings
+
+                    warnings.warn(f"hipGraph capture of the re-expansion failed ({type(e).__name__}: {str(e)[:120]}); "
+                                  "this solve launches eagerly", RuntimeWarning, stacklevel=2)
+                    enqueue()
+                    return
                 finally:
                     if gc_was_on:
                         gc.enable()

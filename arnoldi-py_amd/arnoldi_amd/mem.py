@@ -33,6 +33,12 @@ def _default_backend():
     return "torch" if importlib.util.find_spec("torch") is not None else "hip"
 
 
+# hipGraph captures are serialised over the host threads of a process: entering a capture synchronises the device and
+# (torch) empties the allocator's cache -- hipFree -- which invalidates a capture another thread has in flight
+# ("operation failed due to a previous error during capture": seen once in ~6 runs of two concurrently solving threads,
+# round 5).  A capture happens once per launch sequence; replays take no lock.
+_capture_lock = threading.Lock()
+
 BACKEND = os.environ.get("AKS_HOST_ALLOC") or _default_backend()
 if BACKEND not in ("torch", "hip"):
     raise ValueError(f"AKS_HOST_ALLOC={BACKEND!r}: expected 'torch' or 'hip'")
@@ -89,9 +95,20 @@ if BACKEND == "torch":
         """A launch sequence captured once into a hipGraph and replayed on the current stream."""
 
         def __init__(self, enqueue):
+            # torch.cuda.graph() spelled out, without its device-wide synchronize / gc / empty_cache on entry (the hipFree of
+            # an emptied cache is what invalidates another thread's capture) and with the thread's current stream restored
+            # whatever capture_end does: a failed capture must leave the caller able to launch eagerly on ITS stream
             self.g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g, capture_error_mode="relaxed"):     # (captures on a side stream of torch's)
-                enqueue()
+            origin, side = torch.cuda.current_stream(), torch.cuda.Stream()
+            with _capture_lock:
+                side.wait_stream(origin)
+                with torch.cuda.stream(side):
+                    self.g.capture_begin(capture_error_mode="relaxed")
+                    try:
+                        enqueue()
+                    finally:
+                        self.g.capture_end()
+                origin.wait_stream(side)
 
         def replay(self):
             self.g.replay()
@@ -242,15 +259,16 @@ else:
         def __init__(self, enqueue):
             rt, s = _rt(), C.c_void_p(stream_ptr())
             graph, self.exe = C.c_void_p(), C.c_void_p()
-            _ck(rt.hipStreamBeginCapture(s, 2), "hipStreamBeginCapture")          # hipStreamCaptureModeRelaxed
-            try:
-                enqueue()
-            except BaseException:
-                rt.hipStreamEndCapture(s, C.byref(graph))                         # leave capture mode, drop what was recorded
-                if graph:
-                    rt.hipGraphDestroy(graph)
-                raise
-            _ck(rt.hipStreamEndCapture(s, C.byref(graph)), "hipStreamEndCapture")
+            with _capture_lock:
+                _ck(rt.hipStreamBeginCapture(s, 2), "hipStreamBeginCapture")          # hipStreamCaptureModeRelaxed
+                try:
+                    enqueue()
+                except BaseException:
+                    rt.hipStreamEndCapture(s, C.byref(graph))                         # leave capture mode, drop what was recorded
+                    if graph:
+                        rt.hipGraphDestroy(graph)
+                    raise
+                _ck(rt.hipStreamEndCapture(s, C.byref(graph)), "hipStreamEndCapture")
             try:
                 _ck(rt.hipGraphInstantiate(C.byref(self.exe), graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
             finally:

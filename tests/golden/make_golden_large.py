@@ -148,7 +148,8 @@ def arnoldi_full_size():
 
     out = {}
     for key, build, m, seed in (("c2", lambda: matrices.laplace2d(1000, 1001), 40, 0),
-                                ("c5", lambda: matrices.random_csr(10_000_000, 5, 1234, planted=PLANTED_C5), 20, 0)):
+                                ("c5", lambda: matrices.random_csr(10_000_000, 5, 1234, planted=PLANTED_C5), 20, 0),
+                                ("c4", lambda: matrices.laplace3d(251, 252, 253), 40, 0)):        # 10.5 GB basis, 64-bit offsets
         A = build()
         Ac = A.astype(np.complex128)
         n = A.shape[0]
@@ -165,6 +166,7 @@ def arnoldi_full_size():
                     f"{key}_H": H, f"{key}_rows": rows, f"{key}_V_rows": V[rows, :].copy(),
                     f"{key}_v0_sha256": np.array(hashlib.sha256(v0.tobytes()).hexdigest())})
         print(f"arnoldi {key}: n={n} m={m} n_iter={n_iter} wall={time.time() - t0:.1f}s |H| max {np.abs(H).max():.3f}", flush=True)
+        del V, A, Ac, v0
     np.savez_compressed(os.path.join(HERE, "g14_arnoldi_full.npz"), **out)
 
 
