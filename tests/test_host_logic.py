@@ -1152,6 +1152,30 @@ def test_scalar_load_hazard_lint():
     assert m and m.group(1) == m.group(2) and m.group(3) == m.group(4) and int(m.group(2)) > 100 and int(m.group(4)) > 1000, now.stdout[-600:]
 
 
+def test_hazard_lint_catches_the_pattern_compiled_from_source(tmp_path):
+    """Mutation test of the lint's whole pipeline: tests/hazard_mutation.hip holds round 3's faulty
+    ``k_colscale_after_truncate`` and its fixed form as SOURCE; compiled with today's hipcc, the first must be flagged
+    (the compiler still picks a scalar load and waits for it behind the store loop) and the second must pass."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    out = os.path.join(tmp_path, "mut.s")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", out,
+                        os.path.join(ROOT, "tests", "hazard_mutation.hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lint = subprocess.run([sys.executable, os.path.join(ROOT, "arnoldi-py_amd", "csrc", "check_scalar_hazards.py"), out],
+                          capture_output=True, text=True)
+    assert lint.returncode == 1, lint.stdout
+    flagged = [ln for ln in lint.stdout.splitlines() if ": line " in ln]
+    assert flagged and all(ln.startswith("k_colscale_r03") for ln in flagged), lint.stdout
+    assert "can overtake it" in lint.stdout and "k_colscale_fixed: line" not in lint.stdout
+
+
 def test_complex_schur_takes_the_real_route_only_when_it_is_a_complex_schur_form(monkeypatch):
     """utils.complex_schur: for an exactly real matrix with a real spectrum the real Schur form (dgees, a third of the
     time of zgees) is triangular and is returned as the complex Schur form; 2 x 2 blocks or any imaginary part mean zgees."""
