@@ -163,11 +163,11 @@ def test_full_size_drivers_are_bitwise_repeatable(tmp_path, name, args, forms, d
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks,args", [(2, []), (3, []), (4, ["--workload", "laplace3d", "--rows", "16000000"])])
+@pytest.mark.parametrize("ranks,args", [(2, []), (3, []), (4, ["--workload", "laplace3d", "--rows", "16000000"]), (8, [])])
 def test_one_shot_allreduce_gives_the_collectives_bits(tmp_path, ranks, args):
     """``AKS_ALLREDUCE=oneshot``: every rank writes its [h ; ||w||^2] into a row of
     every peer's mailbox, waits for the arrivals with a stream memory operation and sums the rows in rank order.  Full-size
-    sharded solves (config 5 at 2 and 3 ranks, config 4 at 4: every step with the third reduction) must give H -- after
+    sharded solves (config 5 at 2, 3 and 8 ranks, config 4 at 4: every step with the third reduction) must give H -- after
     every expansion and contraction -- bit for bit what the library collective (here: its order-checking stand-in, which
     also sums in rank order) gives, and must say that the one-shot path is the one that ran.
 
@@ -175,7 +175,7 @@ def test_one_shot_allreduce_gives_the_collectives_bits(tmp_path, ranks, args):
     stream that posts (the wait would block the queue in front of the post: observed as a hang from the second solve of
     a process on, profiles/r05_small_trace.txt).  Rank PROCESSES -- the product's mode -- cannot collide
     (tests/test_gpu_parity.py::test_one_shot_allreduce_across_process_ranks); here each run is a fresh process with one
-    solve and GPU_MAX_HW_QUEUES raised above its stream count, and the 8-rank case (16 streams) is run by hand only."""
+    solve and GPU_MAX_HW_QUEUES raised above its stream count (the 8-rank case, 16 streams: 8 of 8 trials that way)."""
     base = _worker(tmp_path, "repro", ["--ranks", str(ranks), "--repeats", "1"] + args, timeout=240)
     one = _worker(tmp_path, "repro", ["--ranks", str(ranks), "--repeats", "1"] + args, timeout=240,     # (a hang must fail HERE, fast)
                   env_extra={"AKS_ALLREDUCE": "oneshot", "GPU_MAX_HW_QUEUES": "32"})
