@@ -5,7 +5,8 @@
  *     V^H V = I      and      A V_m = V_{m+1} H
  * on the host, then compresses the basis with aks_truncate and re-checks orthonormality, and repeats the
  * factorisation with the operator in the sliced form (aks_sell_plan_size / _fill, aks_csr_block.sell) and in
- * real-packed mode (aks_workspace_set_real + aks_arnoldi_expand with AKS_EXPAND_REAL_PACKED).
+ * real-packed mode (aks_workspace_set_real + aks_arnoldi_expand with AKS_EXPAND_REAL_PACKED), and ends with the communicator entry
+ * points on a one-rank communicator (both all-reduce paths, the byte exchange).
  *
  *   hipcc -x c abi_smoke.c -I../../include -L<dir of the .so> -larnoldi_hip -o abi_smoke
  * Exit code 0 = pass.  Used by tests/test_gpu_parity.py::test_c_abi_from_plain_c. */
@@ -213,5 +214,39 @@ int main(void) {
         }
     }
     printf("real-packed: |V^T V - I| = %.2e, |A V - V H| = %.2e, max |Im H| = %.1e\n", worst_o, worst_r, worst_im);
-    return (worst_o < 1e-12 && worst_r < 1e-12 && worst_im == 0.0) ? 0 : 1;
+    if (!(worst_o < 1e-12 && worst_r < 1e-12 && worst_im == 0.0)) return 1;
+
+    /* ---- the communicator entry points from plain C (ABI 5), on a ONE-rank communicator -- all a one-GPU box can make; RCCL is
+     * the system's (dlopen("librccl.so")), no Python in the process: id, create, the small all-reduce through ncclAllReduce and
+     * -- a second communicator made with AKS_ALLREDUCE=oneshot -- through the one-shot mailbox exchange, and the byte exchange the
+     * torch-free host layer builds its set-up on (aks_comm_alltoallv: this rank's own slice is a device copy). ---- */
+    if (getenv("AKS_ABI_SMOKE_NO_COMM") == NULL) {
+        for (int pass = 0; pass < 2; ++pass) {
+            char ident[AKS_COMM_ID_BYTES], why[128];
+            void *comm = NULL;
+            if (pass == 1) setenv("AKS_ALLREDUCE", "oneshot", 1);
+            CHECK_AKS(aks_comm_unique_id(ident));
+            CHECK_AKS(aks_comm_create(ident, 0, 1, &comm));
+            const int path = aks_comm_allreduce_path(comm, why, (int64_t)sizeof why);
+            CHECK_AKS(path);
+            double h_buf[6] = {1.5, -2.0, 3.25, 0.0, 7.0, -0.5}, h_out[6], *d_buf, *d_out;
+            CHECK_HIP(hipMalloc((void **)&d_buf, sizeof h_buf));
+            CHECK_HIP(hipMalloc((void **)&d_out, sizeof h_buf));
+            CHECK_HIP(hipMemcpy(d_buf, h_buf, sizeof h_buf, hipMemcpyHostToDevice));
+            for (int rep = 0; rep < 3; ++rep) CHECK_AKS(aks_comm_allreduce_sum(comm, d_buf, 6, NULL));    /* sum over one rank = itself */
+            const int64_t zero = 0, bytes = (int64_t)sizeof h_buf;
+            CHECK_AKS(aks_comm_alltoallv(comm, d_buf, &zero, &bytes, d_out, &zero, &bytes, NULL));
+            CHECK_HIP(hipDeviceSynchronize());
+            CHECK_HIP(hipMemcpy(h_out, d_out, sizeof h_buf, hipMemcpyDeviceToHost));
+            int same = 1;
+            for (int i = 0; i < 6; ++i) same = same && h_out[i] == h_buf[i];
+            printf("communicator from plain C, pass %d: all-reduce path %d%s%s, values %s\n", pass, path, why[0] ? " -- " : "", why,
+                   same ? "intact" : "WRONG");
+            CHECK_AKS(aks_comm_destroy(comm));
+            CHECK_HIP(hipFree(d_buf));
+            CHECK_HIP(hipFree(d_out));
+            if (!same || path != pass) return 1;
+        }
+    }
+    return 0;
 }
