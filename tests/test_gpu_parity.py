@@ -1248,6 +1248,33 @@ def test_solves_without_torch_in_the_process(tmp_path):
     assert g["bit_identical"] and g["graphs_eager"] == 0 and g["graphs_replayed"] >= 1 and g["restarts"] > 1, g
 
 
+def test_a_ghost_exchange_is_capturable_on_the_system_runtime(tmp_path):
+    """Where the round-3 capture crash does NOT happen (profiles/r05_capture_crash.txt): in a process without torch the HIP
+    runtime and RCCL are the system's (ROCm 7.2: HIP 7.2.26015, RCCL 2.27.7), and there ``aks_shard_apply`` with its
+    exchange forked onto the communicator's side stream captures into a hipGraph and replays -- three replays on changing
+    input, each equal to  D x + O x[send_idx] -- and the communicator can be destroyed afterwards PROVIDED the graphs go
+    first (with a captured send / recv group still alive ``ncclCommDestroy`` never returns).  The product still keeps
+    sequences with an exchange eager (the guard cannot know which runtime a torch process bundles; multi-rank replay has no
+    rehearsal -- the stand-in synchronises streams); this pins what the next step can build on."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    out = os.path.join(tmp_path, "capture_exchange.json")
+    env = dict(os.environ, AKS_HOST_ALLOC="hip", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("AKS_LIB_PATH", "AKS_ALLREDUCE", "RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "capture_exchange_worker.py"), out], capture_output=True,
+                         text=True, timeout=120, env=env)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    r = json.load(open(out))
+    assert r["torch_imported"] is False and r["hip_runtime_version"] >= 70200000 and r.get("communicator_destroyed"), r
+    for c in r["cases"]:
+        assert c["eager_err"] < 1e-13 and max(c["replay_errs"]) < 1e-13, c
+
+
 def test_graph_replay_gives_identical_results(amd, monkeypatch):
     """Opt-in hipGraph replay of the re-expansion (AKS_GRAPH=1): bit-identical Q, T and History."""
     from arnoldi_amd.matrices import mark
