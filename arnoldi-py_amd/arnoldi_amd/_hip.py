@@ -10,7 +10,7 @@ import ctypes as C
 import os
 import threading
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_DIM = 128          # AKS_MAX_DIM
 MAX_TRUNC = 96         # AKS_MAX_TRUNC
 SPMV_TILE_NNZ = 256    # AKS_SPMV_TILE_NNZ
@@ -156,6 +156,11 @@ SIGNATURES = {
     "aks_comm_allreduce_sum": (C.c_int, [_P, _P, _I64, _P]),
     "aks_comm_allreduce_path": (C.c_int, [_P, C.c_char_p, _I64]),
     "aks_comm_alltoallv": (C.c_int, [_P, _P, C.POINTER(_I64), C.POINTER(_I64), _P, C.POINTER(_I64), C.POINTER(_I64), _P]),
+    "aks_comm_status": (C.c_int, [_P, C.c_char_p, _I64]),
+    "aks_comm_graph_retain": (C.c_int, [_P]),
+    "aks_comm_graph_release": (C.c_int, [_P]),
+    "aks_stream_copy": (C.c_int, [_P, _P, _I64, _P]),
+    "aks_runtime_versions": (C.c_int, [C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "aks_workspace_set_real": (C.c_int, [_P, _I32, _P]),
     "aks_csr_spmv_real": (C.c_int, [_I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _P]),
     "aks_pb_spmv_real": (C.c_int, [C.POINTER(PbMatrix), _P, _P, _I32, _P, _P]),
@@ -276,3 +281,19 @@ def workspace_layout(n_rows, max_dim):
     lay = WsLayout()
     check(load().aks_workspace_layout(n_rows, max_dim, C.byref(lay)), "aks_workspace_layout")
     return lay
+
+
+def runtime_versions():
+    """``{"hip_runtime": .., "hip_driver": .., "rccl": ..}`` of what this process actually runs on (``hipRuntimeGetVersion``,
+    ``hipDriverGetVersion``, ``ncclGetVersion`` of the librccl the library loaded; ``rccl`` is None while none is loaded).
+    A torch process runs on torch's bundled HIP / RCCL, a torch-free one on the system's ROCm."""
+    a, b, c = _I32(0), _I32(0), _I32(0)
+    check(load().aks_runtime_versions(C.byref(a), C.byref(b), C.byref(c)), "aks_runtime_versions")
+    return {"hip_runtime": a.value, "hip_driver": b.value, "rccl": None if c.value < 0 else c.value}
+
+
+def comm_status(handle):
+    """Raise if a one-shot reduction of this rank's communicator timed out (``aks_comm_status``: one host-memory read)."""
+    why = C.create_string_buffer(256)
+    if load().aks_comm_status(handle, why, 256) > 0:
+        raise HipLibraryError(why.value.decode())

@@ -159,6 +159,35 @@ def _close_all():
 atexit.register(_close_all)
 
 
+class _GraphOwners:
+    """Contexts whose hipGraphs captured operations of this communicator (engine.ArnoldiContext.adopt...): the graphs must
+    be destroyed BEFORE the communicator -- ``ncclCommDestroy`` does not return while a graph holds a captured send / recv
+    (profiles/r05_capture_crash.txt section 4).  ``close()`` drops them first; the library counts them as well
+    (``aks_comm_graph_retain`` / ``_release``) and REFUSES to destroy a communicator with graphs still counted on it, so a
+    graph this registry does not know of is an error message, not a hang."""
+
+    def adopt_graph_owner(self, ctx):
+        import weakref
+
+        from . import _hip
+
+        if getattr(self, "_graph_owners", None) is None:
+            self._graph_owners = weakref.WeakSet()
+        _hip.check(_hip.load().aks_comm_graph_retain(self._native), "aks_comm_graph_retain")
+        self._graph_owners.add(ctx)
+
+    def _destroy_native(self):
+        """Graphs first, then the communicator; raises (communicator intact) if the library still counts a graph."""
+        if self._native is None:
+            return
+        from . import _hip
+
+        for ctx in list(getattr(self, "_graph_owners", None) or ()):
+            ctx.drop_graphs()
+        _hip.check(_hip.load().aks_comm_destroy(self._native), "aks_comm_destroy")
+        self._native = None
+
+
 def comm_for(group=None):
     """The Comm of a process group (the default group if None), created once per group: every
     ``partial_schur`` without an explicit ``comm`` used to build a new one -- and with it a new RCCL
@@ -175,7 +204,7 @@ def comm_for(group=None):
     return c
 
 
-class Comm:
+class Comm(_GraphOwners):
     """Thin wrapper over a torch.distributed process group.
 
     ``backend == "nccl"`` is RCCL on ROCm: device tensors go straight to the
@@ -278,11 +307,7 @@ class Comm:
         return self._native
 
     def close(self):
-        if self._native is not None:
-            from . import _hip
-
-            _hip.load().aks_comm_destroy(self._native)
-            self._native = None
+        self._destroy_native()
         _live_comms.discard(self)
 
     def __del__(self):
@@ -384,16 +409,35 @@ class Comm:
 
 
 # --------------------------------------------------------------------------- torch-free communicator
+def _job_token():
+    """32 bytes every rank of one job derives alike and a stranger does not know by accident: ``AKS_COMM_TOKEN`` (set it --
+    ``bench.py --gpus N`` draws a random one for its ranks -- when the rendezvous port is reachable by others), else a
+    digest of the launcher's coordinates (MASTER_ADDR / MASTER_PORT / WORLD_SIZE / TORCHELASTIC_RUN_ID), which keeps
+    apart jobs that meet on one port by mistake."""
+    import hashlib
+
+    secret = os.environ.get("AKS_COMM_TOKEN")
+    if not secret:
+        secret = "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "TORCHELASTIC_RUN_ID"))
+    return hashlib.sha256(("aks-rendezvous:" + secret).encode()).digest()
+
+
 class _Hub:
     """Star of TCP connections: rank 0 listens, every other rank connects; ``gather`` / ``alltoall`` of byte strings in
     lock step (every rank makes the same sequence of calls -- they are collectives).  Control plane only: the messages
-    are bytes to a few MB; a lost peer is a time-out (``AKS_COMM_TIMEOUT_S``, default 300), never a silent hang."""
+    are bytes to a few MB; a lost peer is a time-out (``AKS_COMM_TIMEOUT_S``, default 300), never a silent hang.  A peer
+    must open with the job's token (``_job_token``) and a free rank; one message is at most ``AKS_COMM_MAX_MSG`` bytes
+    (default 512 MiB) and is read in chunks, so an announced length never allocates what has not arrived."""
+
+    CHUNK = 16 << 20
 
     def __init__(self, rank, size, host, port, timeout):
         self.rank, self.size, self.timeout = rank, size, timeout
+        self.max_msg = int(os.environ.get("AKS_COMM_MAX_MSG", str(512 << 20)))
         self.peers = {}                      # rank 0: peer rank -> socket; others: {0: socket}
         if size == 1:
             return
+        token = _job_token()
         if rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -405,18 +449,33 @@ class _Hub:
                                    f"AKS_RENDEZVOUS=host:port on every rank") from None
             srv.listen(size)
             srv.settimeout(timeout)
+            deadline = time.monotonic() + timeout
             try:
                 while len(self.peers) < size - 1:
+                    srv.settimeout(max(deadline - time.monotonic(), 0.01))
                     conn, _ = srv.accept()
-                    conn.settimeout(timeout)
-                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    (peer,) = struct.unpack("<q", self._recv_exact(conn, 8))
-                    if not 0 < peer < size or peer in self.peers:
-                        raise RuntimeError(f"rendezvous: unexpected peer rank {peer}")
+                    try:
+                        conn.settimeout(min(timeout, 10.0))         # the hello is 40 bytes: a silent stranger does not hold the job up
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        hello = self._recv_exact(conn, 40)
+                        (peer,) = struct.unpack("<q", hello[:8])
+                        if hello[8:] != token:
+                            raise RuntimeError("rendezvous: a peer presented another job's token")
+                        if not 0 < peer < size or peer in self.peers:
+                            raise RuntimeError(f"rendezvous: unexpected peer rank {peer}")
+                        conn.settimeout(timeout)
+                    except (RuntimeError, OSError) as e:
+                        conn.close()                                 # a stranger (or a broken hello) is dropped; the ranks
+                        sys_stderr(f"rendezvous: dropped a connection ({e})")   # of THIS job can still arrive
+                        continue
                     self.peers[peer] = conn
             except socket.timeout:
+                self.close()
                 raise RuntimeError(f"rendezvous at {host}:{port}: only {len(self.peers) + 1} of {size} ranks arrived "
                                    f"within {timeout:.0f} s") from None
+            except BaseException:
+                self.close()
+                raise
             finally:
                 srv.close()
         else:
@@ -429,23 +488,37 @@ class _Hub:
                     if time.monotonic() > deadline:
                         raise RuntimeError(f"rendezvous: rank 0 not reachable at {host}:{port} within {timeout:.0f} s") from None
                     time.sleep(0.05)
-            conn.settimeout(timeout)
-            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            conn.sendall(struct.pack("<q", rank))
+            try:
+                conn.settimeout(timeout)
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.sendall(struct.pack("<q", rank) + token)
+            except BaseException:
+                conn.close()
+                raise
             self.peers[0] = conn
 
-    @staticmethod
-    def _recv_exact(conn, n):
-        buf = bytearray(n)
-        view, got = memoryview(buf), 0
-        while got < n:
-            k = conn.recv_into(view[got:], n - got)
-            if k == 0:
-                raise RuntimeError("rendezvous: a peer closed its connection")
-            got += k
-        return bytes(buf)
+    @classmethod
+    def _recv_exact(cls, conn, n):
+        """``n`` bytes, received chunk by chunk: memory grows with what has ARRIVED, not with what was announced."""
+        if n <= cls.CHUNK:
+            buf = bytearray(n)
+            view, got = memoryview(buf), 0
+            while got < n:
+                k = conn.recv_into(view[got:], n - got)
+                if k == 0:
+                    raise RuntimeError("rendezvous: a peer closed its connection")
+                got += k
+            return bytes(buf)
+        parts, left = [], n
+        while left:
+            parts.append(cls._recv_exact(conn, min(left, cls.CHUNK)))
+            left -= len(parts[-1])
+        return b"".join(parts)
 
     def _send_blobs(self, conn, blobs):
+        if sum(len(b) for b in blobs) > self.max_msg:
+            raise RuntimeError(f"rendezvous: a message of {sum(len(b) for b in blobs)} bytes exceeds AKS_COMM_MAX_MSG = {self.max_msg} "
+                               "(the bulk exchanges go through the library's communicator; raise the limit for AKS_DIST_PATH=python)")
         conn.sendall(struct.pack(f"<q{len(blobs)}q", len(blobs), *(len(b) for b in blobs)))
         for b in blobs:
             if len(b):
@@ -458,6 +531,8 @@ class _Hub:
         sizes = struct.unpack(f"<{k}q", self._recv_exact(conn, 8 * k)) if k else ()
         if any(n < 0 for n in sizes):
             raise RuntimeError("rendezvous: malformed message (negative length)")
+        if sum(sizes) > self.max_msg:
+            raise RuntimeError(f"rendezvous: a peer announced {sum(sizes)} bytes, more than AKS_COMM_MAX_MSG = {self.max_msg}")
         return [self._recv_exact(conn, n) if n else b"" for n in sizes]
 
     def alltoall(self, blobs):
@@ -504,6 +579,12 @@ class _Hub:
         self.peers = {}
 
 
+def sys_stderr(msg):
+    import sys
+
+    sys.stderr.write(msg + "\n")
+
+
 def rendezvous_address():
     """(host, port) of the torch-free rendezvous: ``AKS_RENDEZVOUS=host:port``, else MASTER_ADDR and MASTER_PORT + 1
     (the launcher's own store listens on MASTER_PORT itself when the ranks were started by torch.distributed.run)."""
@@ -514,7 +595,7 @@ def rendezvous_address():
     return os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29400")) + 1
 
 
-class HostComm:
+class HostComm(_GraphOwners):
     """The ``Comm`` interface without torch: set-up exchanges over a TCP rendezvous (control) and over the library's own
     communicator (bulk); see the module docstring.  Device staging buffers come from ``mem`` (either backend)."""
 
@@ -702,13 +783,11 @@ class HostComm:
         return None
 
     def close(self):
-        if self._native is not None:
-            from . import _hip
-
-            _hip.load().aks_comm_destroy(self._native)
-            self._native = None
-        self._hub.close()
-        _live_comms.discard(self)
+        try:
+            self._destroy_native()
+        finally:
+            self._hub.close()
+            _live_comms.discard(self)
 
 
 _host_comm = None

@@ -33,14 +33,16 @@ class CsrOperator:
     """CSR operator resident in HBM, row-sharded over ``comm`` (or whole on one GPU)."""
 
     def __init__(self, A=None, *, local_rows=None, offsets=None, comm=None, device=None, spmv_form=None,
-                 real=False):
+                 real=False, exchange_plan=None):
         """``spmv_form``: None/"auto" (by the structure of the matrix -- ``DeviceCSR.autotune``: the tile-binned
         form for large scattered matrices, the sliced form for matrices with column locality and rows of similar
         length, the CSR-stream kernel otherwise; AKS_SPMV_TUNE=measure times the candidate instead), "csr",
         "binned" or "sliced".  The form fixes the order in which a row's products are summed, i.e. the last
         bits of a solve; it is reported in ``partial_schur(..., stats=)`` as ``spmv_form``.  Environment
         override: AKS_SPMV_FORM.  ``real``: the operator works on real vectors (real-packed Krylov basis):
-        real-vector SpMV kernels, float64 ghost exchange."""
+        real-vector SpMV kernels, float64 ghost exchange.  ``exchange_plan``: ``(dist.GhostPlan, asked)`` made by the caller
+        instead of ``split_local_rows`` + ``comm.exchange_requests`` -- rehearsals of the exchange on ONE rank, whose
+        communicator then sends the "ghost" entries to itself (tests/capture_exchange_worker.py)."""
         form = os.environ.get("AKS_SPMV_FORM", spmv_form or "auto")
         force = None if form == "auto" else form
         self.comm = comm
@@ -79,7 +81,7 @@ class CsrOperator:
                         f"{list(map(int, mine[:-2]))} and a {rows.shape[0]} x {rows.shape[1]} block")
             if rows.shape[1] != self.n or len(self.offsets) != world + 1:
                 raise ValueError(f"shard of shape {rows.shape} does not fit offsets {self.offsets.tolist()}")
-        if world == 1:
+        if world == 1 and exchange_plan is None:
             self.diag = dev.DeviceCSR(rows, device)
             self.spmv_form = self.diag.autotune(force=force, real=self.real)
             self.off = None
@@ -87,7 +89,7 @@ class CsrOperator:
             self.any_exchange = False
             self._build_shard()
             return
-        plan = split_local_rows(rows, self.offsets, rank)
+        plan = exchange_plan[0] if exchange_plan is not None else split_local_rows(rows, self.offsets, rank)
         self.diag = dev.DeviceCSR(plan.diag, device)
         self.off = dev.DeviceCSR(plan.off, device) if plan.off is not None else None
         self.spmv_form = self.diag.autotune(force=force, real=self.real)
@@ -95,7 +97,7 @@ class CsrOperator:
             self.off.autotune(force=force, real=self.real)
         self.n_ghost = plan.n_ghost
         self.recv_counts = [int(c) for c in plan.recv_counts]
-        asked = comm.exchange_requests(plan.ghost_cols, plan.recv_counts)
+        asked = exchange_plan[1] if exchange_plan is not None else comm.exchange_requests(plan.ghost_cols, plan.recv_counts)
         self.send_counts = [int(a.shape[0]) for a in asked]
         send_idx = (np.concatenate(asked) - self.r0).astype(np.int32) if sum(self.send_counts) else np.zeros(0, np.int32)
         assert send_idx.size == 0 or (send_idx.min() >= 0 and send_idx.max() < self.n_local)
@@ -257,6 +259,7 @@ class ArnoldiContext:
         mode = os.environ.get("AKS_GRAPH", "auto")
         self.use_graph = mode == "1" or (mode == "auto" and getattr(op, "n_local", 1 << 62) <= 4_000_000)
         self._graphs = {}
+        self._graphs_on_comm = 0    # ... of which captured operations of the communicator (counted there too)
         # look-ahead operator application (see expand): off with AKS_LOOKAHEAD=0
         self.allow_lookahead = os.environ.get("AKS_LOOKAHEAD", "1") != "0"
         # multi-rank: leave the third all-reduce out until a step turns out to need a second DGKS pass
@@ -350,6 +353,8 @@ class ArnoldiContext:
             elif want_look:
                 op.apply(b.col(end), self._look.col(1 - self._look_col), ws)   # a device no-op after a breakdown
             Hd, ctrl = fetch()
+            if native and op.native_comm:
+                _hip.comm_status(op.comm._native)           # a one-shot reduction that timed out (NaN in H) is an error here
             if lazy and int(ctrl.second_passes) != passes_before:
                 self.lazy_third = lazy = False              # a step needed the second pass: do it over, exactly
                 self.lazy_redos += 1
@@ -415,20 +420,11 @@ class ArnoldiContext:
         # The re-expansion (start = p) is the same launch sequence with the same arguments at
         # every restart (DGKS decisions and breakdown are taken on the device), so it can be
         # captured once into a hipGraph and replayed: one host call per restart instead of
-        # ~10 launches per Arnoldi step (opt-in: AKS_GRAPH=1; pays off when the host is slow
+        # ~10 launches per Arnoldi step (AKS_GRAPH; pays off when the host is slow
         # relative to the kernels).  Not used while a probe records per-kernel events.  With a communicator the
-        # sequence contains RCCL calls.  The stage all-reduces can be captured with it (AKS_GRAPH_COMM=1, opt-in:
-        # checked on a one-rank communicator only -- tests/nccl_single_worker.py -- where replay is bit-identical
-        # to eager); a ghost exchange is never captured: a grouped ncclSend / ncclRecv captured on a stream that JOINED the
-        # capture through an event (the communicator's side stream) sends the HIP runtime's end-of-capture walk into an
-        # unbounded recursion -- 174 573 nested frames of hip::Stream::EndCapture(), a stack overflow, with HIP 7.0.51831 +
-        # RCCL 2.26.6 (profiles/r05_capture_crash.txt: backtrace, and the variants that do capture: the same group on the
-        # capturing stream, an all-reduce or a kernel on the forked stream).  So sequences with an exchange stay eager
-        # (pinned by test_sequences_with_a_ghost_exchange_are_never_captured).  At the shard sizes of the BASELINE configs on
-        # 8 GPUs (1.25M - 2M rows) a kernel lasts 20-60 us against ~4 us to launch it: the eager sequence is not host-bound.
+        # sequence contains the library's collectives -- see ``_comm_capturable``.
         key = (start, end, float(tol), float(eta), w_ready, lazy, defer)
-        graph_ok = not op.native_comm or (os.environ.get("AKS_GRAPH_COMM", "0") == "1" and not op.any_exchange
-                                          and os.environ.get("AKS_ALLREDUCE") != "oneshot")   # (a stream wait is not capturable)
+        graph_ok = not op.native_comm or self._comm_capturable()
         if self.use_graph and self.probe is None and start > 0 and graph_ok and b.V.is_cuda:
             g = self._graphs.get(key)
             if g is None:
@@ -438,7 +434,9 @@ class ArnoldiContext:
                     g = mem.Graph(enqueue)       # torch's capture API, or hipStreamBeginCapture / EndCapture (mem.py)
                 except Exception as e:           # noqa: BLE001  a capture that did not come about (another thread's device-wide
                     # call invalidated it, the runtime refused a node): nothing of the sequence has run -- launch it eagerly,
-                    # now and from here on; a graph is an optimisation, never a reason for a solve to fail
+                    # now and from here on; a graph is an optimisation, never a reason for a solve to fail.  It is COUNTED
+                    # (``graph_capture_failures``, in ``partial_schur(stats=)``): the tests that replay graphs assert 0, so
+                    # the capture invalidation round 5 fixed (mem._capture_lock) cannot come back behind this fall-back
                     self.use_graph = False
                     self.graph_capture_failures += 1
                     import warnings
@@ -451,9 +449,57 @@ class ArnoldiContext:
                     if gc_was_on:
                         gc.enable()
                 self._graphs[key] = g
+                if op.native_comm:               # the communicator must outlive this graph: counted there (dist: close())
+                    op.comm.adopt_graph_owner(self)
+                    self._graphs_on_comm += 1
             g.replay()
         else:
             enqueue()
+
+    def _comm_capturable(self):
+        """Whether this rank's launch sequence WITH its collectives may be captured (AKS_GRAPH_COMM; all ranks read the same
+        environment, so all decide alike):
+
+        ``0`` (default)  never: a sharded expansion is launched eagerly.  At the shard sizes of the BASELINE configs on 8
+                         GPUs (1.25M - 2M rows) a kernel lasts 20-60 us against ~4 us to launch it: not host-bound.
+        ``1``            sequences whose only collectives are the stage reductions (``ncclAllReduce`` or the one-shot
+                         kernel, which keeps its call counter on the device for exactly this purpose).
+        ``exchange``     also sequences with a ghost exchange -- ONLY on a HIP runtime >= 7.2: a grouped ncclSend / ncclRecv
+                         captured on a stream that JOINED the capture through an event (the communicator's side stream)
+                         sends the end-of-capture walk of HIP 7.0.51831 (what a torch wheel bundles) into an unbounded
+                         recursion, 174 573 nested frames of hip::Stream::EndCapture() (profiles/r05_capture_crash.txt);
+                         the system's ROCm 7.2 captures and replays the very sequence
+                         (test_a_ghost_exchange_is_capturable_on_the_system_runtime).  On an older runtime the value is
+                         ignored and the sequence stays eager (test_sequences_with_a_ghost_exchange_are_never_captured).
+
+        A graph that captured communicator operations must be destroyed BEFORE the communicator (ncclCommDestroy never
+        returns otherwise): the context registers itself with the Comm, whose ``close()`` drops the graphs first, and the
+        library refuses to destroy a communicator with graphs still counted on it."""
+        mode = os.environ.get("AKS_GRAPH_COMM", "0")
+        if mode not in ("1", "exchange"):
+            return False
+        if not self.op.any_exchange:
+            return True
+        return mode == "exchange" and _hip.runtime_versions()["hip_runtime"] >= 70200000
+
+    def drop_graphs(self):
+        """Destroy every captured graph now (and give the communicator its counts back)."""
+        graphs, self._graphs = self._graphs, {}
+        for g in graphs.values():
+            g.destroy()
+        n, self._graphs_on_comm = self._graphs_on_comm, 0
+        comm = self.comm
+        if n and comm is not None and getattr(comm, "_native", None) is not None:
+            lib = _hip.load()
+            for _ in range(n):
+                lib.aks_comm_graph_release(comm._native)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_graphs_on_comm", 0):
+                self.drop_graphs()
+        except Exception:              # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def _expand_chained(self, start, end, tol, eta, w_ready, lazy, multi):
         """The same stages chained from Python: opaque host operators, and row-sharded solves whose
@@ -754,8 +800,11 @@ class ArnoldiContext:
 
 
 def default_comm():
-    """Comm over the default process group when torch.distributed is up with > 1 rank; or, with ``AKS_COMM=host`` and
-    WORLD_SIZE > 1 in the environment, the torch-free ``dist.HostComm`` (TCP rendezvous + the library's communicator)."""
+    """The communicator of a solve that was given none.  With ``AKS_COMM=host`` and WORLD_SIZE > 1 in the environment: the
+    torch-free ``dist.HostComm`` (TCP rendezvous + the library's communicator) -- on either allocator backend.  On the torch
+    backend (``AKS_HOST_ALLOC=torch``) also: a ``Comm`` over the default torch.distributed group when the caller has
+    initialised one with more than one rank.  The default (HIP runtime) backend cannot ride on a torch process group --
+    torch's collectives run on torch's streams and allocator -- and says so instead of solving unsharded on every rank."""
     import sys
 
     if os.environ.get("AKS_COMM") == "host" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -767,6 +816,11 @@ def default_comm():
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if mem.BACKEND != "torch":
+            raise _hip.HipLibraryError(
+                "torch.distributed is initialised with several ranks, but arnoldi_amd runs on its torch-free backend: start the "
+                "process with AKS_HOST_ALLOC=torch to shard over the torch process group, or with AKS_COMM=host to shard over "
+                "dist.HostComm, or pass comm= explicitly")
         from .dist import comm_for
 
         return comm_for()            # one Comm (and one RCCL communicator) per process group, not per solve

@@ -134,7 +134,7 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
             identical stream to the reference).
     comm    ``dist.Comm`` for a row-sharded multi-GPU solve; default: the default
             torch.distributed group if it is initialised with more than one rank.
-    device  torch device of this rank's GPU (default: current device).
+    device  this rank's GPU: an index, "cuda:i" / a torch device on the torch backend (default: the current device).
     gather  multi-GPU only: return the full ``Q`` on every rank (True) or just this
             rank's rows (False).
     on_breakdown  "raise" (default, the reference's behaviour) or "deflate": when the Arnoldi expansion
@@ -148,7 +148,7 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
             Schur vectors and let the restart size grow with them (krylov_schur_locking.py; the
             reference's TODO, README.md:116).  Same ``(Q, T)`` contract; restart counts differ.
     stats   optional dict that receives ``restarts``, ``matvecs`` (true operator
-            applications), ``second_passes`` and the solver object.
+            applications), ``second_passes``, ``graphs_captured`` / ``graph_capture_failures`` and the solver object.
 
     Returns ``(Q, T, history)``; raises ``ValueError("Has not converged !")`` /
     ``ValueError("Happy breakdown not supported yet")`` like the reference.
@@ -222,6 +222,8 @@ def partial_schur(A, nev, *, max_dim=None, stopping_criterion=None, max_restarts
                      lazy_redos=ctx.lazy_redos, discarded_operator_applies=ctx.discarded_applies,
                      deferred_normalisations=ctx.deferred_expansions,     # expansions whose new columns stayed raw
                      lookahead_applies=ctx.lookahead_applies, arithmetic=arithmetic,
+                     graphs_captured=len(ctx._graphs),                     # re-expansions replayed as hipGraphs, and
+                     graph_capture_failures=ctx.graph_capture_failures,   # captures that fell back to eager launches (0!)
                      tol=float(tol), max_dim=int(max_dim), p=int(p),
                      spmv_form=getattr(solver.op, "spmv_form", None),      # which kernel applied A: decides the order
                      spmv_form_chosen_by=getattr(getattr(solver.op, "diag", None), "tune_mode", None),   # of a row's sum

@@ -1,19 +1,21 @@
-"""Device memory, streams and events of the host layer: through torch (default) or through the HIP runtime alone.
+"""Device memory, streams and events of the host layer: through the HIP runtime alone (default) or through torch.
 
 The C ABI of libarnoldi_hip.so takes raw device pointers and a ``hipStream_t``; what the Python layer needs around it is
 small: allocate / zero / copy buffers, views of rows and sub-blocks, one stream, a few events, pinned staging memory.
 
-``AKS_HOST_ALLOC=torch`` (default when torch is importable)
-                                    torch tensors, torch's current stream -- the host layer then composes with whatever
-                                    else the caller does in torch (torch.distributed carries the multi-rank set-up,
-                                    hipGraph replay uses torch's capture API, tests use torch to inspect results).
-``AKS_HOST_ALLOC=hip``              ``HipArray`` below: hipMalloc / hipMemcpyAsync / hipMemsetAsync / hipHostMalloc /
-                                    events through ctypes on libamdhip64.so.  torch is never imported: the drop-in then
+``AKS_HOST_ALLOC=hip`` (the default)  ``HipArray`` below: hipMalloc / hipMemcpyAsync / hipMemsetAsync / hipHostMalloc /
+                                    events through ctypes on libamdhip64.so.  torch is never imported: the drop-in
                                     needs what the reference needs -- numpy and scipy (the reference's
-                                    dependencies, pyproject.toml:9-13) -- plus the HIP runtime.  hipGraph replay through
-                                    the runtime's capture API; row-sharded solves through ``dist.HostComm`` (TCP
-                                    rendezvous + the library's communicator; ``AKS_COMM=host``).  The default when
-                                    torch cannot be imported.
+                                    dependencies, pyproject.toml:9-13) -- plus the HIP runtime, and it runs on the
+                                    SYSTEM's ROCm (HIP 7.2 / RCCL 2.27 on this image), not on the older runtime a torch
+                                    wheel bundles.  hipGraph replay through the runtime's capture API; row-sharded solves
+                                    through ``dist.HostComm`` (TCP rendezvous + the library's communicator;
+                                    ``AKS_COMM=host``).
+``AKS_HOST_ALLOC=torch``            interop: torch tensors, torch's current stream -- the host layer then composes with
+                                    whatever else the caller does in torch (a torch.distributed process group carries
+                                    the multi-rank set-up, hipGraph replay uses torch's capture API, tests use torch to
+                                    inspect device buffers; the CPU tests drive the host logic on CPU tensors).  The
+                                    backend is chosen once per process, when this module is imported.
 
 Both backends expose the same handful of functions, and their arrays the same handful of methods (``data_ptr``, basic
 slicing, ``view``, ``copy_``, ``zero_``, ``cpu().numpy()``, ``item``), which is all device.py / engine.py use.
@@ -27,10 +29,9 @@ import threading
 import numpy as np
 
 def _default_backend():
-    """torch when it can be imported (not imported here), else the HIP runtime alone -- the reference's own dependency set."""
-    import importlib.util
-
-    return "torch" if importlib.util.find_spec("torch") is not None else "hip"
+    """The HIP runtime alone -- the reference's own dependency set plus ROCm -- whether or not torch is installed (round 6:
+    VERDICT r05 item 4; until then torch was preferred whenever it could be imported)."""
+    return "hip"
 
 
 # hipGraph captures are serialised over the host threads of a process: entering a capture synchronises the device and
@@ -113,6 +114,13 @@ if BACKEND == "torch":
         def replay(self):
             self.g.replay()
 
+        def destroy(self):
+            """Destroy the executable graph NOW (not when the garbage collector gets to it): graphs that captured a
+            communicator's operations must be gone before the communicator is (dist.Comm.close)."""
+            if self.g is not None:
+                self.g.reset()
+                self.g = None
+
 # =============================================================================================== HIP backend
 else:
     c128, f64, u8, i32, i64 = (np.dtype(t) for t in (np.complex128, np.float64, np.uint8, np.int32, np.int64))
@@ -135,7 +143,7 @@ else:
                        "hipEventCreateWithFlags", "hipEventRecord", "hipEventSynchronize", "hipEventDestroy",
                        "hipEventElapsedTime", "hipGetDeviceCount", "hipGetDevice", "hipSetDevice", "hipDeviceSynchronize",
                        "hipStreamBeginCapture", "hipStreamEndCapture", "hipGraphInstantiate", "hipGraphLaunch",
-                       "hipGraphDestroy", "hipGraphExecDestroy"):
+                       "hipGraphDestroy", "hipGraphExecDestroy", "hipRuntimeGetVersion"):
                 getattr(lib, fn).restype = C.c_int
             lib.hipGetErrorString.restype = C.c_char_p
             _rt.lib = lib
@@ -277,10 +285,16 @@ else:
         def replay(self):
             _ck(_rt().hipGraphLaunch(self.exe, C.c_void_p(stream_ptr())), "hipGraphLaunch")
 
+        def destroy(self):
+            """Destroy the executable graph NOW: graphs that captured a communicator's operations must be gone before
+            the communicator is (dist.HostComm.close)."""
+            if self.exe:
+                exe, self.exe = self.exe, C.c_void_p()
+                _ck(_rt().hipGraphExecDestroy(exe), "hipGraphExecDestroy")
+
         def __del__(self):
             try:
-                if self.exe:
-                    _rt().hipGraphExecDestroy(self.exe)
+                self.destroy()
             except Exception:
                 pass
 
@@ -473,12 +487,13 @@ else:
         dtype = np.dtype(dtype)
         nbytes = int(np.prod(shape)) * dtype.itemsize
         device = as_device(device)
-        with _on(device):
+        switched = _on(device)                       # (decided BEFORE entering: inside, the target device is current)
+        with switched:
             alloc = _Allocation(nbytes)
             arr = HipArray(alloc, alloc.ptr.value, shape, shape[1] if len(shape) == 2 else 0, dtype, device)
             if zero and nbytes:
                 _ck(_rt().hipMemsetAsync(alloc.ptr, 0, C.c_size_t(nbytes), C.c_void_p(stream_ptr())), "hipMemsetAsync")
-                if _on(device).ctx is not None:      # zeroed on the OTHER device's stream: done before that stream is left
+                if switched.ctx is not None:         # zeroed on the OTHER device's stream: done before that stream is left
                     _ck(_rt().hipStreamSynchronize(C.c_void_p(stream_ptr())), "hipStreamSynchronize")
         return arr
 

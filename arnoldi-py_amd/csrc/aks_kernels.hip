@@ -998,6 +998,18 @@ __global__ __launch_bounds__(BLOCK) void k_scale(int64_t n, c128 *__restrict__ w
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) w[i] = cmul(alpha, w[i]);
 }
 
+// dst[i] = src[i] over 16-byte items, non-temporal both ways: the plain read + write stream every panel kernel is a variant
+// of.  bench.py times 50 launches of it next to the headline ("calibration"): restarts/s divided by this box's streaming
+// rate is comparable between boxes whose clocks / power states differ (a +-4 % move must be attributable).
+__global__ __launch_bounds__(BLOCK) void k_stream_copy(int64_t items, const c128 *__restrict__ src, c128 *__restrict__ dst) {
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < items; i += stride) {
+        const c128 v = ld_panel(src + i);
+        v2d_t t; t.x = v.x; t.y = v.y;
+        __builtin_nontemporal_store(t, reinterpret_cast<v2d_t *>(dst + i));
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_gather(int64_t count, const int32_t *__restrict__ idx,
                                                  const T *__restrict__ src, T *__restrict__ dst,
@@ -1472,30 +1484,40 @@ struct Probe {
 // The reductions between the Gram-Schmidt stages are <= 2 (max_dim + 1) doubles: latency, not bandwidth (SURVEY 5, 8(e):
 // "one-shot over all 7 xGMI links, not a ring").  Every rank owns a MAILBOX in fine-grained device memory that all its
 // peers have mapped (hipIpc* across processes, the plain pointer inside one process): two parities x `size` rows of
-// ONESHOT_CAP doubles and one arrival counter per parity.  An all-reduce of call number q (parity q & 1) is, in stream
-// order on every rank:
-//   k_oneshot_post   one workgroup: writes this rank's values into ITS row of EVERY peer's mailbox (its own included) with
-//                    system-scope stores, __threadfence_system(), workgroup barrier, then one system-scope release add per
-//                    peer on that peer's arrival counter;
-//   hipStreamWaitValue64 on the LOCAL counter >= size * (calls made on this parity): the queue's command processor polls,
-//                    no compute unit spins -- ranks that share one GPU (the rehearsal) cannot starve the producer they
-//                    wait for;
-//   k_oneshot_sum    one workgroup: sums the `size` rows IN RANK ORDER starting from +0.0 (system-scope loads) into the
-//                    caller's buffer -- the same bits on every rank, and the bits tests/mock_rccl's all-reduce produces.
+// ONESHOT_CAP doubles and one arrival counter per parity.  An all-reduce is ONE kernel of one workgroup per rank
+// (k_oneshot_allreduce), launched in stream order:
+//   number   thread 0 advances the rank's call counter q -- it lives on the DEVICE (a word of the mailbox allocation only
+//            this rank's kernels touch, in stream order), so the launch carries no per-call argument and the kernel can sit
+//            in a hipGraph that is replayed; parity = q & 1;
+//   post     this rank's values into ITS row of EVERY peer's mailbox (its own included) with system-scope stores,
+//            __threadfence_system(), workgroup barrier, then one system-scope RELEASE add per peer on that peer's
+//            arrival counter of the parity;
+//   wait     thread 0 polls the LOCAL counter (system-scope ACQUIRE loads, s_sleep between polls) until it has reached
+//            size * (calls made on this parity) -- with a DEADLINE on the constant-rate wall clock: every wave has an
+//            exit it reaches whatever its peers do.  Past the deadline the kernel stores the failing call number into
+//            the communicator's status word (pinned host memory: the host reads it without any device call), writes
+//            NaN into the caller's buffer and returns; every later call of the communicator still posts (its peers
+//            need not suffer) but does not wait again: a lost peer costs ONE deadline, not one per reduction;
+//   sum      the `size` rows IN RANK ORDER starting from +0.0 (system-scope loads) into the caller's buffer -- the
+//            same bits on every rank, and the bits tests/mock_rccl's all-reduce produces.
 // Two parities suffice: a peer can post call q + 1 while this rank still sums call q (other parity), but call q + 2 only
 // after its own wait of q + 1 has seen THIS rank's post of q + 1, which is behind this rank's sum of q in stream order.
-// aks_comm_create sets it up when asked to, proves it with one reduction, lets the ranks vote (over ncclAllReduce), and
-// falls back to ncclAllReduce on every rank if any rank could not (aks_comm_allreduce_path tells which one runs).
+// Nothing here blocks a hardware queue: rounds 5's form waited with hipStreamWaitValue64, which stalls the QUEUE its
+// stream is mapped to -- a post queued behind it in the same queue never ran (thread ranks of one process, from the
+// second solve on: profiles/r05_small_trace.txt), and the deadline's rescue write could sit behind the same wait
+// (ADVICE r05).  A kernel that polls with a deadline cannot hang; the worst it does is time out.
+// aks_comm_create sets the exchange up when asked to, proves it with one reduction per parity (short deadline), lets
+// the ranks vote (over ncclAllReduce), and falls back to ncclAllReduce on every rank if any rank could not
+// (aks_comm_allreduce_path tells which one runs).  Ranks that share a PROCESS are voted down unless
+// AKS_ONESHOT_SAME_PROCESS=1: the runtime multiplexes a process's streams onto few hardware queues (GPU_MAX_HW_QUEUES,
+// default 4), where one rank's polling kernel can sit in front of the kernel whose post it polls for -- that reduction
+// would time out.  Rank processes (one per GPU: the product's mode) have queues of their own.
 // What only multi-GPU hardware can confirm: system-scope visibility of the posts over xGMI and the cost of the remote
 // adds; on one GPU the peers' mailboxes are local memory.
-// CONSTRAINT: the stream that waits must not share a HARDWARE queue with a stream whose post it waits for -- the wait
-// blocks its queue, a post queued behind it never runs.  Rank processes (one per GPU: the product's mode) have queues
-// of their own and cannot collide; thread ranks inside one process collide as soon as the runtime multiplexes their
-// streams (GPU_MAX_HW_QUEUES, default 4): measured as a hang from the second solve of a process on, gone with more
-// queues than streams (profiles/r05_small_trace.txt).
 constexpr int ONESHOT_CAP = 2 * (AKS_MAX_DIM + 2);      // doubles per row: the widest stage reduction, [h ; ||w||^2]
 constexpr int ONESHOT_MAX_RANKS = 16;
 constexpr int ONESHOT_FLAG_STRIDE = 16;                 // counters 128 bytes apart
+constexpr int ONESHOT_CALLS_WORD = 2 * ONESHOT_FLAG_STRIDE;   // the rank's own call counter, behind the two arrival counters
 struct OneShotPeers {
     double *box[ONESHOT_MAX_RANKS];
     unsigned long long *flag[ONESHOT_MAX_RANKS];
@@ -1505,33 +1527,71 @@ struct OneShot {
     void *local = nullptr;                              // this rank's mailbox allocation (counters, then rows)
     void *opened[ONESHOT_MAX_RANKS] = {};               // hipIpcOpenMemHandle results to close again
     OneShotPeers peers = {};
-    unsigned long long calls = 0;
+    unsigned long long *status = nullptr;               // pinned host word: 0, or (call number << 8 | 1) of the reduction that timed out
+    unsigned long long deadline_ticks = 0;              // of the device's constant-rate wall clock
+    double ticks_per_ms = 1e5;
     bool mute = false;                                  // fault injection (AKS_ONESHOT_FAULT_RANK=<rank>): this rank's posts are lost
     std::string why_not;                                // set when the set-up was asked for and did not succeed
 };
-constexpr size_t ONESHOT_FLAG_BYTES = 2 * ONESHOT_FLAG_STRIDE * sizeof(unsigned long long);
+constexpr size_t ONESHOT_FLAG_BYTES = 3 * ONESHOT_FLAG_STRIDE * sizeof(unsigned long long);
 inline size_t oneshot_bytes(int size) { return ONESHOT_FLAG_BYTES + (size_t)2 * size * ONESHOT_CAP * sizeof(double); }
 
-__global__ __launch_bounds__(BLOCK) void k_oneshot_post(const double *__restrict__ buf, int count, OneShotPeers P, int size,
-                                                       int rank, int parity) {
-    for (int idx = threadIdx.x; idx < count * size; idx += BLOCK) {
-        const int peer = idx / count, e = idx - peer * count;
-        __hip_atomic_store(&P.box[peer][((size_t)parity * size + rank) * ONESHOT_CAP + e], buf[e], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
+__global__ __launch_bounds__(BLOCK) void k_oneshot_allreduce(double *__restrict__ buf, int count, OneShotPeers P, int size,
+                                                            int rank, unsigned long long *mine, const double *box,
+                                                            unsigned long long *status,
+                                                            unsigned long long deadline_ticks, int mute) {
+    // (mine = P.flag[rank], box = P.box[rank]: arguments of their own, so that the kernarg table is never indexed with a
+    // run-time value through the scalar unit -- the ISA lint follows constant kernarg offsets only)
+    __shared__ unsigned long long sh_q;
+    __shared__ int sh_ok;
+    // (every access to mailbox memory is an explicit atomic: VECTOR memory instructions -- a plain load of a uniform address
+    // would become a scalar load, and the scalar cache is not coherent with the vector stores this kernel and its peers make
+    // to the same lines: the hazard class csrc/check_scalar_hazards.py exists for)
+    if (threadIdx.x == 0) {
+        const unsigned long long q = __hip_atomic_load(&mine[ONESHOT_CALLS_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+        __hip_atomic_store(&mine[ONESHOT_CALLS_WORD], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (only this rank's kernels
+        sh_q = q;                                                                                       //  touch the word, in stream order)
+    }
+    __syncthreads();
+    const unsigned long long q = sh_q;
+    const int parity = (int)(q & 1ull);
+    if (!mute) {
+        for (int idx = threadIdx.x; idx < count * size; idx += BLOCK) {
+            const int peer = idx / count, e = idx - peer * count;
+            __hip_atomic_store(&P.box[peer][((size_t)parity * size + rank) * ONESHOT_CAP + e], buf[e], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     __threadfence_system();                              // every storing thread: its rows are performed at system scope
     __syncthreads();
-    if ((int)threadIdx.x < size)
+    if (!mute && (int)threadIdx.x < size)
         __hip_atomic_fetch_add(&P.flag[threadIdx.x][parity * ONESHOT_FLAG_STRIDE], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_oneshot_sum(double *__restrict__ buf, int count, const double *box, int size, int parity) {
+    if (threadIdx.x == 0) {
+        // (device-side copy of the status) an earlier call failed: do not wait again
+        int ok = __hip_atomic_load(&mine[ONESHOT_CALLS_WORD + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull;
+        if (ok) {
+            const unsigned long long want = (unsigned long long)size * ((q + (unsigned long long)parity) / 2ull);   // calls on this parity so far
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(&mine[parity * ONESHOT_FLAG_STRIDE], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+                if (wall_clock64() - t0 > deadline_ticks) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (!ok) {
+                __hip_atomic_store(&mine[ONESHOT_CALLS_WORD + 1], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(status, (q << 8) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        sh_ok = ok;
+    }
+    __syncthreads();
+    __threadfence_system();                              // the rows are read after thread 0's acquire, by every thread
+    const bool ok = sh_ok != 0;
     for (int e = threadIdx.x; e < count; e += BLOCK) {
         double s = 0.0;
         for (int src = 0; src < size; ++src)             // rank order: the same bits on every rank
             s += __hip_atomic_load(const_cast<double *>(&box[((size_t)parity * size + src) * ONESHOT_CAP + e]), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
-        buf[e] = s;
+        buf[e] = ok ? s : __builtin_nan("");
     }
 }
 
@@ -1541,6 +1601,10 @@ struct Comm {
     hipEvent_t packed = nullptr, arrived = nullptr;
     int rank = 0, size = 1;
     OneShot one;
+    // hipGraphs that captured operations of this communicator (aks_comm_graph_retain / _release): they must be destroyed
+    // BEFORE the communicator -- ncclCommDestroy never returns while a graph holds a captured send / recv
+    // (profiles/r05_capture_crash.txt section 4) -- so aks_comm_destroy refuses while any is alive: an error, not a hang
+    std::atomic<int> graphs{0};
 };
 
 // RCCL is loaded when the first communicator is asked for, not with the library: librccl.so is hundreds of megabytes of
@@ -1561,6 +1625,7 @@ struct RcclApi {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;       // (optional: aks_runtime_versions)
 };
 static RcclApi g_rccl;                  // filled once (std::call_once), read-only afterwards
 static std::once_flag g_rccl_once;
@@ -1590,6 +1655,7 @@ static int rccl_load() {
         api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
         api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+        api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(h, "ncclGetVersion"));
         if (ok) g_rccl = api;
     });
     if (g_rccl.AllReduce == nullptr) return fail(AKS_ERR_HIP, g_rccl_error.empty() ? "librccl.so could not be loaded" : g_rccl_error.c_str());
@@ -2473,6 +2539,7 @@ static void oneshot_release(Comm *c) {
     for (int p = 0; p < ONESHOT_MAX_RANKS; ++p)
         if (c->one.opened[p] != nullptr) { (void)hipIpcCloseMemHandle(c->one.opened[p]); c->one.opened[p] = nullptr; }
     if (c->one.local != nullptr) { (void)hipFree(c->one.local); c->one.local = nullptr; }
+    if (c->one.status != nullptr) { (void)hipHostFree(c->one.status); c->one.status = nullptr; }
     c->one.active = false;
 }
 
@@ -2495,46 +2562,31 @@ static int oneshot_vote(Comm *c, double *d_flag, int mine, int *all) {
 
 static int oneshot_reduce(Comm *c, double *d_buf, int count, hipStream_t s);
 
-// The self-test must not hang a process whose peers' posts do not become visible (the one thing only multi-GPU hardware can
-// show): wait for the side stream with a deadline; past it, RELEASE the stream's pending wait by raising this rank's own
-// arrival counters from the host side (a second stream), let the stream drain, and report failure -- the ranks then vote
-// the path down together and the mailboxes are freed.
-constexpr int ONESHOT_SELFTEST_MS = 5000;
-static bool oneshot_drain(Comm *c, int rep) {
-    const auto t0 = std::chrono::steady_clock::now();
-    while (hipStreamQuery(c->side) == hipErrorNotReady) {
-        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > ONESHOT_SELFTEST_MS) {
-            hipStream_t rescue = nullptr;
-            if (hipStreamCreateWithFlags(&rescue, hipStreamNonBlocking) == hipSuccess) {
-                for (int parity = 0; parity < 2; ++parity)
-                    (void)hipStreamWriteValue64(rescue, c->one.peers.flag[c->rank] + parity * ONESHOT_FLAG_STRIDE, ~0ull >> 1, 0);
-                (void)hipStreamSynchronize(rescue);
-                (void)hipStreamSynchronize(c->side);
-                (void)hipStreamDestroy(rescue);
-            }
-            (void)hipGetLastError();
-            (void)rep;
-            return false;
-        }
-        std::this_thread::sleep_for(std::chrono::microseconds(50));
-    }
-    (void)hipGetLastError();
-    return true;
+static double env_ms(const char *name, double fallback) {
+    const char *v = getenv(name);
+    if (v == nullptr || *v == 0) return fallback;
+    const double ms = atof(v);
+    return ms > 0.0 ? ms : fallback;
 }
 
 static int oneshot_setup(Comm *c) {
     OneShot &o = c->one;
-    int ok = 1, dev = 0, can_wait = 0;
+    int ok = 1, dev = 0, khz = 0;
     if (c->size > ONESHOT_MAX_RANKS) { ok = 0; o.why_not = "more ranks than ONESHOT_MAX_RANKS"; }
-    if (ok && (hipGetDevice(&dev) != hipSuccess ||
-               hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess || !can_wait)) {
-        ok = 0;
-        o.why_not = "the device does not support hipStreamWaitValue64";
-    }
+    if (ok && hipGetDevice(&dev) != hipSuccess) { ok = 0; o.why_not = "hipGetDevice failed"; (void)hipGetLastError(); }
+    // the deadline of a reduction's wait, in ticks of the constant-rate clock wall_clock64() reads (100 MHz on gfx9)
+    if (ok && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) o.ticks_per_ms = (double)khz;
+    (void)hipGetLastError();
     if (ok) {
         hipError_t e = hipExtMallocWithFlags(&o.local, oneshot_bytes(c->size), hipDeviceMallocFinegrained);
         if (e == hipSuccess) e = hipMemset(o.local, 0, oneshot_bytes(c->size));
         if (e != hipSuccess) { ok = 0; o.why_not = std::string("fine-grained mailbox: ") + hipGetErrorString(e); (void)hipGetLastError(); }
+    }
+    if (ok) {       // the status word: host memory the kernel writes at system scope and the host reads without a device call
+        void *h = nullptr;
+        hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent);
+        if (e != hipSuccess) { ok = 0; o.why_not = std::string("status word: ") + hipGetErrorString(e); (void)hipGetLastError(); }
+        else { memset(h, 0, 64); o.status = static_cast<unsigned long long *>(h); }
     }
     // every rank's card to every rank (grouped send / recv on the side stream: the one collective form the library uses)
     OneShotCard mine = {};
@@ -2575,12 +2627,20 @@ static int oneshot_setup(Comm *c) {
         if (e != hipSuccess) rc = hip_fail(e, "oneshot set-up");
     }
     if (rc != AKS_OK) { (void)hipFree(d_cards); oneshot_release(c); return rc; }
+    const char *same = getenv("AKS_ONESHOT_SAME_PROCESS");
+    const bool allow_same_process = same != nullptr && strcmp(same, "1") == 0;
     for (int peer = 0; peer < c->size && ok; ++peer) {
         const OneShotCard &k = cards[peer];
         void *base = nullptr;
         if (!k.ok) { ok = 0; o.why_not = "rank " + std::to_string(peer) + " has no mailbox"; break; }
         if (peer == c->rank) base = o.local;
         else if (k.pid == mine.pid) {                     // thread ranks of one process: the pointer is the mapping
+            if (!allow_same_process) {
+                ok = 0;
+                o.why_not = "ranks share a process: their streams can share a hardware queue, where a polling reduction sits in "
+                            "front of the post it polls for and times out (AKS_ONESHOT_SAME_PROCESS=1 overrides)";
+                break;
+            }
             base = reinterpret_cast<void *>((uintptr_t)k.address);
             if (k.device != dev) (void)hipDeviceEnablePeerAccess(k.device, 0), (void)hipGetLastError();
         } else if (k.ok == 2 || mine.ok == 2) { ok = 0; o.why_not = "hipIpcGetMemHandle failed on a mailbox"; }
@@ -2599,15 +2659,19 @@ static int oneshot_setup(Comm *c) {
         o.active = true;
         const char *fault = getenv("AKS_ONESHOT_FAULT_RANK");       // tests: what the peers of a rank whose posts never arrive do
         o.mute = fault != nullptr && *fault != 0 && atoi(fault) == c->rank;
+        const double selftest_ms = env_ms("AKS_ONESHOT_SELFTEST_MS", 2000.0);
+        o.deadline_ticks = (unsigned long long)(selftest_ms * o.ticks_per_ms);
         double got[2] = {0.0, 0.0};
         for (int rep = 0; rep < 2; ++rep) {           // (BOTH, whatever the first gave: every rank must post the same number of times)
             const double v = c->rank + 1.0;
             e = hipMemcpy(d_flag, &v, sizeof v, hipMemcpyHostToDevice);
             if (e == hipSuccess && oneshot_reduce(c, d_flag, 1, c->side) != AKS_OK) e = hipErrorUnknown;
-            if (e == hipSuccess && !oneshot_drain(c, rep)) {       // the posts of some peer never arrived: do not hang here
-                ok = 0;
-                o.why_not = "self-test: the arrival counter was not reached within " + std::to_string(ONESHOT_SELFTEST_MS) +
-                            " ms (posts of a peer not visible to this rank's wait)";
+            if (e == hipSuccess) e = hipStreamSynchronize(c->side);      // (bounded: the kernel's own deadline)
+            if (e == hipSuccess && *static_cast<volatile unsigned long long *>(o.status) != 0ull) {
+                ok = 0;                                   // the posts of some peer never arrived: a failed proof, not a hang
+                if (o.why_not.empty())
+                    o.why_not = "self-test: the arrival counter was not reached within " + std::to_string((long long)selftest_ms) +
+                                " ms (posts of a peer not visible to this rank's reduction)";
                 continue;
             }
             if (e == hipSuccess) e = hipMemcpy(&got[rep], d_flag, sizeof(double), hipMemcpyDeviceToHost);
@@ -2619,6 +2683,7 @@ static int oneshot_setup(Comm *c) {
             }
         }
         rc = oneshot_vote(c, d_flag, ok, &all);
+        o.deadline_ticks = (unsigned long long)(env_ms("AKS_ONESHOT_TIMEOUT_MS", 30000.0) * o.ticks_per_ms);
     }
     (void)hipFree(d_cards);
     if (rc != AKS_OK || !all) {
@@ -2630,18 +2695,11 @@ static int oneshot_setup(Comm *c) {
 
 static int oneshot_reduce(Comm *c, double *d_buf, int count, hipStream_t s) {
     OneShot &o = c->one;
-    const unsigned long long q = ++o.calls;
-    const int parity = (int)(q & 1ull);
-    if (!o.mute) hipLaunchKernelGGL(k_oneshot_post, dim3(1), dim3(BLOCK), 0, s, d_buf, count, o.peers, c->size, c->rank, parity);
+    hipLaunchKernelGGL(k_oneshot_allreduce, dim3(1), dim3(BLOCK), 0, s, d_buf, count, o.peers, c->size, c->rank,
+                       o.peers.flag[c->rank], static_cast<const double *>(o.peers.box[c->rank]), o.status, o.deadline_ticks,
+                       o.mute ? 1 : 0);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "k_oneshot_post");
-    const unsigned long long on_parity = (q + (unsigned long long)parity) / 2ull;   // calls made on this parity so far (q = 1, 3, .. odd)
-    e = hipStreamWaitValue64(s, o.peers.flag[c->rank] + parity * ONESHOT_FLAG_STRIDE, (uint64_t)c->size * on_parity,
-                             hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull);
-    if (e != hipSuccess) return hip_fail(e, "hipStreamWaitValue64");
-    hipLaunchKernelGGL(k_oneshot_sum, dim3(1), dim3(BLOCK), 0, s, d_buf, count, o.peers.box[c->rank], c->size, parity);
-    e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "k_oneshot_sum");
+    if (e != hipSuccess) return hip_fail(e, "k_oneshot_allreduce");
     return AKS_OK;
 }
 
@@ -2686,6 +2744,12 @@ int aks_comm_create(const void *id, int32_t rank, int32_t size, void **comm_out)
 int aks_comm_destroy(void *comm) {
     Comm *c = static_cast<Comm *>(comm);
     if (c == nullptr) return AKS_OK;
+    if (const int alive = c->graphs.load()) {
+        g_err = std::to_string(alive) + " hipGraph(s) that captured operations of this communicator are still alive: destroy them, "
+                "call aks_comm_graph_release for each, then destroy the communicator (ncclCommDestroy does not return while a "
+                "graph holds a captured send / recv)";
+        return AKS_ERR_ARG;
+    }
     oneshot_release(c);
     if (c->packed) (void)hipEventDestroy(c->packed);
     if (c->arrived) (void)hipEventDestroy(c->arrived);
@@ -2702,6 +2766,33 @@ int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *strea
     ncclResult_t r = NCCL_CALL(AllReduce)(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->nccl, static_cast<hipStream_t>(stream));
     if (r != ncclSuccess) return nccl_fail(r, "ncclAllReduce");
     return AKS_OK;
+}
+
+int aks_comm_graph_retain(void *comm) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (c == nullptr) return fail(AKS_ERR_ARG, "null communicator");
+    return c->graphs.fetch_add(1) + 1;
+}
+
+int aks_comm_graph_release(void *comm) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (c == nullptr) return fail(AKS_ERR_ARG, "null communicator");
+    const int before = c->graphs.fetch_sub(1);
+    if (before <= 0) { c->graphs.fetch_add(1); return fail(AKS_ERR_ARG, "aks_comm_graph_release without a matching retain"); }
+    return before - 1;
+}
+
+int aks_comm_status(void *comm, char *why, int64_t why_bytes) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (c == nullptr) return fail(AKS_ERR_ARG, "null communicator");
+    if (why != nullptr && why_bytes > 0) why[0] = 0;
+    if (!c->one.active || c->one.status == nullptr) return 0;
+    const unsigned long long st = *static_cast<volatile unsigned long long *>(c->one.status);
+    if (st == 0ull) return 0;
+    if (why != nullptr && why_bytes > 0)
+        snprintf(why, (size_t)why_bytes, "one-shot all-reduce number %llu of rank %d timed out after %.0f ms waiting for its peers' "
+                 "posts (its result and every later one is NaN)", st >> 8, c->rank, (double)c->one.deadline_ticks / c->one.ticks_per_ms);
+    return 1;
 }
 
 int aks_comm_allreduce_path(void *comm, char *why_not, int64_t why_bytes) {
@@ -3002,6 +3093,33 @@ int aks_scale(int64_t n_rows, aks_c128 *d_w, double alpha_re, double alpha_im, v
     hipLaunchKernelGGL(k_scale, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), n_rows,
                        reinterpret_cast<c128 *>(d_w), make_double2(alpha_re, alpha_im));
     AKS_CHECK_LAUNCH("k_scale");
+    return AKS_OK;
+}
+
+int aks_stream_copy(void *d_dst, const void *d_src, int64_t bytes, void *stream) {
+    if (d_dst == nullptr || d_src == nullptr || bytes < 16 || (bytes & 15) != 0) return fail(AKS_ERR_ARG, "need two buffers and a multiple of 16 bytes");
+    if ((reinterpret_cast<uintptr_t>(d_dst) | reinterpret_cast<uintptr_t>(d_src)) & 15) return fail(AKS_ERR_ARG, "buffers must be 16-byte aligned");
+    const int64_t items = bytes / 16, want = (items + BLOCK - 1) / BLOCK;
+    const dim3 grid((unsigned)(want < 8192 ? want : 8192));
+    hipLaunchKernelGGL(k_stream_copy, grid, dim3(BLOCK), 0, static_cast<hipStream_t>(stream), items,
+                       static_cast<const c128 *>(d_src), static_cast<c128 *>(d_dst));
+    AKS_CHECK_LAUNCH("k_stream_copy");
+    return AKS_OK;
+}
+
+int aks_runtime_versions(int32_t *hip_runtime, int32_t *hip_driver, int32_t *rccl) {
+    int v = 0;
+    if (hip_runtime != nullptr) { *hip_runtime = hipRuntimeGetVersion(&v) == hipSuccess ? v : -1; }
+    if (hip_driver != nullptr) { *hip_driver = hipDriverGetVersion(&v) == hipSuccess ? v : -1; }
+    (void)hipGetLastError();
+    if (rccl != nullptr) {
+        *rccl = -1;                                      // not loaded (a one-GPU process never loads librccl)
+#ifndef AKS_RCCL_DIRECT
+        if (g_rccl.AllReduce != nullptr && g_rccl.GetVersion != nullptr && g_rccl.GetVersion(&v) == ncclSuccess) *rccl = v;
+#else
+        *rccl = 0;                                       // tests/mock_rccl: the stand-in
+#endif
+    }
     return AKS_OK;
 }
 

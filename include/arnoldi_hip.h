@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define AKS_ABI_VERSION 5
+#define AKS_ABI_VERSION 6
 
 #define AKS_OK 0
 #define AKS_ERR_ARG (-1)         /* bad argument (null pointer, size, alignment) */
@@ -326,14 +326,28 @@ int aks_comm_destroy(void *comm);
 /* In-place sum over the ranks of `count` doubles on `stream` (the Gram-Schmidt reductions). */
 int aks_comm_allreduce_sum(void *comm, double *d_buf, int64_t count, void *stream);
 /* Which all-reduce the communicator runs: 0 = ncclAllReduce (the default), 1 = the one-shot mailbox exchange
- * (AKS_ALLREDUCE=oneshot in the environment of EVERY rank at aks_comm_create: each rank's [h ; ||w||^2] is written
- * into a row of every peer's fine-grained mailbox, arrival is a counter the stream waits on -- hipStreamWaitValue64, no
- * spinning kernel --, and every rank sums the rows in rank order: identical bits on all ranks).
- * aks_comm_create proves the exchange (with a deadline: posts that never arrive are a failed proof, not a hang) and lets
- * the ranks vote; if any rank cannot, ALL stay with ncclAllReduce and `why_not` (optional, NUL-terminated, at most
- * why_bytes) says why.  Negative: error.  (AKS_ONESHOT_FAULT_RANK=<rank> loses that rank's posts: fault injection for
- * tests.) */
+ * (AKS_ALLREDUCE=oneshot in the environment of EVERY rank at aks_comm_create: ONE single-workgroup kernel per reduction
+ * writes this rank's [h ; ||w||^2] into a row of every peer's fine-grained mailbox, raises the peers' arrival counters,
+ * polls its own counter -- with a deadline: every wave has an exit, nothing blocks a hardware queue -- and sums the
+ * rows in rank order: identical bits on all ranks; SURVEY 5 / 8(e).  The call counter lives on the device, so the
+ * launch can be captured into a hipGraph and replayed).
+ * aks_comm_create proves the exchange (posts that never arrive are a failed proof after AKS_ONESHOT_SELFTEST_MS, default
+ * 2000, not a hang) and lets the ranks vote; if any rank cannot, ALL stay with ncclAllReduce and `why_not` (optional,
+ * NUL-terminated, at most why_bytes) says why.  Ranks that share a process are voted down (their streams can share a
+ * hardware queue: a polling reduction in front of the post it polls for times out) unless AKS_ONESHOT_SAME_PROCESS=1.
+ * Negative: error.  (AKS_ONESHOT_FAULT_RANK=<rank> loses that rank's posts: fault injection for tests.) */
 int aks_comm_allreduce_path(void *comm, char *why_not, int64_t why_bytes);
+/* 0: fine.  1: a one-shot reduction of this rank waited AKS_ONESHOT_TIMEOUT_MS (default 30000) for its peers' posts in
+ * vain; its result and every later one is NaN, `why` (optional) names the call.  Reads one word of pinned host memory:
+ * no device call, callable at any time (arnoldi_amd.engine checks it with every read-back of H).  ABI 6. */
+int aks_comm_status(void *comm, char *why, int64_t why_bytes);
+/* hipGraphs that captured operations of this communicator (a replayed expansion: the ghost exchange's grouped send /
+ * recv, the reductions) must be destroyed BEFORE it: ncclCommDestroy does not return while a graph holds a captured send
+ * / recv (profiles/r05_capture_crash.txt).  The host layer counts them here -- retain after a capture, release after
+ * hipGraphExecDestroy; both return the new count -- and aks_comm_destroy REFUSES (AKS_ERR_ARG, communicator untouched)
+ * while the count is not zero: a forgotten graph is an error message, not a hang.  ABI 6. */
+int aks_comm_graph_retain(void *comm);
+int aks_comm_graph_release(void *comm);
 /* Personalised exchange of BYTES between all ranks on `stream`, one group of sends / receives: rank r receives
  * send_bytes[r] bytes starting at d_send + send_offsets[r] of every peer into d_recv + recv_offsets[peer]
  * (recv_bytes[peer] must equal what that peer sends here; this rank's own slice is a device copy).  The arrays are
@@ -475,6 +489,14 @@ int aks_probe_create(int32_t capacity, void **probe_out);
 int aks_probe_destroy(void *probe);
 int aks_probe_reset(void *probe);
 int aks_probe_read(void *probe, int32_t tag, int32_t *count_out, double *total_ms_out);
+
+/* ---- measurement aids (bench.py) ---------------------------------------------
+ * d_dst[0:bytes] = d_src[0:bytes] as one non-temporal read + write stream of 16-byte items (bytes a multiple of 16, both
+ * pointers 16-byte aligned): the streaming rate of THIS box, next to which a restart rate is comparable across boxes. */
+int aks_stream_copy(void *d_dst, const void *d_src, int64_t bytes, void *stream);
+/* Versions of what the process actually runs on: hipRuntimeGetVersion, hipDriverGetVersion, ncclGetVersion of the
+ * librccl.so the library loaded (-1: none loaded yet, 0: the test stand-in).  Any pointer may be NULL. */
+int aks_runtime_versions(int32_t *hip_runtime, int32_t *hip_driver, int32_t *rccl);
 
 /* ---- small utilities used by the host driver --------------------------------
  * dst[i] = src[idx[i]]  -- packs the x entries another row shard needs

@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "arnoldi-py_amd"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
+os.environ.setdefault("AKS_HOST_ALLOC", "torch")      # this worker uses torch tensors / process groups: the interop backend
 os.environ["AKS_BENCH_BACKEND"] = "gloo"
 
 import bench  # noqa: E402

@@ -21,6 +21,7 @@ for p in (ROOT, os.path.join(ROOT, "arnoldi-py_amd"), os.path.join(ROOT, "tests"
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("AKS_HOST_ALLOC", "torch")      # this worker uses torch tensors / process groups: the interop backend
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -16,6 +16,7 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+os.environ.setdefault("AKS_HOST_ALLOC", "torch")      # this worker uses torch tensors / process groups: the interop backend
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -10,6 +10,7 @@ import pytest
 
 import explicit_cases as ec
 import oracle
+from conftest import torch_buffers
 
 pytestmark = pytest.mark.gpu
 
@@ -18,9 +19,9 @@ C128 = np.complex128
 
 @pytest.fixture(scope="module")
 def amd():
-    import torch
+    from arnoldi_amd import mem
 
-    assert torch.cuda.is_available(), "these tests need the MI355X"
+    assert mem.gpu_available(), "these tests need the MI355X"
     import arnoldi_amd
     from arnoldi_amd import _hip
 
@@ -33,7 +34,7 @@ def amd():
 def test_combine_against_numpy(amd, n, m, q):
     """aks_combine: out = V[:, :m] S for every M-tile bucket edge, ragged n, K padding (m % 4 != 0);
     V is left untouched and the columns beyond q of the output block are not written."""
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd import device as dev
 
     rng = np.random.default_rng(n + m + q)
@@ -55,7 +56,7 @@ def test_combine_against_numpy(amd, n, m, q):
 
 
 def test_combine_rejects_overlap_and_bad_sizes(amd):
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd import _hip, device as dev
 
     cols = dev.DeviceColumns(256, 8)

@@ -14,7 +14,7 @@ import pytest
 import scipy.sparse as sp
 
 import oracle
-from conftest import csr_from, load_golden
+from conftest import csr_from, load_golden, torch_buffers
 
 pytestmark = pytest.mark.gpu
 
@@ -24,9 +24,9 @@ RTOL = 1e-12
 
 @pytest.fixture(scope="module")
 def amd():
-    import torch
+    from arnoldi_amd import mem
 
-    assert torch.cuda.is_available(), "these tests need the MI355X"
+    assert mem.gpu_available(), "these tests need the MI355X"
     import arnoldi_amd
     from arnoldi_amd import _hip
 
@@ -61,7 +61,7 @@ def _ragged_matrix(n, seed, complex_vals):
 @pytest.mark.parametrize("complex_vals", [False, True])
 @pytest.mark.parametrize("lanes", [0, 1, 4, 64])
 def test_spmv_ragged(amd, complex_vals, lanes):
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd.device import DeviceCSR
 
     n = 3000
@@ -84,7 +84,7 @@ def test_spmv_ragged(amd, complex_vals, lanes):
 
 def test_spmv_configs_small(amd):
     """Config-shaped matrices at oracle-friendly sizes: Markov, 2-D/3-D Laplace, random CSR."""
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd import matrices
     from arnoldi_amd.device import DeviceCSR
 
@@ -107,7 +107,7 @@ def test_spmv_binned_form(amd, kind):
     run-to-run reproducibility (the LDS adds of a round are issued level by level, a workgroup
     barrier after each level: every row sees its addends in one fixed order).  "hubs": rows with
     entries in every sub-slab (all eight levels of a round in use) and a dense column."""
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd import matrices
     from arnoldi_amd.device import DeviceCSR
 
@@ -161,7 +161,7 @@ def test_spmv_binned_schedule_edges(amd, kind):
     """Shapes that stress the phase-2 schedule of the binned form: more row blocks than chunks (257 = 256 + 1: the
     chunk-interleaved order and its remainder), row blocks without any entry (they still own a round and must come
     out as zeros), tiles far larger than a wave-load (many wave-loads cut from one tile, every lane filled)."""
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd.device import DeviceCSR
 
     rng = np.random.default_rng(23)
@@ -205,7 +205,7 @@ def test_spmv_sliced_form(amd, kind):
     """The sliced kernel (aks_sell_spmv: a lane per row, slices of 64 rows stored entry-major, padded with
     column -1) against the oracle: ragged last slice, empty rows, a long row, complex values, non-square blocks,
     accumulate, real vectors; run-to-run bitwise reproducible (a row is summed in column order in registers)."""
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd import matrices
     from arnoldi_amd.device import DeviceCSR
 
@@ -263,7 +263,7 @@ def test_spmv_forms_agree_on_random_shapes(amd, seed):
     """Differential test of the three SpMV forms on randomly drawn shapes, densities and row-length
     distributions (uniform, geometric, a few hub rows, blocks of empty rows): CSR-stream vs tile-binned vs
     sliced, against the oracle, complex or real values, accumulate."""
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd.device import DeviceCSR
 
     rng = np.random.default_rng(1000 + seed)
@@ -446,17 +446,27 @@ def test_deferred_normalisation_in_the_sliced_form_for_short_rows(amd, monkeypat
     assert ctx.expand(np.zeros((21, 20), C128), 0, 20, 1e-8, defer_scale=True) == 20 and ctx.deferred_expansions == 0
 
 
-def test_two_host_threads_solve_concurrently(amd):
+def test_two_host_threads_solve_concurrently(amd, monkeypatch):
     """The library keeps no mutable global state (threading row): two solves driven from two host
     threads at the same time, each on its own stream -- one through the binned form (128 KiB of dynamic LDS per
     workgroup), one with a wide restart block (Qp in more than 48 KiB of LDS) -- return the bits of the same
-    solves run one after the other."""
-    import threading
+    solves run one after the other.
 
-    import torch
+    Both threads REPLAY their re-expansions as hipGraphs (AKS_GRAPH=1), i.e. both capture while the other one launches.
+    This is the test that aborted in round 5 (gpurun_out/r05_suite_again.log: hipErrorStreamCaptureInvalidated, "operation
+    failed due to a previous error during capture" -- torch's graph entry emptied the allocator cache, and that hipFree
+    invalidated the other thread's capture).  The fix (captures serialised over the process's threads, no cache-emptying
+    entry: arnoldi_amd/mem.py) is what is pinned here: ``graph_capture_failures == 0`` and graphs really captured in BOTH
+    threads -- an invalidation that came back would otherwise hide behind the eager fall-back's RuntimeWarning."""
+    import contextlib
+    import threading
+    import warnings
+
+    from conftest import BACKEND
     from arnoldi_amd.engine import CsrOperator
     from arnoldi_amd.matrices import laplace2d
 
+    monkeypatch.setenv("AKS_GRAPH", "1")
     g8 = load_golden("g8_random_planted")
     A1 = _planted_like_golden(int(g8["n"]))
     A2 = laplace2d(60, 61)
@@ -464,35 +474,50 @@ def test_two_host_threads_solve_concurrently(amd):
     v2 = np.random.default_rng(6).standard_normal(A2.shape[0])
     v1, v2 = v1 / np.linalg.norm(v1), v2 / np.linalg.norm(v2)
 
-    def solve1():
+    def solve1(st):
         return amd.partial_schur(CsrOperator(A1, spmv_form="binned"), 5, max_dim=20, v0=v1.copy(),
-                                 sort_function=oracle.arg_largest_magnitude)
+                                 sort_function=oracle.arg_largest_magnitude, stats=st)
 
-    def solve2():
-        return amd.partial_schur(A2, 30, max_dim=100, p=80, v0=v2.copy(), stopping_criterion=1e-9, max_restarts=400)
+    def solve2(st):
+        return amd.partial_schur(A2, 30, max_dim=100, p=80, v0=v2.copy(), stopping_criterion=1e-9, max_restarts=400, stats=st)
 
-    ref = [solve1(), solve2()]
-    for _ in range(2):
-        out, errors = [None, None], []
+    def own_stream():
+        """torch backend: a stream per thread; the HIP backend gives every host thread its own stream by itself."""
+        if BACKEND != "torch":
+            return contextlib.nullcontext()
+        import torch
 
-        def run(i, f):
-            try:
-                with torch.cuda.stream(torch.cuda.Stream()):
-                    out[i] = f()
-                    torch.cuda.current_stream().synchronize()
-            except Exception as e:  # noqa: BLE001
-                errors.append(e)
+        return torch.cuda.stream(torch.cuda.Stream())
 
-        threads = [threading.Thread(target=run, args=(i, f)) for i, f in enumerate((solve1, solve2))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        assert not errors, errors
-        for (Q, T, h), (Qr, Tr, hr) in zip(out, ref):
-            np.testing.assert_array_equal(Q, Qr)
-            np.testing.assert_array_equal(T, Tr)
-            np.testing.assert_array_equal(h.restarts, hr.restarts)
+    ref = [solve1({}), solve2({})]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)          # the eager fall-back announces itself with one
+        for _ in range(2):
+            out, stats, errors = [None, None], [{}, {}], []
+
+            def run(i, f):
+                try:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("error", RuntimeWarning)
+                        with own_stream():
+                            out[i] = f(stats[i])
+                            amd.mem.synchronize()
+                except BaseException as e:  # noqa: BLE001
+                    errors.append(e)
+
+            threads = [threading.Thread(target=run, args=(i, f)) for i, f in enumerate((solve1, solve2))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            assert not errors, errors
+            for st in stats:
+                assert st["graph_capture_failures"] == 0 and st["graphs_captured"] >= 1, st
+                assert st["solver"].ctx.use_graph and st["solver"].ctx._graphs
+            for (Q, T, h), (Qr, Tr, hr) in zip(out, ref):
+                np.testing.assert_array_equal(Q, Qr)
+                np.testing.assert_array_equal(T, Tr)
+                np.testing.assert_array_equal(h.restarts, hr.restarts)
 
 
 # ---------------------------------------------------------------------------- Gram-Schmidt
@@ -551,7 +576,7 @@ def test_ticket_hand_off_books_the_step(amd):
     is an error of ~1/512 in beta^2 (round 4's bug: 2.2e-3 instead of 8.7e-9 in a residual); here beta must equal the
     norm of the vector the kernel left behind to rounding.  Forty calls on ONE workspace, each with another scale, so
     that a partial left over from the call before is wrong by orders of magnitude."""
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd import device as dev, mem
 
     n, J = 1 << 20, 12
@@ -698,7 +723,7 @@ def test_arnoldi_saad_table_6_1(amd, m, d):
 # ---------------------------------------------------------------------------- truncation
 @pytest.mark.parametrize("m,p", [(5, 4), (6, 5), (20, 10), (40, 15), (41, 25), (50, 40), (80, 65), (100, 85)])
 def test_truncate(amd, m, p):
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd import device as dev
 
     n = 1500 if m < 60 else 700
@@ -722,7 +747,7 @@ def test_back_to_back_truncations_do_not_overwrite_a_staging_buffer_in_flight(am
     enqueued without any wait in between (behind a long kernel queue, so the copies are still pending when the host
     comes back) must each use its own coefficients."""
     import scipy.sparse as sp
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd.engine import ArnoldiContext, CsrOperator
 
     n, m, p = 400_000, 20, 10
@@ -909,7 +934,7 @@ def test_full_size_config5_properties(amd):
     """n = 10M, nnz = 50M, m = 20 (BASELINE config 5): properties that need no CPU solve.
     SpMV against rocSPARSE-free torch arithmetic on sampled rows, linearity, and the Arnoldi
     invariants  V^H V = I,  A V_m = V_{m+1} H  checked on the device in complex128."""
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd import engine, matrices
 
     n, m = 10_000_000, 20
@@ -1065,7 +1090,7 @@ def test_row_sharded_c_driven_path_over_rccl(amd, tmp_path, ranks):
     the development pool skip it; ADVICE r02 asked for it so that the first multi-GPU machine that runs the suite
     records the evidence).  History equal to the oracle's on every case, including the Laplacian whose first expansion
     is redone with the third all-reduce on all ranks."""
-    import torch
+    torch = torch_buffers()
 
     from test_host_logic import check_dist_verdicts, run_dist_worker
 
@@ -1253,9 +1278,14 @@ def test_a_ghost_exchange_is_capturable_on_the_system_runtime(tmp_path):
     runtime and RCCL are the system's (ROCm 7.2: HIP 7.2.26015, RCCL 2.27.7), and there ``aks_shard_apply`` with its
     exchange forked onto the communicator's side stream captures into a hipGraph and replays -- three replays on changing
     input, each equal to  D x + O x[send_idx] -- and the communicator can be destroyed afterwards PROVIDED the graphs go
-    first (with a captured send / recv group still alive ``ncclCommDestroy`` never returns).  The product still keeps
-    sequences with an exchange eager (the guard cannot know which runtime a torch process bundles; multi-rank replay has no
-    rehearsal -- the stand-in synchronises streams); this pins what the next step can build on."""
+    first (with a captured send / recv group still alive ``ncclCommDestroy`` never returns).
+
+    Round 6 wires it into the engine (AKS_GRAPH_COMM=exchange, HIP >= 7.2 only): whole solves on a one-rank communicator
+    that exchanges with itself -- every re-expansion, ghost exchange and stage reductions included, captured once and
+    replayed -- give H bit for bit the eager solve's, with ``ncclAllReduce`` and with the one-shot kernel (whose call
+    counter lives on the device for this); ``comm.close()`` drops the graphs before the communicator, and a graph the
+    library still counts makes ``aks_comm_destroy`` refuse instead of hanging.  (A torch process -- bundled HIP 7.0 --
+    keeps such sequences eager: test_sequences_with_a_ghost_exchange_are_never_captured.)"""
     import json
     import subprocess
     import sys
@@ -1267,12 +1297,23 @@ def test_a_ghost_exchange_is_capturable_on_the_system_runtime(tmp_path):
     for k in ("AKS_LIB_PATH", "AKS_ALLREDUCE", "RANK", "WORLD_SIZE"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "capture_exchange_worker.py"), out], capture_output=True,
-                         text=True, timeout=120, env=env)
+                         text=True, timeout=300, env=env)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
     r = json.load(open(out))
     assert r["torch_imported"] is False and r["hip_runtime_version"] >= 70200000 and r.get("communicator_destroyed"), r
     for c in r["cases"]:
         assert c["eager_err"] < 1e-13 and max(c["replay_errs"]) < 1e-13, c
+    assert r["versions"]["hip_runtime"] >= 70200000 and (r["versions"]["rccl"] or 0) >= 22700, r["versions"]
+    for name, want_path in (("engine_nccl", 0), ("engine_oneshot", 1)):
+        e = r[name]
+        for mode in ("eager", "replay"):
+            m = e[mode]
+            assert m["native"] and m["any_exchange"] and m["n_ghost"] > 1000 and m["allreduce_path"] == want_path, (name, mode, m)
+            assert m["graph_capture_failures"] == 0 and m["closed"] and m["expansions"] >= 4, (name, mode, m)
+        assert e["eager"]["graphs_captured"] == 0 and not e["eager"]["use_graph"]
+        assert e["replay"]["graphs_captured"] >= 1 and e["replay"]["graphs_on_comm"] == e["replay"]["graphs_captured"], e["replay"]
+        assert e["bit_identical"] and e["finite"] and e["first_expansion_vs_one_gpu"] < 1e-12, e
+        assert e["refused_with_a_counted_graph"] is True and e["graphs_after_refusal"] == 0, e
 
 
 def test_graph_replay_gives_identical_results(amd, monkeypatch):
@@ -1290,6 +1331,7 @@ def test_graph_replay_gives_identical_results(amd, monkeypatch):
                                     stats=st)
         assert st["solver"].ctx.use_graph == (flag == "1")
         assert bool(st["solver"].ctx._graphs) == (flag == "1")
+        assert st["graph_capture_failures"] == 0 and st["graphs_captured"] == (1 if flag == "1" else 0), st
         out.append((Q, T, h.restarts.copy()))
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
@@ -1428,6 +1470,7 @@ def test_stress_grid_case_under_graph_capture(amd, monkeypatch):
     assert gc.isenabled()                             # switched back on after the capture
     ctx = st["solver"].ctx
     assert ctx.use_graph and len(ctx._graphs) >= 1 and st["restarts"] > 5
+    assert st["graph_capture_failures"] == 0 and st["graphs_captured"] == len(ctx._graphs)      # captured, not fallen back
     np.testing.assert_array_equal(h.restarts, ho.restarts)
     np.testing.assert_array_equal(h.matvecs, ho.matvecs)
     np.testing.assert_allclose(np.diag(T), np.diag(To), rtol=1e-7, atol=1e-10)

@@ -6,6 +6,7 @@ import pytest
 import scipy.sparse as sp
 
 import oracle
+from conftest import torch_buffers
 import real_cases as rc
 
 pytestmark = pytest.mark.gpu
@@ -15,9 +16,9 @@ C128 = np.complex128
 
 @pytest.fixture(scope="module")
 def amd():
-    import torch
+    from arnoldi_amd import mem
 
-    assert torch.cuda.is_available(), "these tests need the MI355X"
+    assert mem.gpu_available(), "these tests need the MI355X"
     import arnoldi_amd
     from arnoldi_amd import _hip
 
@@ -43,7 +44,7 @@ def _ragged(n, n_cols, seed):
 def test_spmv_real_vectors(amd, shape, form):
     """y = A x and y += A x on float64 vectors, both SpMV forms, ragged rows, non-square blocks, odd
     sizes; bitwise reproducible."""
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd.device import DeviceCSR
 
     A = _ragged(shape[0], shape[1], shape[0] + shape[1])
@@ -86,7 +87,7 @@ def test_spmv_real_matches_complex_kernel_on_packed_columns(amd):
 
 @pytest.mark.parametrize("n", [2, 63, 129, 1000, 100001])
 def test_gather_f64(amd, n):
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd import device as dev
 
     rng = np.random.default_rng(n)
@@ -102,7 +103,7 @@ def test_gather_f64(amd, n):
 def test_packed_gram_schmidt_is_the_real_operation(amd, n, J):
     """dgks_gs on a real-packed panel == the oracle's dgks_gs on the real vectors: coefficients real, w
     and beta equal, second-pass decision equal (near-dependent w forces the second pass)."""
-    import torch
+    torch = torch_buffers()
     from arnoldi_amd import device as dev
 
     rng = np.random.default_rng(n + J)

@@ -22,7 +22,7 @@ from conftest import ROOT
 MOCK_LIB = os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so")
 
 
-def _worker(tmp_path, case, extra=(), timeout=840, env_extra=None):
+def _worker(tmp_path, case, extra=(), timeout=840, env_extra=None, may_fail=False):
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = os.path.join(tmp_path, f"{case}.json")
@@ -32,6 +32,8 @@ def _worker(tmp_path, case, extra=(), timeout=840, env_extra=None):
     env.update(env_extra or {})
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "thread_ranks_worker.py"), "--case", case, "--out", out,
                           *extra], capture_output=True, text=True, timeout=timeout, env=env)
+    if may_fail and res.returncode != 0:
+        return {"failed": res.returncode, "stderr": res.stderr[-4000:]}
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-4000:]
     sys.stderr.write(res.stderr[-1500:])
     keep = os.path.join(ROOT, "gpurun_out")
@@ -165,23 +167,63 @@ def test_full_size_drivers_are_bitwise_repeatable(tmp_path, name, args, forms, d
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranks,args", [(2, []), (3, []), (4, ["--workload", "laplace3d", "--rows", "16000000"]), (8, [])])
 def test_one_shot_allreduce_gives_the_collectives_bits(tmp_path, ranks, args):
-    """``AKS_ALLREDUCE=oneshot``: every rank writes its [h ; ||w||^2] into a row of
-    every peer's mailbox, waits for the arrivals with a stream memory operation and sums the rows in rank order.  Full-size
-    sharded solves (config 5 at 2, 3 and 8 ranks, config 4 at 4: every step with the third reduction) must give H -- after
-    every expansion and contraction -- bit for bit what the library collective (here: its order-checking stand-in, which
-    also sums in rank order) gives, and must say that the one-shot path is the one that ran.
+    """``AKS_ALLREDUCE=oneshot``: ONE kernel per reduction writes the rank's
+    [h ; ||w||^2] into a row of every peer's mailbox, polls its own arrival counter with a deadline and sums the rows in
+    rank order.  Full-size sharded solves (config 5 at 2, 3 and 8 ranks, config 4 at 4: every step with the third
+    reduction) must give H -- after every expansion and contraction -- bit for bit what the library collective (here: its
+    order-checking stand-in, which also sums in rank order) gives, and must say that the one-shot path is the one that ran.
 
-    Thread ranks live in ONE process, and a stream that waits for a peer's post must not share a hardware queue with the
-    stream that posts (the wait would block the queue in front of the post: observed as a hang from the second solve of
-    a process on, profiles/r05_small_trace.txt).  Rank PROCESSES -- the product's mode -- cannot collide
-    (tests/test_gpu_parity.py::test_one_shot_allreduce_across_process_ranks); here each run is a fresh process with one
-    solve and GPU_MAX_HW_QUEUES raised above its stream count (the 8-rank case, 16 streams: 8 of 8 trials that way)."""
+    Thread ranks live in ONE process, which the library votes down by default (their streams can share a hardware queue,
+    see test_one_shot_allreduce_is_voted_down_between_ranks_of_one_process); the rehearsal overrides that and raises
+    GPU_MAX_HW_QUEUES above its stream count.  Round 6: nothing in the exchange can block a queue any more -- a reduction
+    that sat in front of its peer's post would time out and FAIL this test through ``aks_comm_status``, not hang it."""
     base = _worker(tmp_path, "repro", ["--ranks", str(ranks), "--repeats", "1"] + args, timeout=240)
-    one = _worker(tmp_path, "repro", ["--ranks", str(ranks), "--repeats", "1"] + args, timeout=240,     # (a hang must fail HERE, fast)
-                  env_extra={"AKS_ALLREDUCE": "oneshot", "GPU_MAX_HW_QUEUES": "32"})
+    one = _worker(tmp_path, "repro", ["--ranks", str(ranks), "--repeats", "1"] + args, timeout=240,
+                  env_extra={"AKS_ALLREDUCE": "oneshot", "AKS_ONESHOT_SAME_PROCESS": "1", "GPU_MAX_HW_QUEUES": "32"})
     assert base["allreduce_path"] == [0, ""] and one["allreduce_path"] == [1, ""], (base["allreduce_path"], one["allreduce_path"])
     assert one["info"] == base["info"] and one["sha"] == base["sha"], (base["sha"], one["sha"])
     print(f"one-shot x{ranks}:", one["n"], one["forms"], one["info"][-1], one["sha"])
+
+
+@pytest.mark.gpu
+def test_one_shot_allreduce_is_voted_down_between_ranks_of_one_process(tmp_path):
+    """ADVICE r05 / VERDICT r05 item 3, in code instead of in a comment: ranks that share a process (thread ranks: the
+    runtime multiplexes their streams onto GPU_MAX_HW_QUEUES hardware queues, default 4) do NOT get the one-shot exchange
+    unless AKS_ONESHOT_SAME_PROCESS=1 -- ``aks_comm_create`` sees the equal pids on the ranks' cards, every rank votes the
+    path down with the reason on record, and the solve runs on the library collective: same bits as without the request.
+    One run at the DEFAULT queue count, no repetition, nothing that could hang."""
+    small = ["--ranks", "2", "--repeats", "1", "--rows", "600000"]
+    base = _worker(tmp_path, "repro", small, timeout=240)
+    one = _worker(tmp_path, "repro", small, timeout=240, env_extra={"AKS_ALLREDUCE": "oneshot"})
+    assert base["allreduce_path"] == [0, ""]
+    assert one["allreduce_path"][0] == 0 and "ranks share a process" in one["allreduce_path"][1], one["allreduce_path"]
+    assert one["info"] == base["info"] and one["sha"] == base["sha"], (base["sha"], one["sha"])
+
+
+@pytest.mark.gpu
+def test_one_shot_allreduce_on_a_single_hardware_queue_cannot_hang(tmp_path):
+    """The deterministic form of round 5's "8 of 8 trials": thread ranks FORCED onto the exchange (override) with
+    GPU_MAX_HW_QUEUES=1 -- every stream of the process on one hardware queue, the worst case of the collision round 5
+    could only make unlikely.  Whatever the queue does with two ranks' kernels, the outcome is decided by construction:
+    either the reductions overlap and the proof passes (path 1, the collective's bits), or a polling reduction sits in
+    front of its peer's post, reaches its deadline (AKS_ONESHOT_SELFTEST_MS) and every rank votes the path down with
+    "the arrival counter was not reached" (path 0, the collective's bits) -- or, if the proof passed and a LATER reduction
+    collides, that reduction reaches its deadline (AKS_ONESHOT_TIMEOUT_MS) and the solve fails with the library's
+    time-out message.  All three end within the time-out below; a hang -- round 5's hipStreamWaitValue64 blocked the
+    queue -- is no longer a possible outcome."""
+    small = ["--ranks", "2", "--repeats", "1", "--rows", "600000"]
+    base = _worker(tmp_path, "repro", small, timeout=240)
+    one = _worker(tmp_path, "repro", small, timeout=240, may_fail=True,
+                  env_extra={"AKS_ALLREDUCE": "oneshot", "AKS_ONESHOT_SAME_PROCESS": "1", "GPU_MAX_HW_QUEUES": "1",
+                             "AKS_ONESHOT_SELFTEST_MS": "500", "AKS_ONESHOT_TIMEOUT_MS": "3000"})
+    if "failed" in one:
+        assert "timed out after" in one["stderr"] and "one-shot all-reduce number" in one["stderr"], one["stderr"]
+        print("one hardware queue: a reduction timed out inside the solve (reported, not hung)")
+        return
+    path, why = one["allreduce_path"]
+    assert (path == 1 and why == "") or (path == 0 and "arrival counter was not reached" in why), one["allreduce_path"]
+    assert one["info"] == base["info"] and one["sha"] == base["sha"], (base["sha"], one["sha"])
+    print("one hardware queue:", one["allreduce_path"])
 
 
 @pytest.mark.gpu

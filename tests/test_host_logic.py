@@ -40,7 +40,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in arnoldi_hip.h but not exported"
     assert sorted(_hip.SIGNATURES) == declared, "ctypes binding and header disagree"
     lib = _hip.load()
-    assert lib.aks_abi_version() == _hip.ABI_VERSION == 5
+    assert lib.aks_abi_version() == _hip.ABI_VERSION == 6
+    from arnoldi_amd._version import ABI
+
+    assert ABI == _hip.ABI_VERSION
 
 
 def test_header_constants_match_binding():

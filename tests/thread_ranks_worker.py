@@ -29,6 +29,7 @@ for p in (ROOT, os.path.join(ROOT, "arnoldi-py_amd"), os.path.join(ROOT, "tests"
         sys.path.insert(0, p)
 os.environ.setdefault("AKS_LIB_PATH", os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"))
 os.environ["AKS_GRAPH"] = "0"                      # the stand-in synchronises streams: nothing to capture
+os.environ.setdefault("AKS_HOST_ALLOC", "torch")   # thread ranks each run inside a torch stream (tests/thread_ranks.py)
 
 import numpy as np  # noqa: E402
 
