@@ -12,17 +12,31 @@ The matrix has no dominant eigenvalues, so the solve never converges: K restarts
 For N > 1 the same n = 10M problem is row-sharded over the ranks (strong scaling); without
 torch.distributed.run around it, ``--gpus N`` starts its own N ranks (one process per GPU).
 
+The ranks run on the package's DEFAULT backend -- device memory, stream and events from the HIP runtime itself, ranks
+bootstrapped over ``dist.HostComm`` (TCP rendezvous next to MASTER_PORT + the library's own RCCL communicator), no torch in
+the process -- i.e. on the system's ROCm.  ``AKS_HOST_ALLOC=torch`` selects the torch interop backend instead.
+
 The line printed by rank 0 also carries
   roofline        live HIP-event timing of the SpMV launches inside the timed region,
                   algorithmic bytes (12 nnz + 36 n + 4) / average launch time vs 8 TB/s;
   roofline_ortho  the same for the Gram-Schmidt launches of the timed region;
+  runtime         allocator backend, hipRuntimeGetVersion / hipDriverGetVersion, RCCL version, whether torch is in the process;
+  device          sclk / mclk / power / temperature from ``rocm-smi --json`` (child process) before and after the timed region;
+  calibration     GB/s of the library's plain read + write stream (``aks_stream_copy``, 50 launches) before and after, and
+                  value / calibration -- comparable across boxes whose clocks differ;
   workloads       (N = 1) the other matrices of BASELINE.json -- Markov n = 10M (config 1 scaled), the 2-D Laplacian
                   of config 2, the banded and the shell-structured stand-ins for config 3 and the 3-D Laplacian of config 4 (on one GPU) --
-                  through the same measurement, a few restarts each;
+                  through the same measurement, a few restarts each; (N > 1) Markov, 3-D Laplace and the real-packed
+                  headline matrix, row-sharded over the same ranks;
   real_arithmetic (N = 1) the same default workload with partial_schur(arithmetic="real");
   cpu_baseline    (N = 1) the CPU oracle (NumPy/SciPy restatement of the reference, validated against
-                  the reference's golden outputs) timed on this host at the full problem size.
-The three extra legs run in child processes after the headline measurement, so nothing in them can
+                  the reference's golden outputs) timed on this host at the full problem size;
+  legs            (N > 1) the headline solve in the OTHER configurations, each in child processes started before the ranks
+                  touch their GPUs, each under a time-out: ``oneshot`` (AKS_ALLREDUCE=oneshot), ``torch_backend`` (torch's
+                  allocator + process group: its bundled HIP / RCCL), ``allreduce_probe`` (both all-reduce paths in isolation),
+                  ``one_gpu_shard`` (the restart on n / N rows on one GPU: the measured terms of ``prediction_model``) --
+                  restarts/s, all-reduce us per call, path taken, per-SpMV split and runtime versions per leg.
+The N = 1 extra legs run in child processes after the headline measurement, so nothing in them can
 cost the run its line; a failed leg is reported as {"error": ...} inside the line.
 """
 import argparse
@@ -91,7 +105,7 @@ def parse_args(argv=None):
     ap.add_argument("--probe-every", type=int, default=1,
                     help="record the HIP-event pairs around the SpMV / Gram-Schmidt launches in every K-th restart of "
                          "the timed region (1 = every restart)")
-    ap.add_argument("--leg", choices=["measure", "cpu", "preflight", "allreduce_probe"], default=None,
+    ap.add_argument("--leg", choices=["measure", "cpu", "preflight", "allreduce_probe", "solve"], default=None,
                     help="(internal) run one extra leg and print its JSON object")
     return ap.parse_args(argv)
 
@@ -547,26 +561,32 @@ def _measure(args, comm, world, rank):
 
 
 # The scaling model of DESIGN section 4 for the headline matrix, so that ONE record of the driver's 1/2/4/8 sweep shows
-# which term misses it: kernel times of the one-GPU run divided by N, the ghost exchange at the per-direction link rate
-# over the N - 1 point-to-point links of a rank, the small reductions at a latency each.
-MODEL_ONE_GPU = {"spmv_ms": 0.481, "gram_schmidt_ms_per_step": 0.864, "compression_ms": 0.965, "host_ms_per_restart": 0.16,
-                 "source": "BENCH_r04.json, one MI355X, random CSR n=10M k=5 m=20"}
-MODEL_LINK_GBS = 50.0          # per direction per xGMI link, as DESIGN 4 assumes
-MODEL_ALLREDUCE_US = 25.0      # one <= 656-byte all-reduce over 8 GPUs
+# which term misses it.  Its one-GPU terms are MEASURED in the same invocation (round 6; they were constants copied from
+# BENCH_r04 before): the "one_gpu_shard" leg runs a shard-sized problem -- n / N rows of the same generator, one GPU, the
+# same restart -- on rank 0's GPU before the ranks touch theirs, the all-reduce latency comes from the same invocation's
+# probe of the default path; only the link rate stays an assumption, and says so.
+MODEL_LINK_GBS = 50.0          # per direction per xGMI link, as DESIGN 4 assumes (the one term no one-GPU box can measure)
+MODEL_ALLREDUCE_US = 25.0      # fall-back when the invocation's probe has no number
 
 
-def predicted_restarts_per_s(world, m, p, ghost_bytes_per_spmv, collectives_per_step):
-    """restarts/s of the headline workload on ``world`` GPUs by DESIGN section 4's model (see MODEL_* above)."""
+def predicted_restarts_per_s(world, m, p, ghost_bytes_per_spmv, collectives_per_step, shard, allreduce_us=None):
+    """restarts/s of the headline workload on ``world`` GPUs by DESIGN section 4's model.  ``shard``: the one-GPU leg of this
+    invocation on n / world rows (``spmv_avg_ms``, ``ortho_avg_ms_per_step``, ``ms_per_step``)."""
     steps = m - p
+    ar_us = float(allreduce_us) if allreduce_us else MODEL_ALLREDUCE_US
     exch_ms = ghost_bytes_per_spmv / (MODEL_LINK_GBS * 1e9 * max(world - 1, 1)) * 1e3 if world > 1 else 0.0
     reductions = max(int(collectives_per_step) - 1, 0) if world > 1 else 0
-    step_ms = exch_ms + (MODEL_ONE_GPU["spmv_ms"] + MODEL_ONE_GPU["gram_schmidt_ms_per_step"]) / world \
-        + reductions * MODEL_ALLREDUCE_US * 1e-3
-    restart_ms = steps * step_ms + MODEL_ONE_GPU["compression_ms"] / world + MODEL_ONE_GPU["host_ms_per_restart"]
-    return 1e3 / restart_ms, {"exchange_ms_per_spmv": round(exch_ms, 4), "kernels_ms_per_step": round(step_ms - exch_ms, 4),
-                              "reductions_per_step": reductions, "restart_ms": round(restart_ms, 3),
-                              "link_GBs_per_direction": MODEL_LINK_GBS, "allreduce_us": MODEL_ALLREDUCE_US,
-                              "one_gpu": MODEL_ONE_GPU}
+    kernels_ms = shard["spmv_avg_ms"] + shard["ortho_avg_ms_per_step"]
+    # compression + host Schur step of the shard's restart, from the EAGER restart time (a sharded expansion is launched eagerly)
+    rest_ms = max(shard.get("ms_per_step_eager_probed", shard["ms_per_step"]) - steps * kernels_ms, 0.0)
+    step_ms = exch_ms + kernels_ms + reductions * ar_us * 1e-3
+    restart_ms = steps * step_ms + rest_ms
+    return 1e3 / restart_ms, {"exchange_ms_per_spmv": round(exch_ms, 4), "kernels_ms_per_step": round(kernels_ms, 4),
+                              "reductions_per_step": reductions, "compression_plus_host_ms": round(rest_ms, 4),
+                              "restart_ms": round(restart_ms, 3), "link_GBs_per_direction_ASSUMED": MODEL_LINK_GBS,
+                              "allreduce_us": round(ar_us, 2),
+                              "allreduce_us_source": "this invocation's probe (ncclAllReduce)" if allreduce_us else "assumed",
+                              "one_gpu_terms": "measured in this invocation (one_gpu_shard leg)"}
 
 
 def spmv_kernel_name(res, world):
@@ -659,6 +679,8 @@ def leg_summary(res, args, world=1):
            "spmv_frac": round(res["achieved"] / HBM_PEAK_GBS, 4) if res["achieved"] else None,
            "ortho_achieved_GBs": res["ortho"]["achieved"] if res["ortho"] else None,
            "ortho_frac": res["ortho"]["frac"] if res["ortho"] else None,
+           "ortho_avg_ms_per_step": res["ortho"]["avg_ms_per_step"] if res["ortho"] else None,
+           "ms_per_step_eager_probed": res["ms_per_step"],
            "second_pass_fraction": round(res["frac_second"], 3), "setup_s": round(res["setup_s"], 2)}
     o_traffic, o_ratio, _ = pmc_ortho_traffic(res, args, world)
     if o_traffic is not None:
@@ -690,25 +712,198 @@ def run_child(extra_argv, timeout_s):
     return {"error": f"exit status {cp.returncode}: " + " | ".join(tail)}
 
 
-# ------------------------------------------------------------------------------------------- multi-rank preflight
+# ------------------------------------------------------------------------------------------- the ranks' two layers
+def backend_kind():
+    """"hip" (the package's default: HIP runtime allocator, ``dist.HostComm`` between ranks, no torch in the process) or
+    "torch" (``AKS_HOST_ALLOC=torch``: torch allocator and streams, a torch.distributed process group between ranks)."""
+    return os.environ.get("AKS_HOST_ALLOC") or "hip"
+
+
+class Ranks:
+    """This process's place among the ranks, on either backend: ``comm`` (None on one GPU without AKS_FORCE_COMM), and how
+    to leave again.  Creating it on the hip backend touches NO GPU until ``attach_gpu()`` -- the pre-GPU legs run in
+    between."""
+
+    def __init__(self, args):
+        self.kind = backend_kind()
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world} (start the ranks with "
+                             f"torch.distributed.run --nproc-per-node {args.gpus}, or drop WORLD_SIZE and let "
+                             f"`bench.py --gpus {args.gpus}` start them)")
+        self.forced = os.environ.get("AKS_FORCE_COMM") == "1" and self.world == 1     # a one-rank communicator whose collectives run
+        self.comm = None
+        self.gloo = os.environ.get("AKS_BENCH_BACKEND", "nccl") != "nccl"             # torch kind: ranks share the visible GPU(s)
+        if self.kind == "hip" and (self.world > 1 or self.forced):
+            from arnoldi_amd.dist import HostComm
+
+            self.comm = HostComm(rank=self.rank, size=self.world, force=self.forced) if self.forced else HostComm()
+
+    def attach_gpu(self):
+        global GPU
+        from arnoldi_amd import mem
+
+        if self.kind == "hip":
+            GPU = mem.gpu_available()
+            if GPU:
+                mem.set_device(self.local_rank % max(mem.device_count(), 1))
+            return
+        import torch
+        import torch.distributed as dist
+        from arnoldi_amd.dist import Comm
+
+        GPU = torch.cuda.is_available()
+        local = self.local_rank % max(torch.cuda.device_count(), 1) if self.gloo else self.local_rank
+        if GPU:
+            torch.cuda.set_device(local)
+        if self.world > 1:
+            if self.gloo:
+                dist.init_process_group(os.environ.get("AKS_BENCH_BACKEND"))
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            self.comm = Comm()
+        elif self.forced:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+            self.comm = Comm(force=True)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.barrier()
+            self.comm.close()                      # the library's own RCCL communicator, if one was made (graphs first)
+            if self.kind == "torch":
+                import torch.distributed as dist
+
+                dist.destroy_process_group()
+            self.comm = None
+
+    def release_device_memory(self):
+        import gc
+
+        gc.collect()
+        if self.kind == "torch" and GPU:
+            sys.modules["torch"].cuda.empty_cache()
+
+    def all_ok(self, ok):
+        """Whether ``ok`` holds on every rank (one small exchange; True alone on one rank)."""
+        if self.comm is None or self.world == 1:
+            return bool(ok)
+        return all(int(v[0]) for v in self.comm.allgather_int64([1 if ok else 0]))
+
+    def describe(self):
+        from arnoldi_amd import mem
+
+        if self.kind == "hip":
+            return "dist.HostComm (TCP rendezvous + aks_comm_alltoallv), AKS_HOST_ALLOC=" + mem.BACKEND
+        return "torch.distributed (" + ("gloo, ranks share the GPU" if self.gloo else "nccl") + "), AKS_HOST_ALLOC=" + mem.BACKEND
+
+
+def runtime_block():
+    """What the numbers of this process ran on: allocator backend, HIP runtime / driver, RCCL (None while none is loaded)."""
+    from arnoldi_amd import _hip, mem
+
+    out = {"backend": mem.BACKEND, "torch_in_process": "torch" in sys.modules}
+    try:
+        out.update(_hip.runtime_versions())
+    except Exception as e:                                   # noqa: BLE001  (a stand-in library without the entry: reported, not fatal)
+        out["versions_error"] = str(e)[:120]
+    return out
+
+
+# ------------------------------------------------------------------------------------------- device state + calibration
+def device_telemetry(index=0, timeout_s=20):
+    """Clocks, power and temperature of GPU ``index`` from ``rocm-smi --json`` in a child process -- sampled once before and
+    once after the timed region, never inside it -- so that a +-4 % move of the headline between two driver records can
+    be attributed (r04 -> r05 moved by -3.6 % with nothing in the record to say whether it was the box)."""
+    cmd = ["rocm-smi", "-d", str(index), "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"]
+    try:
+        cp = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        data = json.loads(cp.stdout[cp.stdout.index("{"):])
+        card = data.get(f"card{index}") or next(iter(data.values()))
+    except Exception as e:                                   # noqa: BLE001  (no rocm-smi, no permission: reported, not fatal)
+        return {"error": f"{type(e).__name__}: {str(e)[:100]}"}
+
+    def pick(*needles, number=True):
+        for k, v in card.items():
+            if all(n in k.lower() for n in needles):
+                if not number:
+                    return v
+                digits = "".join(ch for ch in str(v).replace("Mhz", "").replace("MHz", "") if ch.isdigit() or ch == ".")
+                try:
+                    return float(digits)
+                except ValueError:
+                    return v
+        return None
+
+    return {"sclk_mhz": pick("sclk", "clock"), "mclk_mhz": pick("mclk", "clock"), "fclk_mhz": pick("fclk", "clock"),
+            "power_w": pick("power", "(w)") if pick("power", "(w)") is not None else pick("power"),
+            "temp_c": pick("temperature", "junction") if pick("temperature", "junction") is not None else pick("temperature"),
+            "perf_level": pick("performance level", number=False)}
+
+
+def stream_copy_calibration(launches=50, mib=256):
+    """GB/s of the library's plain non-temporal read + write stream (``aks_stream_copy``: 16-byte items, the access pattern
+    every panel kernel is a variant of) over ``launches`` back-to-back copies of ``mib`` MiB between two device events:
+    the streaming rate of THIS box, now.  ``value / calibration`` is comparable across boxes."""
+    import ctypes as C
+
+    from arnoldi_amd import _hip, mem
+
+    nbytes = mib << 20
+    device = mem.as_device(None)
+    src, dst = mem.zeros(nbytes // 8, mem.f64, device), mem.empty(nbytes // 8, mem.f64, device)
+    lib, stream = _hip.load(), C.c_void_p(mem.stream_ptr())
+    for _ in range(3):
+        _hip.check(lib.aks_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, stream), "aks_stream_copy")
+    e0, e1 = mem.Event(enable_timing=True), mem.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        lib.aks_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, stream)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1)
+    del src, dst
+    return round(2.0 * nbytes * launches / (ms * 1e-3) / 1e9, 1)
+
+
+# ------------------------------------------------------------------------------------------- legs of the N > 1 line
+def run_own_child(leg_argv, env, timeout_s):
+    """One child process of THIS rank (``bench.py <leg_argv>``); its last JSON line, or {"error": ...}.  Started before
+    the rank has touched its GPU -- a fresh child, never a re-exec of a process that has initialised the GPU."""
+    proc = subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + leg_argv, env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        so, se = proc.communicate(timeout=timeout_s)
+        for ln in reversed(so.splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": f"exit status {proc.returncode}: " + " | ".join((se or so).strip().splitlines()[-3:])[-600:]}
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return {"error": f"timed out after {timeout_s} s"}
+
+
 def preflight_child(args):
-    """``--leg preflight`` (one process per rank, started by ``native_preflight``): the C-driven collective path
-    (aks_arnoldi_expand issuing the ghost exchange and the stage all-reduces on the library's RCCL communicator)
-    against the Python-chained torch.distributed path on two small row-sharded problems -- a random graph (nearly
-    every remote entry is exchanged) and a 2-D Laplacian (every step needs the second DGKS pass: the lazy third
-    all-reduce is found out and the expansion repeated on all ranks).  Prints {"ok": ..} and exits."""
-    import torch
-    import torch.distributed as dist
-    from arnoldi_amd import matrices
-    from arnoldi_amd.dist import Comm, row_offsets
+    """``--leg preflight`` (one child per rank): the C-driven collective path (aks_arnoldi_expand issuing the ghost
+    exchange and the stage all-reduces on the library's communicator) against the Python-chained path on two small
+    row-sharded problems -- a random graph (nearly every remote entry is exchanged) and a 2-D Laplacian (every step needs
+    the second DGKS pass: the lazy third all-reduce is found out and the expansion repeated on all ranks).  On whichever
+    backend the environment selects.  Prints {"ok": ..} and exits."""
+    from arnoldi_amd import matrices, mem
+    from arnoldi_amd.dist import row_offsets
     from arnoldi_amd.engine import CsrOperator
     from arnoldi_amd.krylov_schur import KrylovSchurSolver
     from arnoldi_amd.utils import arg_largest_magnitude
 
-    world, rank, local_rank = (int(os.environ[k]) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    out = {"ok": True, "world": world}
+    os.environ["AKS_FORCE_COMM"] = "1" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else os.environ.get("AKS_FORCE_COMM", "0")
+    ranks = Ranks(args)
+    ranks.attach_gpu()
+    world, rank = ranks.world, ranks.rank
+    out = {"ok": True, "world": world, "runtime": None}
     cases = (("random", matrices.random_csr(60_000 * world, 5, 7, planted=(4.0, 3.7, 3.4, 3.1, 2.8, 2.5)), 5, 20, 3),
              ("laplace2d", matrices.laplace2d(200, 40 * world + 1), 6, 24, 2))
     for name, A, nev, m, restarts in cases:
@@ -718,7 +913,7 @@ def preflight_child(args):
         got = {}
         for path in ("native", "python"):
             os.environ["AKS_DIST_PATH"] = path
-            comm = Comm(force=(world == 1))
+            comm = ranks.comm                                 # (native() answers None while AKS_DIST_PATH=python)
             op = CsrOperator(local_rows=rows, offsets=offs, comm=comm)
             np.random.seed(0)
             solver = KrylovSchurSolver(op, nev, m, min(nev + 5, m - 1), 1e-10, arg_largest_magnitude, comm=comm)
@@ -728,147 +923,174 @@ def preflight_child(args):
                 solver.contract(i)
                 solver.expand()
                 Hs.append(solver.H.copy())
-            torch.cuda.synchronize()
+            mem.synchronize()
             got[path] = (np.stack(Hs), bool(op.native_comm), int(solver.ctx.lazy_redos), int(op.n_ghost))
-            comm.close()
+            del solver, op
+        os.environ.pop("AKS_DIST_PATH", None)
         (Hn, nat, redo_n, ghosts), (Hp, nat_p, redo_p, _) = got["native"], got["python"]
         err = float(np.abs(Hn - Hp).max() / max(np.abs(Hp).max(), 1e-300))
         ok = nat and not nat_p and err < 1e-12 and redo_n == redo_p and np.isfinite(Hn).all()
         out[name] = {"ok": bool(ok), "max_rel_diff_H": err, "native_comm": nat, "lazy_redos": redo_n, "n_ghost_rank": ghosts}
         out["ok"] = out["ok"] and bool(ok)
-    flag = torch.tensor([1 if out["ok"] else 0], device="cuda")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    out["ok"] = bool(flag.item())
-    dist.barrier()
-    dist.destroy_process_group()
+    out["ok"] = ranks.all_ok(out["ok"])
+    out["runtime"] = runtime_block()
+    ranks.close()
     print(json.dumps(out), flush=True)
     return 0
 
 
 def allreduce_probe_child(args):
-    """``--leg allreduce_probe`` (one process per rank, started by ``native_preflight`` AFTER the path check, with its own
-    time-out): what the small reductions between the Gram-Schmidt stages cost on THIS machine through each of the two
-    implementations -- ``ncclAllReduce`` and the one-shot mailbox exchange (AKS_ALLREDUCE=oneshot) -- 42 doubles, a batch of
-    200 back-to-back calls between two events, every rank.  On a multi-GPU node this is the number round 5 could not
-    measure; a failure, a hang or a crash here costs the probe, nothing else."""
+    """``--leg allreduce_probe`` (one child per rank, its own time-out): what the small reductions between the Gram-Schmidt
+    stages cost on THIS machine through each of the two implementations -- ``ncclAllReduce`` and the one-shot mailbox
+    kernel (AKS_ALLREDUCE=oneshot) -- 42 doubles, a batch of 200 back-to-back calls between two events, every rank.  On a
+    multi-GPU node this is the number no one-GPU box can produce; a failure, a time-out or a crash here
+    costs the probe, nothing else."""
     import ctypes as C
 
-    import torch
-    import torch.distributed as dist
-    from arnoldi_amd import _hip
-    from arnoldi_amd.dist import Comm
+    from arnoldi_amd import _hip, mem
 
-    world, rank, local_rank = (int(os.environ[k]) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    lib, out = _hip.load(), {"world": world}
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    os.environ["AKS_FORCE_COMM"] = "1" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else os.environ.get("AKS_FORCE_COMM", "0")
+    ranks = Ranks(args)
+    ranks.attach_gpu()
+    lib, comm, out = _hip.load(), ranks.comm, {"world": ranks.world}
     for name, env in (("nccl", None), ("oneshot", "oneshot")):
         if env is None:
             os.environ.pop("AKS_ALLREDUCE", None)
         else:
             os.environ["AKS_ALLREDUCE"] = env
-        comm = Comm(force=(world == 1))
+        comm._destroy_native()                                # (second pass: a NEW library communicator on the same rank layer)
         handle = comm.native()
+        stream = C.c_void_p(mem.stream_ptr())
         why = C.create_string_buffer(256)
         path = lib.aks_comm_allreduce_path(handle, why, 256)
-        buf = torch.full((42,), float(rank + 1), dtype=torch.float64, device="cuda")
+        world, rank = ranks.world, ranks.rank
+        buf = mem.upload(np.full(42, float(rank + 1)), mem.as_device(None))
         _hip.check(lib.aks_comm_allreduce_sum(handle, C.c_void_p(buf.data_ptr()), 42, stream), "allreduce")
-        torch.cuda.synchronize()
-        ok = bool(abs(float(buf[0].item()) - world * (world + 1) / 2) < 1e-9)
+        ok = bool(abs(float(np.asarray(buf.cpu().numpy())[0]) - world * (world + 1) / 2) < 1e-9)
         best = None
         for _ in range(3):
-            buf.fill_(1e-300)                                    # (200 sums of N equal terms stay finite)
-            dist.barrier()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            buf.copy_(mem.host(np.full(42, 1e-300)))                # (200 sums of N equal terms stay finite)
+            mem.synchronize()
+            comm.barrier()
+            e0, e1 = mem.Event(enable_timing=True), mem.Event(enable_timing=True)
             e0.record()
             for _ in range(200):
                 lib.aks_comm_allreduce_sum(handle, C.c_void_p(buf.data_ptr()), 42, stream)
             e1.record()
-            torch.cuda.synchronize()
+            e1.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / 200
             best = us if best is None else min(best, us)
+        _hip.comm_status(handle)
         out[name] = {"path": "one-shot mailbox exchange" if path == 1 else "ncclAllReduce", "why_not_oneshot": why.value.decode() or None,
                      "sum_ok": ok, "device_us_per_call": round(best, 2)}
-        comm.close()
-    t = torch.tensor([out["nccl"]["device_us_per_call"], out["oneshot"]["device_us_per_call"]], device="cuda", dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    out["slowest_rank_us_per_call"] = {"nccl": round(float(t[0]), 2), "oneshot": round(float(t[1]), 2)}
-    dist.barrier()
-    dist.destroy_process_group()
+    out["slowest_rank_us_per_call"] = {k: round(ranks.comm.max_float(out[k]["device_us_per_call"]), 2) for k in ("nccl", "oneshot")}
+    out["runtime"] = runtime_block()
+    ranks.close()
     print(json.dumps(out), flush=True)
     return 0
 
 
-def run_probe_child(leg, env, timeout_s):
-    """One child process of this rank; its last JSON line, or {"error": ...}."""
-    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--leg", leg], env=env,
-                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    try:
-        so, se = proc.communicate(timeout=timeout_s)
-        for ln in reversed(so.splitlines()):
-            if ln.startswith("{"):
-                return json.loads(ln)
-        return {"error": f"exit status {proc.returncode}: " + " | ".join((se or so).strip().splitlines()[-3:])}
-    except subprocess.TimeoutExpired:
-        proc.kill()
-        proc.communicate()
-        return {"error": f"timed out after {timeout_s} s"}
+def solve_leg_child(args):
+    """``--leg solve`` (one child per rank): the HEADLINE measurement in the configuration the child's environment selects
+    (AKS_ALLREDUCE, AKS_HOST_ALLOC, ...), reduced to what the legs of the N > 1 line report: restarts/s, the per-SpMV
+    split, the all-reduce time per call and the path taken, and what it ran on."""
+    ranks = Ranks(args)
+    ranks.attach_gpu()
+    res = measure(args, ranks.comm, ranks.world, ranks.rank)
+    out = {"ok": True}
+    if ranks.rank == 0:
+        ex = res["exchange"] or {}
+        out.update(restarts_per_s=res["value"], ms_per_step=res["ms_per_step"], steps=args.steps, warmup=args.warmup,
+                   path="C-driven (aks_arnoldi_expand)" if res["native"] else "python-chained",
+                   allreduce_path=ex.get("allreduce_path"),
+                   allreduce_device_us_per_call_rank0=ex.get("allreduce_device_us_per_call_rank0"),
+                   allreduce_device_ms_per_step_rank0=ex.get("allreduce_device_ms_per_step_rank0"),
+                   spmv_device_ms_rank0=ex.get("spmv_device_ms_rank0"), spmv_avg_ms=round(res["spmv_avg_ms"], 4),
+                   ortho_avg_ms_per_step=res["ortho"]["avg_ms_per_step"] if res["ortho"] else None,
+                   lazy_redos=ex.get("lazy_redos"), setup_s=round(res["setup_s"], 2), rank_layer=ranks.describe(),
+                   runtime=runtime_block())
+    ranks.close()
+    print(json.dumps(out), flush=True)
+    return 0
 
 
-def native_preflight(world, rank, local_rank, timeout_s=300):
-    """The C-driven RCCL path has only ever met one GPU per developer box; the first time several GPUs see it is the
-    driver's scaling run.  So before THIS process touches its GPU, every rank starts a child (``--leg preflight``,
-    own rendezvous port, same GPU) that checks the path against the torch.distributed one, with a time-out: a
-    child that fails, hangs or crashes costs a minute, and the measurement then runs on the Python-chained path
-    (all ranks agree through a gloo group that never touches a GPU) instead of taking the whole run down.
-    Returns the verdict dict; sets AKS_DIST_PATH=python if it failed."""
-    import torch.distributed as dist
+LEG_TIMEOUT_S = {"preflight": 240, "allreduce_probe": 150, "oneshot": 300, "torch_backend": 480, "one_gpu_shard": 300}
 
-    dist.init_process_group("gloo")
-    port = [free_port() if rank == 0 else None]
-    dist.broadcast_object_list(port, src=0)
-    env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port[0]),
-               RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world))
-    env.pop("AKS_DIST_PATH", None)
-    for k in [k for k in env if k.startswith("TORCHELASTIC_") or k.startswith("TORCH_NCCL_ASYNC")]:
-        env.pop(k)        # under torch.distributed.run the ranks are clients of the agent's store; the children's rank 0
-                          # has to host a store of its own on the fresh port
-    verdict = {"ok": False}
-    t0 = time.perf_counter()
-    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--leg", "preflight"], env=env,
-                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    try:
-        so, se = proc.communicate(timeout=timeout_s)
-        for ln in reversed(so.splitlines()):
-            if ln.startswith("{"):
-                verdict = json.loads(ln)
-                break
+
+def pre_gpu_legs(args, ranks):
+    """N > 1 (or a forced one-rank communicator), BEFORE this process touches its GPU: every rank starts one child per leg
+    -- fresh processes with their own rendezvous, each under a time-out; a leg that fails, hangs or crashes costs itself,
+    nothing else -- so that the FIRST record a multi-GPU node produces decides between the configurations instead of
+    measuring one of them:
+
+      preflight       the C-driven collective path against the chained one on two small problems; if it fails on any
+                      rank the measurement below runs with AKS_DIST_PATH=python (all ranks agree through the rendezvous);
+      allreduce_probe ncclAllReduce and the one-shot kernel timed in isolation, side by side;
+      oneshot         the headline solve with AKS_ALLREDUCE=oneshot;
+      torch_backend   the headline solve on the torch interop backend: torch's allocator and process group, i.e. the HIP /
+                      RCCL a torch wheel bundles (7.0 / 2.26 here) instead of the system's ROCm (7.2 / 2.27);
+      one_gpu_shard   rank 0 only, one GPU: the same restart on n / N rows -- the model's kernel terms, measured.
+
+    ``value`` of the line stays the DEFAULT configuration's (this backend, ncclAllReduce), measured by the ranks themselves
+    afterwards.  Returns {leg: report}."""
+    hub = ranks.comm._hub
+    world, rank = ranks.world, ranks.rank
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    names = ["preflight", "allreduce_probe", "oneshot", "torch_backend", "one_gpu_shard"]
+    skip = set(filter(None, os.environ.get("AKS_BENCH_SKIP_LEGS", "").split(",")))
+    ports = hub.gather(json.dumps([free_port() for _ in names]).encode() if rank == 0 else b"")[0]
+    ports = dict(zip(names, json.loads(ports.decode())))
+    base_env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(ranks.local_rank), WORLD_SIZE=str(world), MASTER_ADDR=host)
+    for k in [k for k in base_env if k.startswith("TORCHELASTIC_") or k.startswith("TORCH_NCCL_ASYNC")] + ["AKS_DIST_PATH", "AKS_RENDEZVOUS"]:
+        base_env.pop(k, None)     # under torch.distributed.run the ranks are clients of the agent's store; the children's
+                                  # rank 0 hosts a store / rendezvous of its own on the fresh port
+    steps, warmup = str(min(args.steps, 5)), "2"
+    solve = ["--gpus", str(world), "--rows", str(args.n), "--per-row", str(args.per_row), "--nev", str(args.nev), "--max-dim",
+             str(args.max_dim), "--workload", args.workload, "--steps", steps, "--warmup", warmup, "--leg", "solve"]
+    if args.matrix:
+        solve += ["--matrix", args.matrix]
+    plan = {
+        "preflight": (["--gpus", str(world), "--leg", "preflight"], {}),
+        "allreduce_probe": (["--gpus", str(world), "--leg", "allreduce_probe"], {}),
+        "oneshot": (solve, {"AKS_ALLREDUCE": "oneshot"}),
+        "torch_backend": (solve, {"AKS_HOST_ALLOC": "torch"}),
+    }
+    out = {}
+    for name in names:
+        if name in skip or (name == "allreduce_probe" and os.environ.get("AKS_BENCH_ALLREDUCE_PROBE", "1") == "0"):
+            continue
+        t0 = time.perf_counter()
+        if name == "one_gpu_shard":
+            report = {"skipped": "not the headline workload at N > 1"}
+            if world > 1 and args.workload == "random" and args.matrix is None:
+                report = None
+                if rank == 0:                                 # one GPU, one process: rank 0's; the others wait at the gather below
+                    env = dict(base_env, RANK="0", LOCAL_RANK=str(ranks.local_rank), WORLD_SIZE="1")
+                    env.pop("AKS_FORCE_COMM", None)
+                    report = run_own_child(["--gpus", "1", "--rows", str(max(args.n // world, 1000)), "--per-row", str(args.per_row),
+                                            "--nev", str(args.nev), "--max-dim", str(args.max_dim), "--steps", steps, "--warmup",
+                                            warmup, "--leg", "measure"], env, LEG_TIMEOUT_S[name])
+            ok_everywhere = all(b == b"y" for b in hub.gather(b"y"))
         else:
-            verdict = {"ok": False, "error": f"exit status {proc.returncode}: " + " | ".join((se or so).strip().splitlines()[-3:])}
-    except subprocess.TimeoutExpired:
-        proc.kill()
-        proc.communicate()
-        verdict = {"ok": False, "error": f"timed out after {timeout_s} s"}
-    import torch
-
-    flag = torch.tensor([1 if verdict.get("ok") else 0])
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    verdict["all_ranks_ok"] = bool(flag.item())
-    verdict["seconds"] = round(time.perf_counter() - t0, 1)
-    if verdict["all_ranks_ok"] and os.environ.get("AKS_BENCH_ALLREDUCE_PROBE", "1") != "0":
-        # the two all-reduce implementations, timed side by side in children of their own (they cannot hurt this process)
-        port = [free_port() if rank == 0 else None]
-        dist.broadcast_object_list(port, src=0)
-        probe = run_probe_child("allreduce_probe", dict(env, MASTER_PORT=str(port[0])), 120)
-        if rank == 0:
-            verdict["allreduce_probe"] = probe
-    dist.barrier()
-    dist.destroy_process_group()
-    if not verdict["all_ranks_ok"]:
+            leg_argv, extra = plan[name]
+            env = dict(base_env, MASTER_PORT=str(ports[name]), AKS_RENDEZVOUS=f"{host}:{ports[name]}", **extra)
+            if world == 1:
+                env["AKS_FORCE_COMM"] = "1"
+            report = run_own_child(leg_argv, env, LEG_TIMEOUT_S[name])
+            mine_ok = "error" not in report and report.get("ok", True) is not False
+            votes = [b == b"y" for b in hub.gather(b"y" if mine_ok else b"n")]
+            ok_everywhere = all(votes)
+            if not ok_everywhere and mine_ok:
+                report = dict(report, error=f"failed on rank {votes.index(False)}")
+        if report is not None:
+            report["all_ranks_ok"] = bool(ok_everywhere)
+            report["seconds"] = round(time.perf_counter() - t0, 1)
+            out[name] = report
+    pre = out.get("preflight")
+    if pre is not None and not pre["all_ranks_ok"]:
         os.environ["AKS_DIST_PATH"] = "python"
-        sys.stderr.write(f"bench.py: rank {rank}: native RCCL preflight failed ({verdict}); using AKS_DIST_PATH=python\n")
-    return verdict
+        sys.stderr.write(f"bench.py: rank {rank}: preflight of the C-driven collective path failed ({pre}); using AKS_DIST_PATH=python\n")
+    return out
 
 
 # ------------------------------------------------------------------------------------------- rank main
@@ -881,15 +1103,18 @@ def emit(line):
 _REAL_STDOUT = 1
 
 
-def model_fields(res, args, world):
-    """``predicted_restarts_per_s`` next to the measured ``value`` (N > 1, headline workload at its BASELINE size only:
-    the model's one-GPU terms are that workload's)."""
+def model_fields(res, args, world, legs=None):
+    """``predicted_restarts_per_s`` next to the measured ``value`` (N > 1, headline workload): DESIGN section 4's model with
+    the one-GPU terms and the all-reduce latency MEASURED in this invocation's legs."""
     ex = res.get("exchange")
-    if world <= 1 or not ex or args.workload != "random" or args.matrix is not None or res["n"] != 10_000_000 \
-            or (res["nev"], res["m"]) != (5, 20) or args.arithmetic != "complex":
+    shard = (legs or {}).get("one_gpu_shard") or {}
+    if world <= 1 or not ex or args.workload != "random" or args.matrix is not None or args.arithmetic != "complex" \
+            or "error" in shard or not shard.get("spmv_avg_ms") or not shard.get("ortho_avg_ms_per_step"):
         return {}
+    probe = (legs or {}).get("allreduce_probe") or {}
+    ar_us = (probe.get("slowest_rank_us_per_call") or {}).get("nccl")
     rate, parts = predicted_restarts_per_s(world, res["m"], res["p"], ex["ghost_bytes_received_per_spmv_rank0"],
-                                           ex["collectives_per_arnoldi_step"])
+                                           ex["collectives_per_arnoldi_step"], shard, ar_us)
     return {"predicted_restarts_per_s": round(rate, 2), "prediction_model": parts}
 
 
@@ -1003,121 +1228,60 @@ def sharded_legs(args, comm, world, rank, log=None):
     return legs
 
 
-def run_rank_torch_free(args):
-    """``AKS_COMM=host``: the ranks of ``--gpus N`` without torch in the process -- ``dist.HostComm`` (TCP rendezvous + the
-    library's own communicator) and the HIP runtime's allocator; rank r takes GPU ``LOCAL_RANK`` (modulo the GPUs that
-    exist: a one-GPU rehearsal shares it).  The same ``measure`` / ``headline`` / sharded legs as the torch ranks; no
-    preflight (that compares the C-driven path with the torch.distributed one) and no child-process legs."""
-    global GPU
-    os.environ.setdefault("AKS_HOST_ALLOC", "hip")
-    from arnoldi_amd import mem
-    from arnoldi_amd.dist import HostComm
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-    GPU = mem.gpu_available()
-    if GPU:
-        mem.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(mem.device_count(), 1))
-    comm = HostComm() if world > 1 else None
-    res = measure(args, comm, world, rank)
-    out = headline(res, args, world, False, None) if rank == 0 else None
-    if rank == 0:
-        out["config"]["rank_layer"] = "dist.HostComm (TCP rendezvous + aks_comm_alltoallv), AKS_HOST_ALLOC=" + mem.BACKEND
-    if world > 1 and args.workload == "random" and args.arithmetic == "complex" and not args.no_workloads:
-        legs = sharded_legs(args, comm, world, rank)
-        if rank == 0:
-            out["workloads"] = legs
-    if comm is not None:
-        comm.barrier()
-        comm.close()
-    if rank == 0:
-        out["torch_in_process"] = "torch" in sys.modules
-        emit(json.dumps(out))
-    return 0
-
-
 def run_rank(args, argv):
+    """One rank: (hip kind, N > 1) pre-GPU legs in child processes; then the measurement on the default configuration; the
+    sharded legs (N > 1) or the child-process legs (N = 1); ONE line from rank 0."""
     global _REAL_STDOUT
     sys.stdout.flush()
     _REAL_STDOUT = os.dup(1)
     os.dup2(2, 1)
-    if os.environ.get("AKS_COMM") == "host" and args.leg is None:
-        return run_rank_torch_free(args)
-    import torch
+    ranks = Ranks(args)
+    world, rank = ranks.world, ranks.rank
+    legs = None
+    if (ranks.kind == "hip" and ranks.comm is not None and args.leg is None and "AKS_DIST_PATH" not in os.environ
+            and os.environ.get("AKS_BENCH_PREFLIGHT", "1") != "0"):
+        legs = pre_gpu_legs(args, ranks)
+    ranks.attach_gpu()
+    telemetry = calibration = None
+    if rank == 0 and GPU and args.leg is None:
+        telemetry = {"before": device_telemetry(ranks.local_rank)}
+        calibration = {"stream_copy_GBs_before": stream_copy_calibration()}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start the ranks with "
-                         f"torch.distributed.run --nproc-per-node {args.gpus}, or drop WORLD_SIZE and let "
-                         f"`bench.py --gpus {args.gpus}` start them)")
-    # AKS_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path with all ranks sharing the visible GPU(s)
-    # (collectives staged through host memory); the measured numbers then mean nothing.
-    backend = os.environ.get("AKS_BENCH_BACKEND", "nccl")
-    forced = os.environ.get("AKS_FORCE_COMM") == "1"
-    preflight = None
-    if ((world > 1 or forced) and backend == "nccl" and "AKS_DIST_PATH" not in os.environ
-            and os.environ.get("AKS_BENCH_PREFLIGHT", "1") != "0" and args.leg is None
-            and torch.cuda.device_count() > 0):          # (device_count does not initialise the GPU)
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(free_port()))
-            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
-        preflight = native_preflight(world, rank, local_rank)
-    global GPU
-    GPU = torch.cuda.is_available()
-    if GPU:
-        if backend != "nccl":
-            local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
-
-    import torch.distributed as dist
-    from arnoldi_amd.dist import Comm
-
-    comm = None
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-        comm = Comm()
-    elif os.environ.get("AKS_FORCE_COMM") == "1":
-        # rehearsal of the multi-rank host path on one GPU: a one-rank RCCL group whose
-        # all-reduces are really issued (measures the per-step host + collective latency)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(free_port()))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        comm = Comm(force=True)
-
-    comm_forced = comm is not None and world == 1
-    res = measure(args, comm, world, rank)
+    res = measure(args, ranks.comm, world, rank)
 
     if args.leg == "measure":                      # child process of a one-GPU run: report and leave
         emit(json.dumps(leg_summary(res, args)))
         return 0
 
-    out = headline(res, args, world, comm_forced, preflight) if rank == 0 else None
+    out = None
+    if rank == 0:
+        out = headline(res, args, world, ranks.forced, legs.get("preflight") if legs else None)
+        out["config"]["rank_layer"] = ranks.describe() if ranks.comm is not None else "single process, AKS_HOST_ALLOC=" + backend_kind()
+        out["runtime"] = runtime_block()
+        if GPU and calibration is not None:
+            calibration["stream_copy_GBs_after"] = stream_copy_calibration()
+            mean = 0.5 * (calibration["stream_copy_GBs_before"] + calibration["stream_copy_GBs_after"])
+            calibration.update(kernel="aks_stream_copy (non-temporal 16-byte read + write stream)", launches=50,
+                               bytes_moved_per_launch=2 * (256 << 20), of_hbm_peak=round(mean / HBM_PEAK_GBS, 4),
+                               value_per_copy_TBs=round(res["value"] / (mean / 1e3), 3))
+            telemetry["after"] = device_telemetry(ranks.local_rank)
+            out["calibration"], out["device"] = calibration, telemetry
+        if legs:
+            out["legs"] = {k: v for k, v in legs.items() if k != "preflight"}
+            out.update(model_fields(res, args, world, legs))
 
     # ---- N > 1: the workloads that can scale, through the same ranks (no child processes once the GPUs are in use)
     if world > 1 and args.workload == "random" and args.arithmetic == "complex" and not args.no_workloads:
-        legs = sharded_legs(args, comm, world, rank)
+        more = sharded_legs(args, ranks.comm, world, rank)
         if rank == 0:
-            out["workloads"] = legs
+            out["workloads"] = more
 
-    if comm is not None:
-        comm.barrier()
-        comm.close()                      # the library's own RCCL communicator, if one was made
-        dist.destroy_process_group()
+    ranks.close()
 
     # ---- extra legs (one GPU only): child processes, after this process has released the GPU memory
     if rank == 0 and world == 1 and GPU:
-        import gc
-
-        gc.collect()
-        torch.cuda.empty_cache()
+        del res
+        ranks.release_device_memory()
         base = ["--steps", str(min(args.steps, 5)), "--warmup", "2", "--leg", "measure"]
         if args.workload == "random" and args.arithmetic == "complex":
             if not args.no_real_leg:
@@ -1130,7 +1294,7 @@ def run_rank(args, argv):
                                     "one when it would cut a conjugate pair")
                 out["real_arithmetic"] = leg
             if not args.no_workloads:
-                legs = []
+                more = []
                 for name, extra in (("markov", ["--workload", "markov", "--rows", "10000000"]),
                                     ("laplace2d", ["--workload", "laplace2d", "--rows", "1000000", "--nev", "10",
                                                    "--max-dim", "40"]),                       # BASELINE config 2
@@ -1142,8 +1306,8 @@ def run_rank(args, argv):
                                                    "--max-dim", "40"])):                      # config 4 on ONE GPU
                     leg = run_child(extra + base, 600)
                     leg["name"] = name
-                    legs.append(leg)
-                out["workloads"] = legs
+                    more.append(leg)
+                out["workloads"] = more
         if not args.no_cpu_baseline:
             leg = run_child((["--matrix", args.matrix] if args.matrix else []) +
                             ["--leg", "cpu", "--workload", "random" if args.matrix else args.workload, "--rows", str(args.n), "--per-row",
@@ -1152,6 +1316,7 @@ def run_rank(args, argv):
                              "--cpu-budget-s", str(args.cpu_budget_s)], 900)
             out["cpu_baseline"] = leg
     if rank == 0:
+        out["torch_in_process"] = "torch" in sys.modules
         emit(json.dumps(out))
     return 0
 
@@ -1168,6 +1333,8 @@ def main():
         return preflight_child(args)
     if args.leg == "allreduce_probe":
         return allreduce_probe_child(args)
+    if args.leg == "solve":
+        return solve_leg_child(args)
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, argv)
     return run_rank(args, argv)

@@ -1102,8 +1102,9 @@ def test_row_sharded_c_driven_path_over_rccl(amd, tmp_path, ranks):
 
 
 def test_bench_multi_rank_line_on_the_c_driven_path(amd):
-    """``bench.py --gpus 2`` as the driver starts it, rehearsed on ONE GPU: two ranks share it, the library's own
-    communicator (C-driven ghost exchange + stage all-reduces) runs over tests/mock_rccl, gloo carries the set-up.
+    """``AKS_HOST_ALLOC=torch bench.py --gpus 2`` -- the torch INTEROP backend (round 6: no longer the default) -- rehearsed on
+    ONE GPU: two ranks share it, the library's own communicator (C-driven ghost exchange + stage all-reduces) runs over
+    tests/mock_rccl, a gloo process group carries the set-up.
     The line must come from the C path and carry the per-SpMV device-time split of rank 0."""
     import json
     import subprocess
@@ -1113,7 +1114,7 @@ def test_bench_multi_rank_line_on_the_c_driven_path(amd):
 
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    env = dict(os.environ, AKS_LIB_PATH=os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"),
+    env = dict(os.environ, AKS_LIB_PATH=os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"), AKS_HOST_ALLOC="torch",
                AKS_COMM_OVER_GLOO="1", AKS_BENCH_BACKEND="gloo", AKS_GRAPH="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -1144,8 +1145,14 @@ def test_bench_multi_rank_line_on_the_c_driven_path(amd):
 
 
 def test_bench_multi_rank_line_without_torch(amd):
-    """``AKS_COMM=host python bench.py --gpus 2``: the ranks bootstrap over ``dist.HostComm``, allocate
-    through the HIP runtime and never import torch; same line -- C-driven path, exchange block, sharded legs."""
+    """``python bench.py --gpus 2`` as the DRIVER starts it, on the package's default backend:
+    the ranks bootstrap over ``dist.HostComm``, allocate through the HIP runtime and never import torch; same line -- C-driven
+    path, exchange block, sharded legs -- and, from child processes started BEFORE the ranks touch the GPU, the headline solve
+    in the other configurations, so that one driver record decides between them: ``oneshot`` (AKS_ALLREDUCE=oneshot),
+    ``torch_backend`` (torch allocator + process group = the HIP / RCCL the torch wheel bundles), ``allreduce_probe`` (both
+    all-reduce paths in isolation), ``one_gpu_shard`` (the restart on n / N rows on one GPU: the model's measured terms) --
+    each with restarts/s, all-reduce us per call, path taken, per-SpMV split and runtime versions.  Two ranks share the one
+    GPU here, so the library is the build against tests/mock_rccl (numbers: structure only)."""
     import json
     import subprocess
     import sys
@@ -1154,32 +1161,64 @@ def test_bench_multi_rank_line_without_torch(amd):
 
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    env = dict(os.environ, AKS_LIB_PATH=os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"), AKS_COMM="host",
-               AKS_GRAPH="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AKS_HOST_ALLOC"):
+    # (AKS_COMM_OVER_GLOO / AKS_BENCH_BACKEND are read by the torch_backend leg only: its two ranks share the GPU, too)
+    env = dict(os.environ, AKS_LIB_PATH=os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"),
+               AKS_COMM_OVER_GLOO="1", AKS_BENCH_BACKEND="gloo", AKS_GRAPH="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AKS_HOST_ALLOC", "AKS_COMM", "AKS_ALLREDUCE"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "400000", "--steps", "2",
                           "--warmup", "1", "--no-cpu-baseline", "--leg-rows", "300000"], capture_output=True, text=True,
-                         timeout=600, env=env)
+                         timeout=900, env=env)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["torch_in_process"] is False and out["config"]["rank_layer"].startswith("dist.HostComm")
+    assert out["runtime"]["backend"] == "hip" and out["runtime"]["hip_runtime"] >= 70200000, out["runtime"]
     assert out["n_gpus"] == 2 and "issued from C" in out["config"]["path"] and out["value"] > 0
     ex = out["config"]["exchange"]
     assert ex["ghost_bytes_received_per_spmv_rank0"] > 0 and ex["collectives_per_arnoldi_step"] == 3
     assert ex["allreduce_path"].startswith("ncclAllReduce") and ex["allreduce_device_ms_per_step_rank0"] > 0
-    legs = {leg["name"]: leg for leg in out["workloads"]}
-    assert set(legs) == {"markov", "laplace3d", "random_real_packed"}
-    assert all("error" not in leg and leg["restarts_per_s"] > 0 and leg["path"].startswith("C-driven") for leg in legs.values())
+    pre = out["config"]["native_preflight"]
+    assert pre["all_ranks_ok"] and pre["random"]["ok"] and pre["laplace2d"]["lazy_redos"] == 1, pre
+    # ---- the legs: every configuration in the line, each with its numbers, its path and what it ran on
+    legs = out["legs"]
+    assert set(legs) == {"allreduce_probe", "oneshot", "torch_backend", "one_gpu_shard"}, sorted(legs)
+    assert all("error" not in leg and leg["all_ranks_ok"] for leg in legs.values()), legs
+    one, tor = legs["oneshot"], legs["torch_backend"]
+    for leg in (one, tor):
+        assert leg["restarts_per_s"] > 0 and leg["path"].startswith("C-driven") and leg["allreduce_device_us_per_call_rank0"] > 0, leg
+        assert all(leg["spmv_device_ms_rank0"][k] > 0 for k in ("pack", "exchange", "diag_block", "ghost_wait_plus_offdiag_block")), leg
+    assert one["allreduce_path"] == "one-shot mailbox exchange" and one["runtime"]["backend"] == "hip" and not one["runtime"]["torch_in_process"]
+    assert one["runtime"]["hip_runtime"] >= 70200000
+    assert tor["allreduce_path"].startswith("ncclAllReduce") and tor["runtime"]["backend"] == "torch" and tor["runtime"]["torch_in_process"]
+    assert tor["runtime"]["hip_runtime"] > 0 and tor["rank_layer"].startswith("torch.distributed")
+    probe = legs["allreduce_probe"]
+    assert probe["nccl"]["sum_ok"] and probe["oneshot"]["sum_ok"] and probe["oneshot"]["path"] == "one-shot mailbox exchange", probe
+    assert set(probe["slowest_rank_us_per_call"]) == {"nccl", "oneshot"}
+    shard = legs["one_gpu_shard"]
+    assert shard["n"] == 200000 and shard["spmv_avg_ms"] > 0 and shard["ortho_avg_ms_per_step"] > 0, shard
+    # ---- the model next to the measurement, from THIS invocation's terms
+    model = out["prediction_model"]
+    assert out["predicted_restarts_per_s"] > 0 and model["one_gpu_terms"].startswith("measured")
+    assert model["allreduce_us_source"].startswith("this invocation") and model["allreduce_us"] == probe["slowest_rank_us_per_call"]["nccl"]
+    assert abs(model["kernels_ms_per_step"] - (shard["spmv_avg_ms"] + shard["ortho_avg_ms_per_step"])) < 1e-3
+    # ---- device state and calibration around the timed region
+    assert out["calibration"]["stream_copy_GBs_before"] > 500 and out["calibration"]["stream_copy_GBs_after"] > 500, out["calibration"]
+    assert set(out["device"]) == {"before", "after"}
+    more = {leg["name"]: leg for leg in out["workloads"]}
+    assert set(more) == {"markov", "laplace3d", "random_real_packed"}
+    assert all("error" not in leg and leg["restarts_per_s"] > 0 and leg["path"].startswith("C-driven") for leg in more.values())
+    print("legs x2 rehearsal:", {k: v.get("restarts_per_s") for k, v in legs.items()}, "default", out["value"],
+          "device", out["device"]["before"])
 
 
 def test_bench_preflight_probes_both_allreduce_paths(amd):
-    """``bench.py`` with a communicator (here: a forced one-rank RCCL group, the only kind a one-GPU box can make) runs its
-    preflight children before it touches the GPU: the C-driven path against the chained one, then -- in a child of its own
-    -- the two all-reduce implementations timed side by side (``ncclAllReduce`` / one-shot mailbox exchange).  On the
-    driver's multi-GPU run that block of the line is the measurement round 5 could not make."""
+    """``bench.py`` with a communicator (here: a forced one-rank group, the only kind a one-GPU box can make with the REAL
+    RCCL) runs its legs in child processes before it touches the GPU: the C-driven path against the chained one, the two
+    all-reduce implementations timed side by side, the headline solve on the one-shot path and on the torch backend.  The
+    default backend runs on the system's ROCm (HIP >= 7.2, RCCL 2.27), the torch leg on what the torch wheel bundles: both
+    versions are in the line ("both versions are in the line")."""
     import json
     import subprocess
     import sys
@@ -1187,20 +1226,30 @@ def test_bench_preflight_probes_both_allreduce_paths(amd):
     from test_host_logic import ROOT
 
     env = dict(os.environ, AKS_FORCE_COMM="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AKS_LIB_PATH", "AKS_ALLREDUCE", "AKS_DIST_PATH"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AKS_LIB_PATH", "AKS_ALLREDUCE", "AKS_DIST_PATH",
+              "AKS_HOST_ALLOC", "AKS_COMM"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "300000", "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline", "--no-real-leg", "--no-workloads"], capture_output=True, text=True, timeout=600, env=env)
+                          "--no-cpu-baseline", "--no-real-leg", "--no-workloads"], capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     pre = out["config"]["native_preflight"]
     assert pre["all_ranks_ok"] and "issued from C" in out["config"]["path"], pre
-    probe = pre["allreduce_probe"]
-    assert "error" not in probe, probe
+    assert out["runtime"]["backend"] == "hip" and out["runtime"]["hip_runtime"] >= 70200000 and out["runtime"]["rccl"] >= 22700, out["runtime"]
+    assert out["torch_in_process"] is False
+    legs = out["legs"]
+    assert set(legs) == {"allreduce_probe", "oneshot", "torch_backend"}, sorted(legs)        # (one_gpu_shard: N > 1 only)
+    assert all("error" not in leg for leg in legs.values()), legs
+    probe = legs["allreduce_probe"]
     assert probe["nccl"]["path"] == "ncclAllReduce" and probe["nccl"]["sum_ok"] and probe["nccl"]["device_us_per_call"] > 0
     assert probe["oneshot"]["path"] == "one-shot mailbox exchange" and probe["oneshot"]["sum_ok"], probe
     assert probe["oneshot"]["device_us_per_call"] > 0 and set(probe["slowest_rank_us_per_call"]) == {"nccl", "oneshot"}
-    print("all-reduce probe, one rank:", probe["slowest_rank_us_per_call"])
+    assert legs["oneshot"]["allreduce_path"] == "one-shot mailbox exchange" and legs["oneshot"]["restarts_per_s"] > 0
+    tor = legs["torch_backend"]
+    assert tor["runtime"]["backend"] == "torch" and tor["runtime"]["torch_in_process"] and tor["restarts_per_s"] > 0, tor
+    assert tor["runtime"]["hip_runtime"] != out["runtime"]["hip_runtime"] or tor["runtime"]["rccl"] != out["runtime"]["rccl"], (
+        "the torch leg is expected to run on the wheel's bundled runtime", tor["runtime"], out["runtime"])
+    print("all-reduce probe, one rank:", probe["slowest_rank_us_per_call"], "| runtimes:", out["runtime"], tor["runtime"])
 
 
 def test_rccl_collectives_one_rank(amd, tmp_path):

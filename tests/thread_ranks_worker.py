@@ -400,9 +400,20 @@ def case_bench(ranks, rows, steps, warmup, leg_rows):
         argv += ["--leg-rows", str(leg_rows)]           # (0: the legs at their BASELINE sizes)
     args = bench.parse_args(argv)
 
+    # the model's one-GPU terms, measured as bench.py's "one_gpu_shard" leg measures them: the same restart on n / ranks rows
+    import copy
+
+    shard_args = copy.copy(args)
+    shard_args.n, shard_args.gpus, shard_args.steps, shard_args.warmup = max(rows // ranks, 1000), 1, min(steps, 5), 2
+    shard = bench.leg_summary(bench.measure(shard_args, None, 1, 0), shard_args)
+    log(f"bench: one-GPU shard leg ({shard_args.n} rows): {shard['restarts_per_s']} restarts/s")
+
     def rank_fn(comm, rank):
         res = bench.measure(args, comm, ranks, rank)
         out = bench.headline(res, args, ranks) if rank == 0 else None
+        if rank == 0:
+            out["legs"] = {"one_gpu_shard": shard}
+            out.update(bench.model_fields(res, args, ranks, out["legs"]))
         if not args.no_workloads:
             legs = bench.sharded_legs(args, comm, ranks, rank, log=log if rank == 0 else None)
             if rank == 0:
