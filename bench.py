@@ -95,6 +95,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-real-leg", action="store_true",
                     help="skip the extra measurement of partial_schur(arithmetic='real') on the same matrix")
     ap.add_argument("--no-workloads", action="store_true", help="skip the Markov / Laplace legs")
+    ap.add_argument("--no-device-state", action="store_true",
+                    help="skip the rocm-smi samples and the streaming-copy calibration around the timed region (profiler "
+                         "passes: no child process, no extra kernel in the trace)")
     ap.add_argument("--leg-rows", type=int, default=None,
                     help="(N > 1) matrix dimension of the sharded Markov / 3-D Laplace / real-packed legs instead of their "
                          "BASELINE sizes (rehearsals)")
@@ -1061,15 +1064,15 @@ def pre_gpu_legs(args, ranks):
             continue
         t0 = time.perf_counter()
         if name == "one_gpu_shard":
-            report = {"skipped": "not the headline workload at N > 1"}
-            if world > 1 and args.workload == "random" and args.matrix is None:
-                report = None
-                if rank == 0:                                 # one GPU, one process: rank 0's; the others wait at the gather below
-                    env = dict(base_env, RANK="0", LOCAL_RANK=str(ranks.local_rank), WORLD_SIZE="1")
-                    env.pop("AKS_FORCE_COMM", None)
-                    report = run_own_child(["--gpus", "1", "--rows", str(max(args.n // world, 1000)), "--per-row", str(args.per_row),
-                                            "--nev", str(args.nev), "--max-dim", str(args.max_dim), "--steps", steps, "--warmup",
-                                            warmup, "--leg", "measure"], env, LEG_TIMEOUT_S[name])
+            if not (world > 1 and args.workload == "random" and args.matrix is None):
+                continue                                      # (the model it feeds is the headline workload's at N > 1)
+            report = None
+            if rank == 0:                                     # one GPU, one process: rank 0's; the others wait at the gather below
+                env = dict(base_env, RANK="0", LOCAL_RANK=str(ranks.local_rank), WORLD_SIZE="1")
+                env.pop("AKS_FORCE_COMM", None)
+                report = run_own_child(["--gpus", "1", "--rows", str(max(args.n // world, 1000)), "--per-row", str(args.per_row),
+                                        "--nev", str(args.nev), "--max-dim", str(args.max_dim), "--steps", steps, "--warmup",
+                                        warmup, "--leg", "measure"], env, LEG_TIMEOUT_S[name])
             ok_everywhere = all(b == b"y" for b in hub.gather(b"y"))
         else:
             leg_argv, extra = plan[name]
@@ -1243,7 +1246,7 @@ def run_rank(args, argv):
         legs = pre_gpu_legs(args, ranks)
     ranks.attach_gpu()
     telemetry = calibration = None
-    if rank == 0 and GPU and args.leg is None:
+    if rank == 0 and GPU and args.leg is None and not args.no_device_state:
         telemetry = {"before": device_telemetry(ranks.local_rank)}
         calibration = {"stream_copy_GBs_before": stream_copy_calibration()}
 

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${AKS_PMC_OUT:-prof}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-real-leg --no-workloads $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-real-leg --no-workloads --no-device-state $*"
 
 run() {  # name, rocprof args...
     local name=$1; shift

@@ -1144,8 +1144,11 @@ def test_bench_multi_rank_line_on_the_c_driven_path(amd):
     assert legs["laplace3d"]["exchange"]["ghost_bytes_received_per_spmv_rank0"] == 16 * nx * (nx + 1)
 
 
-def test_bench_multi_rank_line_without_torch(amd):
-    """``python bench.py --gpus 2`` as the DRIVER starts it, on the package's default backend:
+@pytest.mark.parametrize("launcher", ["bench.py --gpus 2", "torch.distributed.run"])
+def test_bench_multi_rank_line_without_torch(amd, launcher):
+    """``python bench.py --gpus 2`` -- started by itself, and exactly as the DRIVER starts it (``python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2``: the
+    launcher imports torch, the ranks do not) -- on the package's default backend:
     the ranks bootstrap over ``dist.HostComm``, allocate through the HIP runtime and never import torch; same line -- C-driven
     path, exchange block, sharded legs -- and, from child processes started BEFORE the ranks touch the GPU, the headline solve
     in the other configurations, so that one driver record decides between them: ``oneshot`` (AKS_ALLREDUCE=oneshot),
@@ -1166,9 +1169,17 @@ def test_bench_multi_rank_line_without_torch(amd):
                AKS_COMM_OVER_GLOO="1", AKS_BENCH_BACKEND="gloo", AKS_GRAPH="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AKS_HOST_ALLOC", "AKS_COMM", "AKS_ALLREDUCE"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "400000", "--steps", "2",
-                          "--warmup", "1", "--no-cpu-baseline", "--leg-rows", "300000"], capture_output=True, text=True,
-                         timeout=900, env=env)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
+    if launcher == "torch.distributed.run":
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")]
+    res = subprocess.run(cmd + ["--gpus", "2", "--rows", "400000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                                "--leg-rows", "300000"], capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1

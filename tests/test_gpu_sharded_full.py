@@ -227,10 +227,15 @@ def test_one_shot_allreduce_on_a_single_hardware_queue_cannot_hang(tmp_path):
         assert "timed out after" in one["stderr"] and "one-shot all-reduce number" in one["stderr"], one["stderr"]
         print("one hardware queue: a reduction timed out inside the solve (reported, not hung)")
         return
-    path, why = one["allreduce_path"]
-    assert (path == 1 and why == "") or (path == 0 and "arrival counter was not reached" in why), one["allreduce_path"]
+    paths = [tuple(pw) for pw in one["allreduce_paths"]]          # (path, reason) of every rank
+    if paths[0][0] == 1:
+        assert all(pw == (1, "") for pw in paths), paths
+    else:        # voted down TOGETHER: the rank whose reduction sat in front times out, its peer learns it from the vote
+        assert all(path == 0 for path, _ in paths), paths
+        assert any("arrival counter was not reached" in why for _, why in paths), paths
+        assert all("arrival counter was not reached" in why or "another rank could not" in why for _, why in paths), paths
     assert one["info"] == base["info"] and one["sha"] == base["sha"], (base["sha"], one["sha"])
-    print("one hardware queue:", one["allreduce_path"])
+    print("one hardware queue:", paths)
 
 
 @pytest.mark.gpu

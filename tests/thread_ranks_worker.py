@@ -309,6 +309,7 @@ def case_repro(ranks, n, repeats=3, workload="random", real=False, sweep=False):
 
         out = run_ranks(ranks, rank_fn)
         runs.append(out[0])
+        paths_all = [o[3] for o in out]
         log(f"repro: run {rep} done, {len(out[0][0])} snapshots, info {out[0][1]}")
     base = runs[0][0]
     report = []
@@ -327,7 +328,7 @@ def case_repro(ranks, n, repeats=3, workload="random", real=False, sweep=False):
             cols = [float(np.abs(a[:, j] - b[:, j]).max() / max(np.abs(a[:, j]).max(), 1e-300)) for j in range(a.shape[1])]
         report.append({"run": rep, "first_differing_snapshot": first, "max_rel_diff": worst, "snapshots": len(base),
                        "spectrum_rel_diff_per_snapshot": spec, "column_rel_diff_in_first_bad_snapshot": cols})
-    return {"ranks": ranks, "n": n, "forms": runs[0][2], "info": runs[0][1], "report": report, "allreduce_path": runs[0][3],
+    return {"ranks": ranks, "n": n, "forms": runs[0][2], "info": runs[0][1], "report": report, "allreduce_path": runs[0][3], "allreduce_paths": paths_all,
             "sha": [hashlib.sha256(np.ascontiguousarray(r[0][-1]).tobytes()).hexdigest()[:12] for r in runs]}
 
 
