@@ -431,22 +431,35 @@ class _Hub:
 
     CHUNK = 16 << 20
 
-    def __init__(self, rank, size, host, port, timeout):
+    def __init__(self, rank, size, host, port, timeout, span=1):
+        """``span``: how many consecutive ports, from ``port`` on, may carry the rendezvous.  With an address derived from
+        the launcher's (MASTER_PORT + 1, which nobody reserved) rank 0 listens on the first port of the span it can bind,
+        and the others find it by the handshake: a listener that does not answer the hello with the job's token -- some
+        other service that happens to own the port -- is not it, and the next port is tried.  An explicit
+        ``AKS_RENDEZVOUS=host:port`` names one port (span 1)."""
         self.rank, self.size, self.timeout = rank, size, timeout
         self.max_msg = int(os.environ.get("AKS_COMM_MAX_MSG", str(512 << 20)))
         self.peers = {}                      # rank 0: peer rank -> socket; others: {0: socket}
+        self.port = None
         if size == 1:
             return
         token = _job_token()
+        bind_host = host if host not in ("", "localhost") else "127.0.0.1"
         if rank == 0:
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            try:
-                srv.bind((host if host not in ("", "localhost") else "127.0.0.1", port))
-            except OSError as e:
-                srv.close()
-                raise RuntimeError(f"rendezvous: rank 0 cannot listen on {host}:{port} ({e}); choose another port with "
-                                   f"AKS_RENDEZVOUS=host:port on every rank") from None
+            srv, err = None, None
+            for candidate in range(port, port + max(int(span), 1)):
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    srv.bind((bind_host, candidate))
+                    self.port = candidate
+                    break
+                except OSError as e:
+                    srv.close()
+                    srv, err = None, e
+            if srv is None:
+                raise RuntimeError(f"rendezvous: rank 0 cannot listen on {host}:{port}" + (f"..{port + span - 1}" if span > 1 else "")
+                                   + f" ({err}); choose another port with AKS_RENDEZVOUS=host:port on every rank") from None
             srv.listen(size)
             srv.settimeout(timeout)
             deadline = time.monotonic() + timeout
@@ -463,6 +476,7 @@ class _Hub:
                             raise RuntimeError("rendezvous: a peer presented another job's token")
                         if not 0 < peer < size or peer in self.peers:
                             raise RuntimeError(f"rendezvous: unexpected peer rank {peer}")
+                        conn.sendall(b"AKS1" + token[:28])           # the answer a peer waits for: this IS its job's rendezvous
                         conn.settimeout(timeout)
                     except (RuntimeError, OSError) as e:
                         conn.close()                                 # a stranger (or a broken hello) is dropped; the ranks
@@ -480,21 +494,29 @@ class _Hub:
                 srv.close()
         else:
             deadline = time.monotonic() + timeout
-            while True:
-                try:
-                    conn = socket.create_connection((host, port), timeout=min(5.0, timeout))
-                    break
-                except OSError:
+            conn = None
+            while conn is None:
+                for candidate in range(port, port + max(int(span), 1)):
+                    try:
+                        c = socket.create_connection((host, candidate), timeout=min(5.0, timeout))
+                    except OSError:
+                        continue
+                    try:
+                        c.settimeout(min(timeout, 10.0))
+                        c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        c.sendall(struct.pack("<q", rank) + token)
+                        if self._recv_exact(c, 32) == b"AKS1" + token[:28]:
+                            c.settimeout(timeout)
+                            conn, self.port = c, candidate
+                            break
+                    except (RuntimeError, OSError):
+                        pass                                        # not our listener (or it turned us away): next port
+                    c.close()
+                if conn is None:
                     if time.monotonic() > deadline:
-                        raise RuntimeError(f"rendezvous: rank 0 not reachable at {host}:{port} within {timeout:.0f} s") from None
+                        raise RuntimeError(f"rendezvous: rank 0 not reachable at {host}:{port}"
+                                           + (f"..{port + span - 1}" if span > 1 else "") + f" within {timeout:.0f} s") from None
                     time.sleep(0.05)
-            try:
-                conn.settimeout(timeout)
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                conn.sendall(struct.pack("<q", rank) + token)
-            except BaseException:
-                conn.close()
-                raise
             self.peers[0] = conn
 
     @classmethod
@@ -585,14 +607,19 @@ def sys_stderr(msg):
     sys.stderr.write(msg + "\n")
 
 
+RENDEZVOUS_SPAN = 16
+
+
 def rendezvous_address():
-    """(host, port) of the torch-free rendezvous: ``AKS_RENDEZVOUS=host:port``, else MASTER_ADDR and MASTER_PORT + 1
-    (the launcher's own store listens on MASTER_PORT itself when the ranks were started by torch.distributed.run)."""
+    """(host, port, span) of the torch-free rendezvous: ``AKS_RENDEZVOUS=host:port`` (that port, span 1), else MASTER_ADDR
+    and the ``RENDEZVOUS_SPAN`` ports from MASTER_PORT + 1 on (the launcher's own store listens on MASTER_PORT itself when
+    the ranks were started by torch.distributed.run; nobody reserved the ports behind it, so rank 0 takes the first one
+    it can bind and the handshake tells the others which)."""
     spec = os.environ.get("AKS_RENDEZVOUS")
     if spec:
         host, _, port = spec.rpartition(":")
-        return host or "127.0.0.1", int(port)
-    return os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29400")) + 1
+        return host or "127.0.0.1", int(port), 1
+    return os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29400")) + 1, RENDEZVOUS_SPAN
 
 
 class HostComm(_GraphOwners):
@@ -606,9 +633,9 @@ class HostComm(_GraphOwners):
         self.size = int(os.environ.get("WORLD_SIZE", "1")) if size is None else int(size)
         if not 0 <= self.rank < self.size:
             raise ValueError(f"HostComm: rank {self.rank} of {self.size}")
-        host, port = address if address is not None else rendezvous_address()
+        host, port, span = (tuple(address) + (1,))[:3] if address is not None else rendezvous_address()
         self.force, self.group, self._native = bool(force), None, None
-        self._hub = _Hub(self.rank, self.size, host, port, float(os.environ.get("AKS_COMM_TIMEOUT_S", "300")))
+        self._hub = _Hub(self.rank, self.size, host, port, float(os.environ.get("AKS_COMM_TIMEOUT_S", "300")), span)
         _live_comms.add(self)
 
     @property

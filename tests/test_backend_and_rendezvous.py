@@ -426,3 +426,51 @@ def test_rendezvous_messages_are_capped_and_read_in_chunks(monkeypatch):
         hub0._send_blobs(hub0.peers[1], [b"\0" * ((1 << 20) + 1)])
     hub0.close()
     box["hub"].close()
+
+
+def test_rendezvous_finds_its_port_when_the_first_one_is_taken(monkeypatch):
+    """The default address is MASTER_PORT + 1 -- a port nobody reserved.  If some other service owns it, rank 0 listens on
+    the next port of the span it can bind, and the other ranks find it by the handshake: the foreign listener does not
+    answer the hello with the job's token, so they move on (a driver-started run must not die of a port collision)."""
+    from arnoldi_amd.dist import _Hub
+
+    monkeypatch.setenv("AKS_COMM_TOKEN", "job-span")
+    foreign = socket.socket()
+    foreign.bind(("127.0.0.1", 0))
+    foreign.listen(4)
+    port = foreign.getsockname()[1]
+
+    def foreign_service():                          # accepts, says something else, hangs up
+        foreign.settimeout(10)
+        try:
+            while True:
+                c, _ = foreign.accept()
+                c.sendall(b"HTTP/1.1 400 Bad Request\r\n\r\n")
+                c.close()
+        except OSError:
+            pass
+
+    threading.Thread(target=foreign_service, daemon=True).start()
+    box = {}
+
+    def rank1():
+        h = _Hub(1, 2, "127.0.0.1", port, 10.0, span=4)
+        box["port"], box["got"] = h.port, h.gather(b"one")
+        h.close()
+
+    t = threading.Thread(target=rank1)
+    t.start()
+    hub0 = _Hub(0, 2, "127.0.0.1", port, 10.0, span=4)
+    assert hub0.port != port and port < hub0.port < port + 4
+    assert hub0.gather(b"zero") == [b"zero", b"one"]
+    t.join(10)
+    hub0.close()
+    foreign.close()
+    assert box["port"] == hub0.port and box["got"] == [b"zero", b"one"]
+    # an explicit address names ONE port: taken means an error that says what to do
+    busy = socket.socket()
+    busy.bind(("127.0.0.1", 0))
+    busy.listen(1)
+    with pytest.raises(RuntimeError, match="AKS_RENDEZVOUS=host:port"):
+        _Hub(0, 2, "127.0.0.1", busy.getsockname()[1], 2.0)
+    busy.close()
