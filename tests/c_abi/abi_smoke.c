@@ -216,7 +216,7 @@ int main(void) {
     printf("real-packed: |V^T V - I| = %.2e, |A V - V H| = %.2e, max |Im H| = %.1e\n", worst_o, worst_r, worst_im);
     if (!(worst_o < 1e-12 && worst_r < 1e-12 && worst_im == 0.0)) return 1;
 
-    /* ---- the communicator entry points from plain C (ABI 5), on a ONE-rank communicator -- all a one-GPU box can make; RCCL is
+    /* ---- the communicator entry points from plain C (ABI 5 and 6), on a ONE-rank communicator -- all a one-GPU box can make; RCCL is
      * the system's (dlopen("librccl.so")), no Python in the process: id, create, the small all-reduce through ncclAllReduce and
      * -- a second communicator made with AKS_ALLREDUCE=oneshot -- through the one-shot mailbox exchange, and the byte exchange the
      * torch-free host layer builds its set-up on (aks_comm_alltoallv: this rank's own slice is a device copy). ---- */
@@ -242,11 +242,41 @@ int main(void) {
             for (int i = 0; i < 6; ++i) same = same && h_out[i] == h_buf[i];
             printf("communicator from plain C, pass %d: all-reduce path %d%s%s, values %s\n", pass, path, why[0] ? " -- " : "", why,
                    same ? "intact" : "WRONG");
+            /* ABI 6: no reduction timed out; a communicator that still counts a captured graph refuses to be destroyed (and is
+             * intact afterwards), then goes once the count is back at zero */
+            if (aks_comm_status(comm, why, (int64_t)sizeof why) != 0) { printf("aks_comm_status: %s\n", why); return 1; }
+            if (aks_comm_graph_retain(comm) != 1) return 1;
+            if (aks_comm_destroy(comm) >= 0) { printf("aks_comm_destroy accepted a communicator with a counted graph\n"); return 1; }
+            CHECK_AKS(aks_comm_allreduce_sum(comm, d_buf, 6, NULL));                 /* still usable after the refusal */
+            CHECK_HIP(hipDeviceSynchronize());
+            if (aks_comm_graph_release(comm) != 0) return 1;
             CHECK_AKS(aks_comm_destroy(comm));
             CHECK_HIP(hipFree(d_buf));
             CHECK_HIP(hipFree(d_out));
             if (!same || path != pass) return 1;
         }
+    }
+    /* ---- ABI 6 measurement aids: the streaming copy (bit-exact) and the versions of what this process runs on ---- */
+    {
+        const int64_t bytes = 1 << 20;
+        unsigned char *h = (unsigned char *)malloc((size_t)bytes), *d_a, *d_b;
+        for (int64_t i = 0; i < bytes; ++i) h[i] = (unsigned char)(i * 131 + 7);
+        CHECK_HIP(hipMalloc((void **)&d_a, (size_t)bytes));
+        CHECK_HIP(hipMalloc((void **)&d_b, (size_t)bytes));
+        CHECK_HIP(hipMemcpy(d_a, h, (size_t)bytes, hipMemcpyHostToDevice));
+        CHECK_AKS(aks_stream_copy(d_b, d_a, bytes, NULL));
+        if (aks_stream_copy(d_b, d_a, bytes - 8, NULL) >= 0) { printf("aks_stream_copy accepted a size that is no multiple of 16\n"); return 1; }
+        CHECK_HIP(hipDeviceSynchronize());
+        unsigned char *back = (unsigned char *)malloc((size_t)bytes);
+        CHECK_HIP(hipMemcpy(back, d_b, (size_t)bytes, hipMemcpyDeviceToHost));
+        const int same = memcmp(back, h, (size_t)bytes) == 0;
+        int32_t v_rt = 0, v_drv = 0, v_rccl = 0;
+        CHECK_AKS(aks_runtime_versions(&v_rt, &v_drv, &v_rccl));
+        printf("aks_stream_copy: %s; hip runtime %d, driver %d, rccl %d\n", same ? "bit-exact" : "WRONG", v_rt, v_drv, v_rccl);
+        free(h); free(back);
+        CHECK_HIP(hipFree(d_a));
+        CHECK_HIP(hipFree(d_b));
+        if (!same || v_rt <= 0) return 1;
     }
     return 0;
 }

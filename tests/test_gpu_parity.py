@@ -1584,6 +1584,10 @@ def test_c_abi_from_plain_c():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "|A V - V H|" in r.stdout and "real-packed:" in r.stdout
+    # ... the communicator entry points on the SYSTEM's RCCL (both all-reduce paths, the refusal to destroy a communicator that
+    # still counts a captured graph) and the ABI-6 measurement aids
+    assert "pass 0: all-reduce path 0" in r.stdout and "pass 1: all-reduce path 1" in r.stdout, r.stdout
+    assert "aks_stream_copy: bit-exact; hip runtime 702" in r.stdout, r.stdout
 
 
 def test_lookahead_is_bitwise_neutral(amd, monkeypatch):
