@@ -32,7 +32,8 @@ The line printed by rank 0 also carries
   cpu_baseline    (N = 1) the CPU oracle (NumPy/SciPy restatement of the reference, validated against
                   the reference's golden outputs) timed on this host at the full problem size;
   legs            (N > 1) the headline solve in the OTHER configurations, each in child processes started before the ranks
-                  touch their GPUs, each under a time-out: ``oneshot`` (AKS_ALLREDUCE=oneshot), ``torch_backend`` (torch's
+                  touch their GPUs, each under a time-out: ``oneshot`` (AKS_ALLREDUCE=oneshot), ``graph_replay`` (whole sharded
+                  re-expansions replayed as hipGraphs: AKS_GRAPH=1 AKS_GRAPH_COMM=exchange), ``torch_backend`` (torch's
                   allocator + process group: its bundled HIP / RCCL), ``allreduce_probe`` (both all-reduce paths in isolation),
                   ``one_gpu_shard`` (the restart on n / N rows on one GPU: the measured terms of ``prediction_model``) --
                   restarts/s, all-reduce us per call, path taken, per-SpMV split and runtime versions per leg.
@@ -498,9 +499,11 @@ def _measure(args, comm, world, rank):
 
     # Small problems (kernels of 20-60 us) follow the host's launch latency: the same restarts again with the
     # re-expansion replayed as a hipGraph (AKS_GRAPH=1 of the product: one launch per restart), no probe.
+    # With a communicator only where the engine may capture its collectives (AKS_GRAPH_COMM, engine._comm_capturable: the
+    # ghost exchange on a HIP runtime >= 7.2 only); AKS_GRAPH=1 asks for it at any shard size (the "graph_replay" leg).
     graph_rate = None
-    comm_in_graph = comm is not None and os.environ.get("AKS_GRAPH_COMM") == "1" and not getattr(op, "any_exchange", False)
-    if native and GPU and (comm is None or comm_in_graph) and op.n_local <= 4_000_000:
+    comm_in_graph = comm is not None and native and ctx._comm_capturable()
+    if native and GPU and (comm is None or comm_in_graph) and (op.n_local <= 4_000_000 or os.environ.get("AKS_GRAPH") == "1"):
         ctx.probe = None
         was_graph, ctx.use_graph = ctx.use_graph, True
         for i in range(2):
@@ -558,7 +561,7 @@ def _measure(args, comm, world, rank):
         "n_local": op.n_local, "exchange": exchange,
         "levels_per_round": getattr(getattr(op.diag, "binned", None), "levels_per_round", None),
         "lanes_per_wave_load": getattr(getattr(op.diag, "binned", None), "lanes_per_load", None),
-        "graph_rate": graph_rate,
+        "graph_rate": graph_rate, "graphs_captured": len(ctx._graphs), "graph_capture_failures": ctx.graph_capture_failures,
     }
     return res
 
@@ -1010,6 +1013,8 @@ def solve_leg_child(args):
                    allreduce_device_ms_per_step_rank0=ex.get("allreduce_device_ms_per_step_rank0"),
                    spmv_device_ms_rank0=ex.get("spmv_device_ms_rank0"), spmv_avg_ms=round(res["spmv_avg_ms"], 4),
                    ortho_avg_ms_per_step=res["ortho"]["avg_ms_per_step"] if res["ortho"] else None,
+                   restarts_per_s_hipgraph=round(res["graph_rate"], 4) if res["graph_rate"] else None,
+                   graphs_captured=res["graphs_captured"], graph_capture_failures=res["graph_capture_failures"],
                    lazy_redos=ex.get("lazy_redos"), setup_s=round(res["setup_s"], 2), rank_layer=ranks.describe(),
                    runtime=runtime_block())
     ranks.close()
@@ -1017,7 +1022,7 @@ def solve_leg_child(args):
     return 0
 
 
-LEG_TIMEOUT_S = {"preflight": 240, "allreduce_probe": 150, "oneshot": 300, "torch_backend": 480, "one_gpu_shard": 300}
+LEG_TIMEOUT_S = {"preflight": 240, "allreduce_probe": 150, "oneshot": 300, "graph_replay": 300, "torch_backend": 480, "one_gpu_shard": 300}
 
 
 def pre_gpu_legs(args, ranks):
@@ -1030,6 +1035,9 @@ def pre_gpu_legs(args, ranks):
                       rank the measurement below runs with AKS_DIST_PATH=python (all ranks agree through the rendezvous);
       allreduce_probe ncclAllReduce and the one-shot kernel timed in isolation, side by side;
       oneshot         the headline solve with AKS_ALLREDUCE=oneshot;
+      graph_replay    the headline solve with AKS_GRAPH=1 AKS_GRAPH_COMM=exchange: after the eager (probed) restarts, the same
+                      restarts with every re-expansion -- ghost exchange and reductions included -- replayed as ONE hipGraph
+                      (``restarts_per_s_hipgraph``, with ``graphs_captured`` / ``graph_capture_failures``);
       torch_backend   the headline solve on the torch interop backend: torch's allocator and process group, i.e. the HIP /
                       RCCL a torch wheel bundles (7.0 / 2.26 here) instead of the system's ROCm (7.2 / 2.27);
       one_gpu_shard   rank 0 only, one GPU: the same restart on n / N rows -- the model's kernel terms, measured.
@@ -1039,7 +1047,7 @@ def pre_gpu_legs(args, ranks):
     hub = ranks.comm._hub
     world, rank = ranks.world, ranks.rank
     host = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    names = ["preflight", "allreduce_probe", "oneshot", "torch_backend", "one_gpu_shard"]
+    names = ["preflight", "allreduce_probe", "oneshot", "graph_replay", "torch_backend", "one_gpu_shard"]
     skip = set(filter(None, os.environ.get("AKS_BENCH_SKIP_LEGS", "").split(",")))
     ports = hub.gather(json.dumps([free_port() for _ in names]).encode() if rank == 0 else b"")[0]
     ports = dict(zip(names, json.loads(ports.decode())))
@@ -1056,6 +1064,7 @@ def pre_gpu_legs(args, ranks):
         "preflight": (["--gpus", str(world), "--leg", "preflight"], {}),
         "allreduce_probe": (["--gpus", str(world), "--leg", "allreduce_probe"], {}),
         "oneshot": (solve, {"AKS_ALLREDUCE": "oneshot"}),
+        "graph_replay": (solve, {"AKS_GRAPH": "1", "AKS_GRAPH_COMM": "exchange"}),
         "torch_backend": (solve, {"AKS_HOST_ALLOC": "torch"}),
     }
     out = {}

@@ -1165,7 +1165,9 @@ def test_bench_multi_rank_line_without_torch(amd, launcher):
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     # (AKS_COMM_OVER_GLOO / AKS_BENCH_BACKEND are read by the torch_backend leg only: its two ranks share the GPU, too)
-    env = dict(os.environ, AKS_LIB_PATH=os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"),
+    # (graph_replay is left out: the stand-in synchronises streams, nothing can be captured over it -- that leg is rehearsed with
+    # the real RCCL in test_bench_preflight_probes_both_allreduce_paths)
+    env = dict(os.environ, AKS_LIB_PATH=os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"), AKS_BENCH_SKIP_LEGS="graph_replay",
                AKS_COMM_OVER_GLOO="1", AKS_BENCH_BACKEND="gloo", AKS_GRAPH="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AKS_HOST_ALLOC", "AKS_COMM", "AKS_ALLREDUCE"):
         env.pop(k, None)
@@ -1249,7 +1251,10 @@ def test_bench_preflight_probes_both_allreduce_paths(amd):
     assert out["runtime"]["backend"] == "hip" and out["runtime"]["hip_runtime"] >= 70200000 and out["runtime"]["rccl"] >= 22700, out["runtime"]
     assert out["torch_in_process"] is False
     legs = out["legs"]
-    assert set(legs) == {"allreduce_probe", "oneshot", "torch_backend"}, sorted(legs)        # (one_gpu_shard: N > 1 only)
+    assert set(legs) == {"allreduce_probe", "oneshot", "graph_replay", "torch_backend"}, sorted(legs)        # (one_gpu_shard: N > 1 only)
+    gr = legs["graph_replay"]        # re-expansions with the communicator's reductions in the sequence, captured and replayed
+    assert gr["graphs_captured"] >= 1 and gr["graph_capture_failures"] == 0 and gr["restarts_per_s_hipgraph"] > 0, gr
+    assert gr["runtime"]["hip_runtime"] >= 70200000 and gr["allreduce_path"].startswith("ncclAllReduce"), gr
     assert all("error" not in leg for leg in legs.values()), legs
     probe = legs["allreduce_probe"]
     assert probe["nccl"]["path"] == "ncclAllReduce" and probe["nccl"]["sum_ok"] and probe["nccl"]["device_us_per_call"] > 0
