@@ -810,11 +810,9 @@ class HostComm(_GraphOwners):
         return None
 
     def close(self):
-        try:
-            self._destroy_native()
-        finally:
-            self._hub.close()
-            _live_comms.discard(self)
+        self._destroy_native()          # (raises, with everything intact, while the library still counts a captured graph:
+        self._hub.close()               #  destroy that graph, then close() again)
+        _live_comms.discard(self)
 
 
 _host_comm = None

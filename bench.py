@@ -36,7 +36,9 @@ The line printed by rank 0 also carries
                   re-expansions replayed as hipGraphs: AKS_GRAPH=1 AKS_GRAPH_COMM=exchange), ``torch_backend`` (torch's
                   allocator + process group: its bundled HIP / RCCL), ``allreduce_probe`` (both all-reduce paths in isolation),
                   ``one_gpu_shard`` (the restart on n / N rows on one GPU: the measured terms of ``prediction_model``) --
-                  restarts/s, all-reduce us per call, path taken, per-SpMV split and runtime versions per leg.
+                  restarts/s, all-reduce us per call, path taken, per-SpMV split and runtime versions per leg, and
+                  ``h_agrees_with_default``: the projected matrix of the leg's first expansion against the default's (a leg
+                  whose numbers came out of a broken path does not agree).
 The N = 1 extra legs run in child processes after the headline measurement, so nothing in them can
 cost the run its line; a failed leg is reported as {"error": ...} inside the line.
 """
@@ -430,6 +432,11 @@ def _measure(args, comm, world, rank):
         mem.synchronize()
     initial_ms = (time.perf_counter() - t0) * 1e3
     deferred_initial = ctx.deferred_expansions > 0          # did the m-step expansion leave its columns raw?
+    # What the m-step expansion produced, in two numbers: every configuration of one invocation (the legs of the N > 1 line)
+    # starts from the same matrix and start vector, so their projected matrices agree to rounding -- a leg whose number
+    # came out of a broken path shows here (the legs report restarts/s; this is what says the restarts were the same ones)
+    Hm = np.asarray(solver.H[: m + 1, :m])
+    h_check = {"fro": float(np.linalg.norm(Hm)), "abs_sum": float(np.abs(Hm).sum()), "finite": bool(np.isfinite(Hm).all())}
 
     for i in range(args.warmup):
         solver.contract(i)
@@ -562,6 +569,7 @@ def _measure(args, comm, world, rank):
         "levels_per_round": getattr(getattr(op.diag, "binned", None), "levels_per_round", None),
         "lanes_per_wave_load": getattr(getattr(op.diag, "binned", None), "lanes_per_load", None),
         "graph_rate": graph_rate, "graphs_captured": len(ctx._graphs), "graph_capture_failures": ctx.graph_capture_failures,
+        "h_check": h_check,
     }
     return res
 
@@ -1015,6 +1023,7 @@ def solve_leg_child(args):
                    ortho_avg_ms_per_step=res["ortho"]["avg_ms_per_step"] if res["ortho"] else None,
                    restarts_per_s_hipgraph=round(res["graph_rate"], 4) if res["graph_rate"] else None,
                    graphs_captured=res["graphs_captured"], graph_capture_failures=res["graph_capture_failures"],
+                   h_check=res["h_check"],
                    lazy_redos=ex.get("lazy_redos"), setup_s=round(res["setup_s"], 2), rank_layer=ranks.describe(),
                    runtime=runtime_block())
     ranks.close()
@@ -1278,8 +1287,17 @@ def run_rank(args, argv):
                                value_per_copy_TBs=round(res["value"] / (mean / 1e3), 3))
             telemetry["after"] = device_telemetry(ranks.local_rank)
             out["calibration"], out["device"] = calibration, telemetry
+        out["h_check"] = res["h_check"]
         if legs:
             out["legs"] = {k: v for k, v in legs.items() if k != "preflight"}
+            # the solve legs against THIS measurement: the projected matrix of the first expansion, relative difference
+            # (rounding level: the collective sums in another order than the one-shot kernel; anything larger is a broken path)
+            mine = res["h_check"]
+            for leg in out["legs"].values():
+                theirs = leg.get("h_check") if isinstance(leg, dict) else None
+                if theirs:
+                    leg["h_vs_default_rel_diff"] = max(abs(theirs[k] - mine[k]) / max(abs(mine[k]), 1e-300) for k in ("fro", "abs_sum"))
+                    leg["h_agrees_with_default"] = bool(theirs["finite"] and mine["finite"] and leg["h_vs_default_rel_diff"] < 1e-10)
             out.update(model_fields(res, args, world, legs))
 
     # ---- N > 1: the workloads that can scale, through the same ranks (no child processes once the GPUs are in use)

@@ -29,7 +29,13 @@ class ThreadGroup:
         self.rng_lock = threading.Lock()          # numpy's global RNG is per process: ranks draw v0 one at a time
 
 
-class ThreadComm:
+def _graph_owners_base():
+    from arnoldi_amd.dist import _GraphOwners          # (graphs before the communicator: the product's own rule)
+
+    return _GraphOwners
+
+
+class ThreadComm(_graph_owners_base()):
     """One rank's view of a ``ThreadGroup``: same methods as ``arnoldi_amd.dist.Comm``."""
 
     backend = "threads"
@@ -109,11 +115,7 @@ class ThreadComm:
         return handle
 
     def close(self):
-        if self._native is not None:
-            from arnoldi_amd import _hip
-
-            _hip.load().aks_comm_destroy(self._native)
-            self._native = None
+        self._destroy_native()
 
 
 def run_ranks(size, fn, timeout=900):
