@@ -592,6 +592,14 @@ class _Hub:
             self._send_blobs(self.peers[peer], parts)
         return parts
 
+    def set_timeout(self, seconds):
+        """How long a collective of this hub waits for its slowest rank (``bench.py`` raises it around its child-process
+        legs, whose own time-outs are longer than the default of a set-up exchange); returns the previous value."""
+        before, self.timeout = self.timeout, float(seconds)
+        for conn in self.peers.values():
+            conn.settimeout(self.timeout)
+        return before
+
     def close(self):
         for conn in self.peers.values():
             try:

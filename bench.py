@@ -946,6 +946,8 @@ def preflight_child(args):
         ok = nat and not nat_p and err < 1e-12 and redo_n == redo_p and np.isfinite(Hn).all()
         out[name] = {"ok": bool(ok), "max_rel_diff_H": err, "native_comm": nat, "lazy_redos": redo_n, "n_ghost_rank": ghosts}
         out["ok"] = out["ok"] and bool(ok)
+    if os.environ.get("AKS_BENCH_INJECT_PREFLIGHT_FAILURE") == "1" and ranks.rank == ranks.world - 1:
+        out["ok"], out["injected"] = False, "AKS_BENCH_INJECT_PREFLIGHT_FAILURE=1: what the ranks do when this check fails"
     out["ok"] = ranks.all_ok(out["ok"])
     out["runtime"] = runtime_block()
     ranks.close()
@@ -1041,7 +1043,8 @@ def pre_gpu_legs(args, ranks):
     measuring one of them:
 
       preflight       the C-driven collective path against the chained one on two small problems; if it fails on any
-                      rank the measurement below runs with AKS_DIST_PATH=python (all ranks agree through the rendezvous);
+                      rank (all ranks learn it through the rendezvous) the measurement is handed to the torch backend,
+                      see ``measure_on_the_torch_backend_instead``;
       allreduce_probe ncclAllReduce and the one-shot kernel timed in isolation, side by side;
       oneshot         the headline solve with AKS_ALLREDUCE=oneshot;
       graph_replay    the headline solve with AKS_GRAPH=1 AKS_GRAPH_COMM=exchange: after the eager (probed) restarts, the same
@@ -1054,6 +1057,16 @@ def pre_gpu_legs(args, ranks):
     ``value`` of the line stays the DEFAULT configuration's (this backend, ncclAllReduce), measured by the ranks themselves
     afterwards.  Returns {leg: report}."""
     hub = ranks.comm._hub
+    # a rank whose child ended at once waits here for the ranks whose children run into their time-outs: the rendezvous must
+    # outwait the longest leg (its default is sized for set-up exchanges), or one crashed child would cost the whole run
+    patience = hub.set_timeout(max(LEG_TIMEOUT_S.values()) + 120)
+    try:
+        return _pre_gpu_legs(args, ranks, hub)
+    finally:
+        hub.set_timeout(patience)
+
+
+def _pre_gpu_legs(args, ranks, hub):
     world, rank = ranks.world, ranks.rank
     host = os.environ.get("MASTER_ADDR", "127.0.0.1")
     names = ["preflight", "allreduce_probe", "oneshot", "graph_replay", "torch_backend", "one_gpu_shard"]
@@ -1107,11 +1120,40 @@ def pre_gpu_legs(args, ranks):
             report["all_ranks_ok"] = bool(ok_everywhere)
             report["seconds"] = round(time.perf_counter() - t0, 1)
             out[name] = report
-    pre = out.get("preflight")
-    if pre is not None and not pre["all_ranks_ok"]:
-        os.environ["AKS_DIST_PATH"] = "python"
-        sys.stderr.write(f"bench.py: rank {rank}: preflight of the C-driven collective path failed ({pre}); using AKS_DIST_PATH=python\n")
     return out
+
+
+def measure_on_the_torch_backend_instead(args, argv, ranks, legs):
+    """The default configuration's collective path failed its preflight on some rank: a measurement on it would at best be the
+    host-staged chained path (every ghost exchange through the TCP rendezvous: seconds per SpMV at n = 10M) -- not a number
+    worth having.  The ranks have not touched their GPUs yet, so each starts ONE child that runs this same command on the
+    torch interop backend -- its C-driven path if the ``torch_backend`` leg just showed it working, else the Python-chained
+    stages over torch.distributed -- and rank 0 forwards that child's line, with the legs and the reason beside it.  The
+    driver's first multi-GPU record must not be empty because ONE configuration does not work there."""
+    pre = legs["preflight"]
+    torch_leg = legs.get("torch_backend") or {}
+    chained = "error" in torch_leg or not torch_leg.get("all_ranks_ok", False)
+    sys.stderr.write(f"bench.py: rank {ranks.rank}: preflight of the default configuration failed ({pre.get('error') or pre}); "
+                     f"measuring on the torch backend ({'Python-chained' if chained else 'C-driven'} path)\n")
+    ranks.comm._hub.gather(b"leaving")               # every rank has its verdict: the rendezvous can go
+    ranks.comm.close()
+    env = dict(os.environ, AKS_HOST_ALLOC="torch", AKS_BENCH_PREFLIGHT="0")
+    env.pop("AKS_RENDEZVOUS", None)
+    if chained:
+        env["AKS_DIST_PATH"] = "python"
+    proc = subprocess.run([sys.executable, os.path.abspath(sys.argv[0])] + argv, env=env, stdout=subprocess.PIPE, text=True)
+    if ranks.rank == 0:
+        line = next((ln for ln in reversed(proc.stdout.splitlines()) if ln.startswith("{")), None)
+        if line is None:
+            sys.stderr.write("bench.py: the torch-backend measurement printed no line either\n")
+            return proc.returncode or 1
+        out = json.loads(line)
+        out["legs"] = {k: v for k, v in legs.items() if k != "preflight"}
+        out["config"]["native_preflight"] = pre
+        out["config"]["fallback"] = ("the default configuration (HIP-runtime backend, dist.HostComm) failed its preflight; this line was "
+                                     "measured on the torch interop backend, " + ("Python-chained stages" if chained else "C-driven path"))
+        emit(json.dumps(out))
+    return proc.returncode
 
 
 # ------------------------------------------------------------------------------------------- rank main
@@ -1262,6 +1304,8 @@ def run_rank(args, argv):
     if (ranks.kind == "hip" and ranks.comm is not None and args.leg is None and "AKS_DIST_PATH" not in os.environ
             and os.environ.get("AKS_BENCH_PREFLIGHT", "1") != "0"):
         legs = pre_gpu_legs(args, ranks)
+        if "preflight" in legs and not legs["preflight"]["all_ranks_ok"]:
+            return measure_on_the_torch_backend_instead(args, argv, ranks, legs)
     ranks.attach_gpu()
     telemetry = calibration = None
     if rank == 0 and GPU and args.leg is None and not args.no_device_state:

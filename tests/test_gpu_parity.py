@@ -1226,6 +1226,38 @@ def test_bench_multi_rank_line_without_torch(amd, launcher):
           "device", out["device"]["before"])
 
 
+def test_bench_falls_back_to_the_torch_backend_when_its_preflight_fails(amd):
+    """The first multi-GPU record must not be empty because ONE configuration does not work on that machine: when the preflight
+    of the default configuration fails on any rank (here: injected on the last rank), no rank has touched its GPU yet, so
+    each hands the measurement to a child on the torch interop backend -- its C-driven path, which the ``torch_backend`` leg
+    has just shown to work -- and rank 0 forwards that line with the legs and the reason beside it."""
+    import json
+    import subprocess
+    import sys
+
+    from test_host_logic import ROOT
+
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    env = dict(os.environ, AKS_LIB_PATH=os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"), AKS_BENCH_INJECT_PREFLIGHT_FAILURE="1",
+               AKS_BENCH_SKIP_LEGS="allreduce_probe,oneshot,graph_replay,one_gpu_shard", AKS_COMM_OVER_GLOO="1", AKS_BENCH_BACKEND="gloo",
+               AKS_GRAPH="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AKS_HOST_ALLOC", "AKS_COMM", "AKS_ALLREDUCE", "AKS_DIST_PATH"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "300000", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-workloads"], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    pre = out["config"]["native_preflight"]
+    assert pre["all_ranks_ok"] is False and pre["random"]["ok"], pre                 # (the check itself was fine: the failure is the injected one)
+    assert "torch interop backend, C-driven path" in out["config"]["fallback"], out["config"].get("fallback")
+    assert out["runtime"]["backend"] == "torch" and out["n_gpus"] == 2 and out["value"] > 0 and "issued from C" in out["config"]["path"]
+    assert set(out["legs"]) == {"torch_backend"} and out["legs"]["torch_backend"]["all_ranks_ok"], out["legs"]
+    assert "measuring on the torch backend" in res.stderr
+
+
 def test_bench_preflight_probes_both_allreduce_paths(amd):
     """``bench.py`` with a communicator (here: a forced one-rank group, the only kind a one-GPU box can make with the REAL
     RCCL) runs its legs in child processes before it touches the GPU: the C-driven path against the chained one, the two
