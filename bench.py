@@ -111,6 +111,7 @@ def parse_args(argv=None):
     ap.add_argument("--probe-every", type=int, default=1,
                     help="record the HIP-event pairs around the SpMV / Gram-Schmidt launches in every K-th restart of "
                          "the timed region (1 = every restart)")
+    ap.add_argument("--exchange-probe-bytes", type=int, default=8 << 20, help="(internal) bytes per peer of the exchange probe")
     ap.add_argument("--leg", choices=["measure", "cpu", "preflight", "allreduce_probe", "solve"], default=None,
                     help="(internal) run one extra leg and print its JSON object")
     return ap.parse_args(argv)
@@ -578,17 +579,19 @@ def _measure(args, comm, world, rank):
 # which term misses it.  Its one-GPU terms are MEASURED in the same invocation (round 6; they were constants copied from
 # BENCH_r04 before): the "one_gpu_shard" leg runs a shard-sized problem -- n / N rows of the same generator, one GPU, the
 # same restart -- on rank 0's GPU before the ranks touch theirs, the all-reduce latency comes from the same invocation's
-# probe of the default path; only the link rate stays an assumption, and says so.
-MODEL_LINK_GBS = 50.0          # per direction per xGMI link, as DESIGN 4 assumes (the one term no one-GPU box can measure)
+# probe of the default path, and the rate of the exchange's transport from the same probe (a grouped send / recv to all peers at
+# once, message size = the headline's): on a multi-GPU node no term of the model is assumed any more.
+MODEL_LINK_GBS = 50.0          # fall-back: per direction per xGMI link, as DESIGN 4 assumed before there was a probe
 MODEL_ALLREDUCE_US = 25.0      # fall-back when the invocation's probe has no number
 
 
-def predicted_restarts_per_s(world, m, p, ghost_bytes_per_spmv, collectives_per_step, shard, allreduce_us=None):
+def predicted_restarts_per_s(world, m, p, ghost_bytes_per_spmv, collectives_per_step, shard, allreduce_us=None, link_GBs=None):
     """restarts/s of the headline workload on ``world`` GPUs by DESIGN section 4's model.  ``shard``: the one-GPU leg of this
     invocation on n / world rows (``spmv_avg_ms``, ``ortho_avg_ms_per_step``, ``ms_per_step``)."""
     steps = m - p
     ar_us = float(allreduce_us) if allreduce_us else MODEL_ALLREDUCE_US
-    exch_ms = ghost_bytes_per_spmv / (MODEL_LINK_GBS * 1e9 * max(world - 1, 1)) * 1e3 if world > 1 else 0.0
+    link = float(link_GBs) if link_GBs else MODEL_LINK_GBS
+    exch_ms = ghost_bytes_per_spmv / (link * 1e9 * max(world - 1, 1)) * 1e3 if world > 1 else 0.0
     reductions = max(int(collectives_per_step) - 1, 0) if world > 1 else 0
     kernels_ms = shard["spmv_avg_ms"] + shard["ortho_avg_ms_per_step"]
     # compression + host Schur step of the shard's restart, from the EAGER restart time (a sharded expansion is launched eagerly)
@@ -597,7 +600,9 @@ def predicted_restarts_per_s(world, m, p, ghost_bytes_per_spmv, collectives_per_
     restart_ms = steps * step_ms + rest_ms
     return 1e3 / restart_ms, {"exchange_ms_per_spmv": round(exch_ms, 4), "kernels_ms_per_step": round(kernels_ms, 4),
                               "reductions_per_step": reductions, "compression_plus_host_ms": round(rest_ms, 4),
-                              "restart_ms": round(restart_ms, 3), "link_GBs_per_direction_ASSUMED": MODEL_LINK_GBS,
+                              "restart_ms": round(restart_ms, 3), "link_GBs_per_direction": round(link, 2),
+                              "link_rate_source": ("this invocation's exchange probe (grouped send / recv to all peers at once)"
+                                                   if link_GBs else "ASSUMED (no probe in this invocation)"),
                               "allreduce_us": round(ar_us, 2),
                               "allreduce_us_source": "this invocation's probe (ncclAllReduce)" if allreduce_us else "assumed",
                               "one_gpu_terms": "measured in this invocation (one_gpu_shard leg)"}
@@ -1000,6 +1005,36 @@ def allreduce_probe_child(args):
         out[name] = {"path": "one-shot mailbox exchange" if path == 1 else "ncclAllReduce", "why_not_oneshot": why.value.decode() or None,
                      "sum_ok": ok, "device_us_per_call": round(best, 2)}
     out["slowest_rank_us_per_call"] = {k: round(ranks.comm.max_float(out[k]["device_us_per_call"]), 2) for k in ("nccl", "oneshot")}
+    # ... and what the ghost exchange's transport delivers: every rank sends `per_peer` bytes to every other rank in ONE
+    # grouped send / recv (aks_comm_alltoallv, the form aks_shard_apply issues), 5 back-to-back exchanges between two events.
+    # per_peer ~ what a rank of the headline workload sends one peer per SpMV.  On a multi-GPU node this is the per-direction
+    # link rate the scaling model otherwise has to ASSUME.
+    world, rank = ranks.world, ranks.rank
+    if world > 1:
+        per_peer = int(min(max(args.exchange_probe_bytes, 1 << 20), 128 << 20)) & ~255
+        send = mem.zeros(world * per_peer // 8, mem.f64, mem.as_device(None))
+        recv = mem.empty(world * per_peer // 8, mem.f64, mem.as_device(None))
+        offs = (C.c_int64 * world)(*[r * per_peer for r in range(world)])
+        sizes = (C.c_int64 * world)(*[per_peer] * world)
+        handle, stream = comm.native(), C.c_void_p(mem.stream_ptr())
+
+        def exchange():
+            _hip.check(lib.aks_comm_alltoallv(handle, C.c_void_p(send.data_ptr()), offs, sizes, C.c_void_p(recv.data_ptr()), offs, sizes, stream),
+                       "aks_comm_alltoallv")
+
+        exchange()
+        mem.synchronize()
+        comm.barrier()
+        e0, e1 = mem.Event(enable_timing=True), mem.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            exchange()
+        e1.record()
+        e1.synchronize()
+        ms = comm.max_float(e0.elapsed_time(e1) / 5)
+        out["exchange_probe"] = {"bytes_per_peer": per_peer, "peers": world - 1, "slowest_rank_ms": round(ms, 4),
+                                 "GBs_per_peer_per_direction": round(per_peer / (ms * 1e-3) / 1e9, 2),
+                                 "what": "one grouped ncclSend / ncclRecv to and from every other rank at once (aks_comm_alltoallv)"}
     out["runtime"] = runtime_block()
     ranks.close()
     print(json.dumps(out), flush=True)
@@ -1031,6 +1066,17 @@ def solve_leg_child(args):
     ranks.close()
     print(json.dumps(out), flush=True)
     return 0
+
+
+def ghost_bytes_per_peer(args, world):
+    """Bytes a rank of the HEADLINE workload sends one peer per SpMV (uniformly random columns: a rank references
+    n (N-1)/N (1 - exp(-per_row / N)) remote entries of 16 bytes, spread evenly over its N - 1 peers); 8 MiB for other workloads."""
+    if world < 2 or args.workload != "random" or args.matrix is not None:
+        return 8 << 20
+    import math
+
+    remote = args.n * (world - 1) / world * (1.0 - math.exp(-args.per_row / world))
+    return int(16 * remote / (world - 1))
 
 
 LEG_TIMEOUT_S = {"preflight": 240, "allreduce_probe": 150, "oneshot": 300, "graph_replay": 300, "torch_backend": 480, "one_gpu_shard": 300}
@@ -1084,7 +1130,7 @@ def _pre_gpu_legs(args, ranks, hub):
         solve += ["--matrix", args.matrix]
     plan = {
         "preflight": (["--gpus", str(world), "--leg", "preflight"], {}),
-        "allreduce_probe": (["--gpus", str(world), "--leg", "allreduce_probe"], {}),
+        "allreduce_probe": (["--gpus", str(world), "--leg", "allreduce_probe", "--exchange-probe-bytes", str(ghost_bytes_per_peer(args, world))], {}),
         "oneshot": (solve, {"AKS_ALLREDUCE": "oneshot"}),
         "graph_replay": (solve, {"AKS_GRAPH": "1", "AKS_GRAPH_COMM": "exchange"}),
         "torch_backend": (solve, {"AKS_HOST_ALLOC": "torch"}),
@@ -1176,8 +1222,9 @@ def model_fields(res, args, world, legs=None):
         return {}
     probe = (legs or {}).get("allreduce_probe") or {}
     ar_us = (probe.get("slowest_rank_us_per_call") or {}).get("nccl")
+    link = (probe.get("exchange_probe") or {}).get("GBs_per_peer_per_direction")
     rate, parts = predicted_restarts_per_s(world, res["m"], res["p"], ex["ghost_bytes_received_per_spmv_rank0"],
-                                           ex["collectives_per_arnoldi_step"], shard, ar_us)
+                                           ex["collectives_per_arnoldi_step"], shard, ar_us, link)
     return {"predicted_restarts_per_s": round(rate, 2), "prediction_model": parts}
 
 

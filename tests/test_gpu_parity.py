@@ -1209,12 +1209,15 @@ def test_bench_multi_rank_line_without_torch(amd, launcher):
     probe = legs["allreduce_probe"]
     assert probe["nccl"]["sum_ok"] and probe["oneshot"]["sum_ok"] and probe["oneshot"]["path"] == "one-shot mailbox exchange", probe
     assert set(probe["slowest_rank_us_per_call"]) == {"nccl", "oneshot"}
+    xp = probe["exchange_probe"]       # the exchange's transport, message size = what a rank of this workload sends one peer
+    assert xp["peers"] == 1 and xp["GBs_per_peer_per_direction"] > 0 and 1 << 20 <= xp["bytes_per_peer"] <= 128 << 20, xp
     shard = legs["one_gpu_shard"]
     assert shard["n"] == 200000 and shard["spmv_avg_ms"] > 0 and shard["ortho_avg_ms_per_step"] > 0, shard
     # ---- the model next to the measurement, from THIS invocation's terms
     model = out["prediction_model"]
     assert out["predicted_restarts_per_s"] > 0 and model["one_gpu_terms"].startswith("measured")
     assert model["allreduce_us_source"].startswith("this invocation") and model["allreduce_us"] == probe["slowest_rank_us_per_call"]["nccl"]
+    assert model["link_rate_source"].startswith("this invocation") and model["link_GBs_per_direction"] == xp["GBs_per_peer_per_direction"]
     assert abs(model["kernels_ms_per_step"] - (shard["spmv_avg_ms"] + shard["ortho_avg_ms_per_step"])) < 1e-3
     # ---- device state and calibration around the timed region
     assert out["calibration"]["stream_copy_GBs_before"] > 500 and out["calibration"]["stream_copy_GBs_after"] > 500, out["calibration"]
