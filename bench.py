@@ -1079,7 +1079,9 @@ def ghost_bytes_per_peer(args, world):
     return int(16 * remote / (world - 1))
 
 
-LEG_TIMEOUT_S = {"preflight": 240, "allreduce_probe": 150, "oneshot": 300, "graph_replay": 300, "torch_backend": 480, "one_gpu_shard": 300}
+LEG_TIMEOUT_S = {"preflight": 180, "allreduce_probe": 120, "oneshot": 240, "graph_replay": 240, "torch_backend": 360, "one_gpu_shard": 240}
+LEGS_BUDGET_S = 600.0          # all legs together (AKS_BENCH_LEGS_BUDGET_S): once spent, the remaining legs are skipped -- the
+                               # measurement itself must still fit the time the driver gives one bench run
 
 
 def pre_gpu_legs(args, ranks):
@@ -1136,8 +1138,16 @@ def _pre_gpu_legs(args, ranks, hub):
         "torch_backend": (solve, {"AKS_HOST_ALLOC": "torch"}),
     }
     out = {}
+    budget, t_legs = float(os.environ.get("AKS_BENCH_LEGS_BUDGET_S", LEGS_BUDGET_S)), time.perf_counter()
     for name in names:
         if name in skip or (name == "allreduce_probe" and os.environ.get("AKS_BENCH_ALLREDUCE_PROBE", "1") == "0"):
+            continue
+        # rank 0's clock decides for all whether there is time for another leg (a leg that ran into its time-out -- a hang on
+        # this machine -- must not be followed by four more)
+        go = hub.gather(b"go" if time.perf_counter() - t_legs < budget else b"stop")[0] == b"go"
+        if not go:
+            if name != "preflight":
+                out[name] = {"skipped": f"the legs' budget of {budget:.0f} s was spent", "all_ranks_ok": False}
             continue
         t0 = time.perf_counter()
         if name == "one_gpu_shard":

@@ -1238,6 +1238,30 @@ def test_bench_multi_rank_line_without_torch(amd, launcher):
           "device", out["device"]["before"])
 
 
+def test_bench_skips_its_legs_once_their_budget_is_spent(amd):
+    """The legs run before the measurement and must not eat the time the driver gives one bench run: a budget
+    (AKS_BENCH_LEGS_BUDGET_S, rank 0's clock decides for all ranks) -- here spent from the start -- skips them, says so in the
+    line, and the measurement on the default configuration follows as always."""
+    import json
+    import subprocess
+    import sys
+
+    from test_host_logic import ROOT
+
+    env = dict(os.environ, AKS_LIB_PATH=os.path.join(ROOT, "tests", "mock_rccl", "libarnoldi_hip.so"), AKS_BENCH_LEGS_BUDGET_S="0",
+               AKS_GRAPH="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AKS_HOST_ALLOC", "AKS_COMM", "AKS_ALLREDUCE", "AKS_DIST_PATH"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "300000", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-workloads"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["value"] > 0 and out["runtime"]["backend"] == "hip" and "issued from C" in out["config"]["path"]
+    assert set(out["legs"]) == {"allreduce_probe", "oneshot", "graph_replay", "torch_backend", "one_gpu_shard"}
+    assert all("budget" in leg["skipped"] for leg in out["legs"].values()), out["legs"]
+    assert "predicted_restarts_per_s" not in out and out["config"]["native_preflight"] is None
+
+
 def test_bench_falls_back_to_the_torch_backend_when_its_preflight_fails(amd):
     """The first multi-GPU record must not be empty because ONE configuration does not work on that machine: when the preflight
     of the default configuration fails on any rank (here: injected on the last rank), no rank has touched its GPU yet, so
