@@ -1179,6 +1179,18 @@ def _pre_gpu_legs(args, ranks, hub):
     return out
 
 
+def compare_legs_with_default(legs, mine):
+    """The solve legs against the default configuration's own measurement: the projected matrix of the first expansion
+    (``h_check``: Frobenius norm and absolute sum), relative difference.  Rounding level is expected -- a collective sums in
+    another order than the one-shot kernel --; anything larger, or a non-finite H, is a leg that solved something else."""
+    for leg in legs.values():
+        theirs = leg.get("h_check") if isinstance(leg, dict) else None
+        if theirs:
+            leg["h_vs_default_rel_diff"] = max(abs(theirs[k] - mine[k]) / max(abs(mine[k]), 1e-300) for k in ("fro", "abs_sum"))
+            leg["h_agrees_with_default"] = bool(theirs["finite"] and mine["finite"] and leg["h_vs_default_rel_diff"] < 1e-10)
+    return legs
+
+
 def measure_on_the_torch_backend_instead(args, argv, ranks, legs):
     """The default configuration's collective path failed its preflight on some rank: a measurement on it would at best be the
     host-staged chained path (every ghost exchange through the TCP rendezvous: seconds per SpMV at n = 10M) -- not a number
@@ -1390,15 +1402,7 @@ def run_rank(args, argv):
             out["calibration"], out["device"] = calibration, telemetry
         out["h_check"] = res["h_check"]
         if legs:
-            out["legs"] = {k: v for k, v in legs.items() if k != "preflight"}
-            # the solve legs against THIS measurement: the projected matrix of the first expansion, relative difference
-            # (rounding level: the collective sums in another order than the one-shot kernel; anything larger is a broken path)
-            mine = res["h_check"]
-            for leg in out["legs"].values():
-                theirs = leg.get("h_check") if isinstance(leg, dict) else None
-                if theirs:
-                    leg["h_vs_default_rel_diff"] = max(abs(theirs[k] - mine[k]) / max(abs(mine[k]), 1e-300) for k in ("fro", "abs_sum"))
-                    leg["h_agrees_with_default"] = bool(theirs["finite"] and mine["finite"] and leg["h_vs_default_rel_diff"] < 1e-10)
+            out["legs"] = compare_legs_with_default({k: v for k, v in legs.items() if k != "preflight"}, res["h_check"])
             out.update(model_fields(res, args, world, legs))
 
     # ---- N > 1: the workloads that can scale, through the same ranks (no child processes once the GPUs are in use)
