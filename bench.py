@@ -1378,8 +1378,10 @@ def run_rank(args, argv):
     ranks.attach_gpu()
     telemetry = calibration = None
     if rank == 0 and GPU and args.leg is None and not args.no_device_state:
-        telemetry = {"before": device_telemetry(ranks.local_rank)}
+        # (the calibration first: both samples of the device state are then taken right behind 50 streaming launches -- an idle
+        # GPU parks at ~160 MHz, which says nothing about the clocks the timed region will run at)
         calibration = {"stream_copy_GBs_before": stream_copy_calibration()}
+        telemetry = {"before": device_telemetry(ranks.local_rank)}
 
     res = measure(args, ranks.comm, world, rank)
 
