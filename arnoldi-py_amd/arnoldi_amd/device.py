@@ -26,7 +26,14 @@ def _require_gpu(device):
             "(there is no CPU fallback)"
         )
     device = mem.as_device(device)
-    _hip.device_init(device.index if device.index is not None else mem.current_device())
+    current = mem.current_device()
+    if device.index is not None and device.index != current:
+        # Kernels are launched on the CURRENT device's stream (one process per GPU: SURVEY 8(b), 8(e)); buffers on another
+        # device would be handed to kernels that run here -- a fault at best.  Refuse, and say what to do.
+        raise _hip.HipLibraryError(
+            f"device {device.index} was asked for but device {current} is current: make it current first "
+            f"(arnoldi_amd.mem.set_device({device.index}); one process drives one GPU) -- a solve runs on the current device's stream")
+    _hip.device_init(device.index if device.index is not None else current)
     return device
 
 

@@ -474,3 +474,18 @@ def test_rendezvous_finds_its_port_when_the_first_one_is_taken(monkeypatch):
     with pytest.raises(RuntimeError, match="AKS_RENDEZVOUS=host:port"):
         _Hub(0, 2, "127.0.0.1", busy.getsockname()[1], 2.0)
     busy.close()
+
+
+def test_a_device_that_is_not_current_is_refused(monkeypatch):
+    """A solve launches on the CURRENT device's stream (one process per GPU).  Asking for another device used to allocate
+    there and launch here; now it is refused with the remedy in the message (and the current / default device still passes)."""
+    from arnoldi_amd import _hip, device as dev, mem
+
+    inited = []
+    monkeypatch.setattr(mem, "gpu_available", lambda: True)
+    monkeypatch.setattr(mem, "current_device", lambda: 0)
+    monkeypatch.setattr(mem, "as_device", lambda d: type("D", (), {"index": d})())
+    monkeypatch.setattr(_hip, "device_init", lambda i: inited.append(i))
+    with pytest.raises(_hip.HipLibraryError, match=r"make it current first \(arnoldi_amd.mem.set_device\(1\)"):
+        dev._require_gpu(1)
+    assert dev._require_gpu(0).index == 0 and dev._require_gpu(None).index is None and inited == [0, 0]
