@@ -720,7 +720,7 @@ def run_child(extra_argv, timeout_s):
     try:
         cp = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
     except subprocess.TimeoutExpired:
-        return {"error": f"timed out after {timeout_s} s"}
+        return {"error": f"timed out after {timeout_s:.0f} s"}
     for ln in reversed(cp.stdout.splitlines()):
         if ln.startswith("{"):
             try:
@@ -889,6 +889,18 @@ def stream_copy_calibration(launches=50, mib=256):
 
 
 # ------------------------------------------------------------------------------------------- legs of the N > 1 line
+def struct_pack_double(x):
+    import struct
+
+    return struct.pack("<d", float(x))
+
+
+def struct_unpack_double(b):
+    import struct
+
+    return struct.unpack("<d", b)[0]
+
+
 def run_own_child(leg_argv, env, timeout_s):
     """One child process of THIS rank (``bench.py <leg_argv>``); its last JSON line, or {"error": ...}.  Started before
     the rank has touched its GPU -- a fresh child, never a re-exec of a process that has initialised the GPU."""
@@ -903,7 +915,7 @@ def run_own_child(leg_argv, env, timeout_s):
     except subprocess.TimeoutExpired:
         proc.kill()
         proc.communicate()
-        return {"error": f"timed out after {timeout_s} s"}
+        return {"error": f"timed out after {timeout_s:.0f} s"}
 
 
 def preflight_child(args):
@@ -1080,8 +1092,9 @@ def ghost_bytes_per_peer(args, world):
 
 
 LEG_TIMEOUT_S = {"preflight": 180, "allreduce_probe": 120, "oneshot": 240, "graph_replay": 240, "torch_backend": 360, "one_gpu_shard": 240}
-LEGS_BUDGET_S = 600.0          # all legs together (AKS_BENCH_LEGS_BUDGET_S): once spent, the remaining legs are skipped -- the
-                               # measurement itself must still fit the time the driver gives one bench run
+LEGS_BUDGET_S = 420.0          # all legs together (AKS_BENCH_LEGS_BUDGET_S), a HARD cap: a leg's time-out is cut to what is left of
+                               # it, and with less than 20 s left the remaining legs are skipped -- the measurement itself must
+                               # still fit the time the driver gives one bench run
 
 
 def pre_gpu_legs(args, ranks):
@@ -1144,11 +1157,13 @@ def _pre_gpu_legs(args, ranks, hub):
             continue
         # rank 0's clock decides for all whether there is time for another leg (a leg that ran into its time-out -- a hang on
         # this machine -- must not be followed by four more)
-        go = hub.gather(b"go" if time.perf_counter() - t_legs < budget else b"stop")[0] == b"go"
-        if not go:
+        left = hub.gather(struct_pack_double(budget - (time.perf_counter() - t_legs)))[0]
+        left = struct_unpack_double(left)
+        if left < 20.0:
             if name != "preflight":
                 out[name] = {"skipped": f"the legs' budget of {budget:.0f} s was spent", "all_ranks_ok": False}
             continue
+        leg_timeout = min(float(LEG_TIMEOUT_S[name]), left)
         t0 = time.perf_counter()
         if name == "one_gpu_shard":
             if not (world > 1 and args.workload == "random" and args.matrix is None):
@@ -1159,14 +1174,14 @@ def _pre_gpu_legs(args, ranks, hub):
                 env.pop("AKS_FORCE_COMM", None)
                 report = run_own_child(["--gpus", "1", "--rows", str(max(args.n // world, 1000)), "--per-row", str(args.per_row),
                                         "--nev", str(args.nev), "--max-dim", str(args.max_dim), "--steps", steps, "--warmup",
-                                        warmup, "--leg", "measure"], env, LEG_TIMEOUT_S[name])
+                                        warmup, "--leg", "measure"], env, leg_timeout)
             ok_everywhere = all(b == b"y" for b in hub.gather(b"y"))
         else:
             leg_argv, extra = plan[name]
             env = dict(base_env, MASTER_PORT=str(ports[name]), AKS_RENDEZVOUS=f"{host}:{ports[name]}", **extra)
             if world == 1:
                 env["AKS_FORCE_COMM"] = "1"
-            report = run_own_child(leg_argv, env, LEG_TIMEOUT_S[name])
+            report = run_own_child(leg_argv, env, leg_timeout)
             mine_ok = "error" not in report and report.get("ok", True) is not False
             votes = [b == b"y" for b in hub.gather(b"y" if mine_ok else b"n")]
             ok_everywhere = all(votes)

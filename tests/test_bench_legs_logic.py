@@ -46,7 +46,7 @@ def _run(monkeypatch, child, world=2, extra_env=None, argv=()):
                    next((k for k in ("AKS_ALLREDUCE", "AKS_GRAPH_COMM", "AKS_HOST_ALLOC") if k in env and leg_argv[leg_argv.index("--leg") + 1] == "solve"), None),
                    leg_argv[leg_argv.index("--leg") + 1]))
         with lock:
-            started.append((tls.rank, leg, list(leg_argv), dict(env)))
+            started.append((tls.rank, leg, list(leg_argv), dict(env, __timeout__=timeout_s)))
         return child(tls.rank, leg, leg_argv, env)
 
     monkeypatch.setattr(bench, "run_own_child", fake_child)
@@ -130,6 +130,14 @@ def test_the_legs_stop_when_their_budget_is_spent(monkeypatch):
         assert "preflight" not in legs[r] and all("budget" in leg["skipped"] for leg in legs[r].values()) and len(legs[r]) == 5
     legs, started = _run(monkeypatch, _ok_child, extra_env={"AKS_BENCH_SKIP_LEGS": "graph_replay,torch_backend", "AKS_BENCH_LEGS_BUDGET_S": "600"})
     assert {leg for _, leg, _, _ in started} == {"preflight", "allreduce_probe", "oneshot", "one_gpu_shard"}
+    assert {leg: env["__timeout__"] for _, leg, _, env in started} == {k: float(bench.LEG_TIMEOUT_S[k]) for k in ("preflight", "allreduce_probe", "oneshot", "one_gpu_shard")}
+    # the budget is a hard cap: no child may run longer than what is left of it (rank 0's clock, the same number on all ranks)
+    legs, started = _run(monkeypatch, _ok_child, extra_env={"AKS_BENCH_SKIP_LEGS": "", "AKS_BENCH_LEGS_BUDGET_S": "100"})
+    assert len(started) == 11 and all(20.0 <= env["__timeout__"] <= 100.0 for _, _, _, env in started)
+    per_leg = {}
+    for rank, leg, _, env in started:
+        per_leg.setdefault(leg, set()).add(env["__timeout__"])
+    assert all(len(v) == 1 for v in per_leg.values()), per_leg
 
 
 def test_legs_are_checked_against_the_default_and_feed_the_model(monkeypatch):
